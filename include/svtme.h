@@ -1,0 +1,217 @@
+/*
+ * svtme.h - C ABI of the MI355X open-loop motion-estimation engine.
+ *
+ * The engine replaces, at picture granularity, the body of the 64x64-block loop of SVT-AV1's
+ * motion_estimation_kernel() (Source/Lib/Encoder/Codec/EbMotionEstimationProcess.c:750-846): for
+ * every 64x64 block (b64) and every searched reference it runs init_me_hme_data, hme_b64,
+ * hme_prune_ref_and_adjust_sr and integer_search_b64 (EbMotionEstimation.c:2868, 2337, 2373, 1286)
+ * on the GPU and hands back exactly the MeContext fields the unchanged host tail (me_prune_ref,
+ * construct_me_candidate_array, compute_distortion, perform_gm_detection) reads.
+ *
+ * Everything in the signatures is plain C: pointers, sizes and POD structs. No HIP or torch types.
+ * All entry points are thread-safe. Return value: 0 on success, a negative svtme_status otherwise.
+ */
+#ifndef SVTME_H
+#define SVTME_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SVTME_MAX_LISTS 2 /* MAX_NUM_OF_REF_PIC_LIST, Source/Lib/Common/Codec/EbDefinitions.h:2431 */
+#define SVTME_MAX_REFS 4 /* MAX_REF_IDX / REF_LIST_MAX_DEPTH, EbDefinitions.h:2448, Source/API/EbSvtAv1Enc.h:27 */
+#define SVTME_PU_COUNT 85 /* SQUARE_PU_COUNT, Source/Lib/Encoder/Codec/EbMotionEstimationLcuResults.h:25 */
+#define SVTME_MAX_SAD_VALUE (128 * 128 * 255) /* MAX_SAD_VALUE, EbMotionEstimation.h:93 */
+
+typedef enum svtme_status {
+    SVTME_OK               = 0,
+    SVTME_ERR_BAD_ARG      = -1, /* maps to EB_ErrorBadParameter */
+    SVTME_ERR_NO_RESOURCES = -2, /* maps to EB_ErrorInsufficientResources */
+    SVTME_ERR_NOT_FOUND    = -3, /* unknown store key / ticket; maps to EB_ErrorUndefined */
+    SVTME_ERR_DEVICE       = -4, /* a HIP call failed; maps to EB_ErrorUndefined */
+    SVTME_ERR_UNSUPPORTED  = -5  /* a control combination the engine does not implement */
+} svtme_status;
+
+/* SearchArea / SearchAreaMinMax, EbMotionEstimationContext.h:304-311 */
+typedef struct svtme_sa {
+    uint16_t width;
+    uint16_t height;
+} svtme_sa;
+typedef struct svtme_sa_minmax {
+    svtme_sa sa_min;
+    svtme_sa sa_max;
+} svtme_sa_minmax;
+
+/*
+ * The per-picture ME controls: the fields of MeContext that signal_derivation_me_kernel_oq()
+ * (EbMotionEstimationProcess.c:430-538) and its setters write, flattened. Field names follow the
+ * reference (MeContext, PreHmeCtrls, MeHmeRefPruneCtrls, MeSrCtrls;
+ * EbMotionEstimationContext.h:279-323, 379-403, 464-472).
+ */
+typedef struct svtme_controls {
+    svtme_sa_minmax me_sa; /* integer search area */
+    svtme_sa_minmax hme_l0_sa; /* total HME level-0 area */
+    svtme_sa        hme_l1_sa;
+    svtme_sa        hme_l2_sa;
+    uint16_t        num_hme_sa_w;
+    uint16_t        num_hme_sa_h;
+    uint8_t         enable_hme_flag;
+    uint8_t         enable_hme_level0_flag;
+    uint8_t         enable_hme_level1_flag;
+    uint8_t         enable_hme_level2_flag;
+    uint8_t         hme_search_method; /* 0 = SUB_SAD_SEARCH, 1 = FULL_SAD_SEARCH (EbDefinitions.h:2044) */
+    uint8_t         me_search_method;
+    /* PreHmeCtrls */
+    uint8_t         prehme_enable;
+    uint8_t         prehme_skip_search_line;
+    uint8_t         prehme_l1_early_exit;
+    uint8_t         reserved0;
+    svtme_sa_minmax prehme_sa_cfg[2];
+    /* MeHmeRefPruneCtrls */
+    uint8_t  enable_me_hme_ref_pruning;
+    uint8_t  protect_closest_refs;
+    uint16_t prune_ref_if_hme_sad_dev_bigger_than_th;
+    uint16_t prune_ref_if_me_sad_dev_bigger_than_th;
+    /* MeSrCtrls */
+    uint8_t  enable_me_sr_adjustment;
+    uint8_t  distance_based_hme_resizing;
+    uint16_t reduce_me_sr_based_on_mv_length_th;
+    uint16_t stationary_hme_sad_abs_th;
+    uint16_t stationary_me_sr_divisor;
+    uint16_t reduce_me_sr_based_on_hme_sad_abs_th;
+    uint16_t me_sr_divisor_for_low_hme_sad;
+    /* misc MeContext controls */
+    uint8_t  reduce_hme_l0_sr_th_min;
+    uint8_t  reduce_hme_l0_sr_th_max;
+    uint8_t  stat_factor; /* host tail only */
+    uint8_t  use_best_unipred_cand_only; /* host tail only */
+    int32_t  prune_me_candidates_th; /* host tail only */
+    uint32_t me_early_exit_th;
+} svtme_controls;
+
+/* Inputs of signal_derivation_me_kernel_oq(): what the preset tables key on. */
+typedef struct svtme_preset_key {
+    int8_t   enc_mode; /* EbEncMode: ENC_MRS (-2) .. ENC_M13 (13) */
+    uint8_t  sc_class1; /* screen-content class */
+    uint8_t  input_resolution; /* EbInputResolution 0..6; see svtme_input_resolution() */
+    uint8_t  reserved;
+    uint32_t frame_rate; /* 16.16 fixed point, scs->static_config.frame_rate */
+} svtme_preset_key;
+
+/*
+ * Restates signal_derivation_me_kernel_oq() (EbMotionEstimationProcess.c:430-538) with
+ * set_me_search_params :154, set_hme_search_params :68, set_prehme_ctrls :385,
+ * set_me_hme_ref_prune_ctrls :241, set_me_sr_adjustment_ctrls :290, and the HME level flags of
+ * signal_derivation_multi_processes_oq() (EbPictureDecisionProcess.c:1797-1814).
+ */
+int svtme_derive_controls(const svtme_preset_key *key, svtme_controls *out);
+
+/* derive_input_resolution(), Source/Lib/Encoder/Codec/EbSequenceControlSet.c:396-415. */
+uint8_t svtme_input_resolution(uint32_t width, uint32_t height);
+
+typedef struct svtme_engine svtme_engine;
+
+typedef struct svtme_config {
+    int32_t  device; /* HIP device ordinal */
+    uint32_t max_width; /* luma; multiples of 8 */
+    uint32_t max_height;
+    uint32_t store_slots; /* capacity of the device picture store (>= references + pictures in flight) */
+    uint32_t max_in_flight; /* pictures submitted but not yet waited for */
+} svtme_config;
+
+/* Replaces nothing in the reference (the reference has no device): engine life cycle. */
+int  svtme_create(const svtme_config *cfg, svtme_engine **out);
+void svtme_destroy(svtme_engine *e);
+
+/*
+ * Device picture store = mirror of EbPaReferenceObject (Source/Lib/Encoder/Codec/EbReferenceObject.h:69-82):
+ * full, quarter and sixteenth resolution 8-bit luma with replicated borders (pads 72 / 32 / 16,
+ * Source/Lib/Encoder/Globals/EbEncHandle.c:1331-1355, 3447-3460).
+ * svtme_store_put uploads the un-padded 8-bit luma (`stride` bytes per row) and builds all three padded
+ * planes on the device: generate_padding (Source/Lib/Common/Codec/EbMcp.c:112-164) and
+ * downsample_filtering_input_picture (EbPictureAnalysisProcess.c:2688-2752). `key` identifies the slot
+ * (the integration uses the EbPaReferenceObject pointer); putting an existing key overwrites it (the
+ * temporal filter rewrites planes, EbTemporalFiltering.c:5169-5217). The host buffer may be reused as
+ * soon as the call returns.
+ */
+int svtme_store_put(svtme_engine *e, uint64_t key, uint64_t picture_number, const uint8_t *luma,
+                    uint32_t stride, uint32_t width, uint32_t height);
+/* Mirrors release_pa_reference_objects (EbReferenceObject.c:298): frees the slot once no submitted
+ * picture still reads it. */
+int svtme_store_release(svtme_engine *e, uint64_t key);
+/* Test/diagnostic read-back of one padded plane (level 0 = sixteenth, 1 = quarter, 2 = full). `dst` must
+ * hold stride*(height + 2*pad) bytes; geometry is returned through the out parameters. */
+int svtme_store_read(svtme_engine *e, uint64_t key, int level, uint8_t *dst, size_t dst_size,
+                     uint32_t *stride, uint32_t *width, uint32_t *height, uint32_t *pad);
+
+/* One picture's ME job: what motion_estimation_kernel() sets on MeContext before the b64 loop
+ * (EbMotionEstimationProcess.c:795-837) plus the pcs/scs fields integer_search_b64 reads. */
+typedef struct svtme_picture {
+    uint64_t cur_key; /* store key of the current picture */
+    uint64_t picture_number; /* pcs->picture_number */
+    uint32_t width; /* input_ptr->width  (== pcs->aligned_width here) */
+    uint32_t height; /* input_ptr->height (== pcs->aligned_height here) */
+    uint8_t  temporal_layer_index;
+    uint8_t  is_used_as_reference_flag;
+    uint8_t  num_of_list_to_search; /* 1 for P, 2 for B */
+    uint8_t  num_of_ref_pic_to_search[SVTME_MAX_LISTS]; /* ref_list{0,1}_count_try */
+    uint8_t  reserved[3];
+    uint64_t ref_key[SVTME_MAX_LISTS][SVTME_MAX_REFS]; /* store keys of pcs->ref_pa_pic_ptr_array */
+    uint64_t ref_picture_number[SVTME_MAX_LISTS][SVTME_MAX_REFS];
+    svtme_controls ctrl;
+} svtme_picture;
+
+/* SearchResults, EbMotionEstimationContext.h:330-337, as left by hme_prune_ref_and_adjust_sr. */
+typedef struct svtme_search_result {
+    int16_t  hme_sc_x;
+    int16_t  hme_sc_y;
+    uint8_t  do_ref;
+    uint8_t  list_i;
+    uint8_t  ref_i;
+    uint8_t  reserved;
+    uint64_t hme_sad;
+} svtme_search_result;
+
+/* Per-b64 outputs, in the layout of the MeContext arrays they are copied into. Pointers are engine-owned
+ * pinned host memory, valid until svtme_picture_done(). n_b64 = ceil(w/64)*ceil(h/64), raster order. */
+typedef struct svtme_results {
+    uint32_t                   n_b64;
+    const uint32_t            *p_sb_best_sad; /* [n_b64][2][4][85], EbMotionEstimationContext.h:367 */
+    const uint32_t            *p_sb_best_mv; /* [n_b64][2][4][85], (y_qpel << 16) | (x_qpel & 0xffff), :368 */
+    const svtme_search_result *search_results; /* [n_b64][2][4] */
+    const uint32_t            *zz_sad; /* [n_b64][2][4], MeContext::zz_sad :471 */
+    const uint32_t            *reduce_me_sr_divisor; /* [n_b64][2][4], :400 */
+} svtme_results;
+
+typedef uint64_t svtme_ticket;
+
+/* Queues the whole picture (all b64 x all references) on the engine's stream and returns at once.
+ * Replaces the per-b64 calls motion_estimation_b64 -> init_me_hme_data / hme_b64 /
+ * hme_prune_ref_and_adjust_sr / integer_search_b64 (EbMotionEstimation.c:2954-2970). */
+int svtme_picture_submit(svtme_engine *e, const svtme_picture *pic, svtme_ticket *ticket);
+/* Blocks until the picture's results are in host memory. */
+int svtme_picture_wait(svtme_engine *e, svtme_ticket ticket, svtme_results *out);
+/* Returns the result buffers of a waited picture to the engine. */
+int svtme_picture_done(svtme_engine *e, svtme_ticket ticket);
+
+/* Device time of the last waited picture's kernels in milliseconds (HIP events on the engine stream):
+ * [0] = HME kernel, [1] = integer-search kernel, [2] = whole picture incl. D2H. Diagnostic only. */
+int svtme_picture_timing(svtme_engine *e, svtme_ticket ticket, float ms[3]);
+
+/* Copies one b64's results into caller arrays shaped like MeContext's
+ * (p_sb_best_sad[2][4][85], p_sb_best_mv[2][4][85], search_results[2][4], zz_sad[2][4],
+ * reduce_me_sr_divisor[2][4]); this is what the shim in motion_estimation_kernel() calls per b64
+ * instead of hme_b64 + integer_search_b64. */
+int svtme_unpack_b64(const svtme_results *res, uint32_t b64_index, uint32_t *p_sb_best_sad,
+                     uint32_t *p_sb_best_mv, svtme_search_result *search_results, uint32_t *zz_sad,
+                     uint32_t *reduce_me_sr_divisor);
+
+const char *svtme_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SVTME_H */

@@ -1,0 +1,538 @@
+/*
+ * ref_driver.c - TEST INFRASTRUCTURE, not part of the product.
+ *
+ * Drives the REAL reference open-loop ME (motion_estimation_b64 and everything below it) over
+ * synthetic pictures and dumps what it computed. Compiled only where /root/reference exists, against the
+ * reference's own headers and objects (see oracle/Makefile, target _ref); nothing of the reference is
+ * copied into this repository. The binary lands in oracle/_ref/ and is used
+ *   - to generate the golden fixtures under tests/golden/ (tests/golden/make_golden.py),
+ *   - to validate the oracle restatement (oracle/me_oracle.c),
+ *   - as the "reference" CPU baseline of bench.py (C control code of the reference + its AVX2 SAD
+ *     kernels, re-pointed below exactly as setup_rtcd_internal would on an AVX2 machine,
+ *     Source/Lib/Encoder/Codec/aom_dsp_rtcd.c:406,417-423).
+ *
+ * It mirrors what motion_estimation_kernel() does around the call
+ * (Source/Lib/Encoder/Codec/EbMotionEstimationProcess.c:698-846): signal derivation, pointing MeContext at
+ * the source block and at the reference planes, then motion_estimation_b64 per 64x64 block.
+ *
+ * Usage: ref_me <job file> <output file>
+ */
+#include <pthread.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <time.h>
+
+#include "EbDefinitions.h"
+#include "EbPictureControlSet.h"
+#include "EbSequenceControlSet.h"
+#include "EbMotionEstimation.h"
+#include "EbMotionEstimationProcess.h"
+#include "EbMotionEstimationContext.h"
+#include "EbPictureBufferDesc.h"
+#include "EbComputeSAD.h"
+#include "aom_dsp_rtcd.h"
+#include "common_dsp_rtcd.h"
+#include "EbMcp.h"
+
+#include "../include/svtme.h"
+#include "ref_dump.h"
+
+/* reference functions without a prototype in an installed header */
+void    setup_common_rtcd_internal(CPU_FLAGS flags);
+uint8_t get_disallow_below_16x16_picture_level(EbEncMode enc_mode, EbInputResolution resolution,
+                                               EB_SLICE slice_type, uint8_t sc_class1,
+                                               uint8_t is_used_as_reference_flag,
+                                               uint8_t temporal_layer_index);
+uint8_t get_enable_me_16x16(EbEncMode enc_mode);
+void    get_max_allocated_me_refs(uint8_t ref_count_used_list0, uint8_t ref_count_used_list1,
+                                  uint8_t *max_ref_to_alloc, uint8_t *max_cand_to_alloc);
+
+/* AVX2 kernels of the reference, compiled stand-alone from
+ * Source/Lib/Encoder/ASM_AVX2/EbComputeSAD_Intrinsic_AVX2.c (prototypes as in aom_dsp_rtcd.h). */
+#ifdef REF_HAVE_AVX2
+void svt_sad_loop_kernel_avx2_intrin(uint8_t *src, uint32_t src_stride, uint8_t *ref, uint32_t ref_stride,
+                                     uint32_t block_height, uint32_t block_width, uint64_t *best_sad,
+                                     int16_t *x_search_center, int16_t *y_search_center,
+                                     uint32_t src_stride_raw, uint8_t skip_search_line,
+                                     int16_t search_area_width, int16_t search_area_height);
+void svt_ext_all_sad_calculation_8x8_16x16_avx2(uint8_t *src, uint32_t src_stride, uint8_t *ref,
+                                                uint32_t ref_stride, uint32_t mv, uint8_t out_8x8,
+                                                uint32_t *p_best_sad_8x8, uint32_t *p_best_sad_16x16,
+                                                uint32_t *p_best_mv8x8, uint32_t *p_best_mv16x16,
+                                                uint32_t p_eight_sad16x16[16][8],
+                                                uint32_t p_eight_sad8x8[64][8], EbBool sub_sad);
+void svt_ext_eight_sad_calculation_32x32_64x64_avx2(uint32_t p_sad16x16[16][8], uint32_t *p_best_sad_32x32,
+                                                    uint32_t *p_best_sad_64x64, uint32_t *p_best_mv32x32,
+                                                    uint32_t *p_best_mv64x64, uint32_t mv,
+                                                    uint32_t p_sad32x32[4][8]);
+void svt_ext_sad_calculation_8x8_16x16_avx2_intrin(uint8_t *src, uint32_t src_stride, uint8_t *ref,
+                                                   uint32_t ref_stride, uint32_t *p_best_sad_8x8,
+                                                   uint32_t *p_best_sad_16x16, uint32_t *p_best_mv8x8,
+                                                   uint32_t *p_best_mv16x16, uint32_t mv,
+                                                   uint32_t *p_sad16x16, uint32_t *p_sad8x8, EbBool sub_sad);
+uint32_t svt_nxm_sad_kernel_helper_avx2(const uint8_t *src, uint32_t src_stride, const uint8_t *ref,
+                                        uint32_t ref_stride, uint32_t height, uint32_t width);
+#endif
+
+#define FULL_PAD 72 /* scs->left_padding etc., Source/Lib/Encoder/Globals/EbEncHandle.c:3447-3460 */
+
+typedef struct Planes {
+    EbPictureBufferDesc full, quarter, sixteenth;
+} Planes;
+
+static void die(const char *msg) {
+    fprintf(stderr, "ref_me: %s\n", msg);
+    exit(2);
+}
+
+static void desc_init(EbPictureBufferDesc *d, uint32_t w, uint32_t h, uint32_t pad) {
+    memset(d, 0, sizeof(*d));
+    d->width     = (uint16_t)w;
+    d->height    = (uint16_t)h;
+    d->max_width = (uint16_t)w;
+    d->max_height = (uint16_t)h;
+    d->origin_x  = (uint16_t)pad;
+    d->origin_y  = (uint16_t)pad;
+    d->origin_bot_y = (uint16_t)pad;
+    d->stride_y  = (uint16_t)(w + 2 * pad);
+    d->bit_depth = EB_8BIT;
+    d->luma_size = (uint32_t)d->stride_y * (h + 2 * pad);
+    d->buffer_y  = (EbByte)calloc(d->luma_size + 64, 1);
+    if (!d->buffer_y) die("out of memory");
+}
+
+/* The reference store of one picture, built with the reference's own functions in the order
+ * picture_analysis_kernel uses them: pad_input_pictures -> generate_padding
+ * (EbPictureAnalysisProcess.c:2754-2764), then downsample_filtering_input_picture (:2688-2752). */
+static void build_planes(Planes *p, const uint8_t *luma, uint32_t w, uint32_t h) {
+    desc_init(&p->full, w, h, FULL_PAD);
+    desc_init(&p->quarter, w >> 1, h >> 1, 32);
+    desc_init(&p->sixteenth, w >> 2, h >> 2, 16);
+    for (uint32_t y = 0; y < h; ++y)
+        memcpy(p->full.buffer_y + (size_t)(y + FULL_PAD) * p->full.stride_y + FULL_PAD, luma + (size_t)y * w, w);
+    generate_padding(p->full.buffer_y, p->full.stride_y, w, h, FULL_PAD, FULL_PAD);
+    downsample_2d(&p->full.buffer_y[p->full.origin_x + p->full.origin_y * p->full.stride_y],
+                  p->full.stride_y, p->full.width, p->full.height,
+                  &p->quarter.buffer_y[p->quarter.origin_x + p->quarter.origin_x * p->quarter.stride_y],
+                  p->quarter.stride_y, 2);
+    generate_padding(p->quarter.buffer_y, p->quarter.stride_y, p->quarter.width, p->quarter.height,
+                     p->quarter.origin_x, p->quarter.origin_y);
+    downsample_2d(&p->quarter.buffer_y[p->quarter.origin_x + p->quarter.origin_y * p->quarter.stride_y],
+                  p->quarter.stride_y, p->quarter.width, p->quarter.height,
+                  &p->sixteenth.buffer_y[p->sixteenth.origin_x + p->sixteenth.origin_x * p->sixteenth.stride_y],
+                  p->sixteenth.stride_y, 2);
+    generate_padding(p->sixteenth.buffer_y, p->sixteenth.stride_y, p->sixteenth.width, p->sixteenth.height,
+                     p->sixteenth.origin_x, p->sixteenth.origin_y);
+}
+
+typedef struct Job {
+    ref_job_header hdr;
+    uint8_t       *frames;
+    ref_job_pic   *pics;
+    Planes        *planes;
+} Job;
+
+typedef struct PicState {
+    SequenceControlSet      *scs;
+    PictureParentControlSet *pcs;
+    MotionEstimationData    *me_data;
+    uint32_t                 n_b64, b64_w, b64_h;
+    uint8_t                 *out; /* ref_pic_dump followed by n_b64 ref_b64_dump */
+} PicState;
+
+static void fill_controls(svtme_controls *c, const MeContext *m) {
+    memset(c, 0, sizeof(*c));
+    c->me_sa.sa_min.width  = m->me_sa.sa_min.width;  c->me_sa.sa_min.height = m->me_sa.sa_min.height;
+    c->me_sa.sa_max.width  = m->me_sa.sa_max.width;  c->me_sa.sa_max.height = m->me_sa.sa_max.height;
+    c->hme_l0_sa.sa_min.width = m->hme_l0_sa.sa_min.width; c->hme_l0_sa.sa_min.height = m->hme_l0_sa.sa_min.height;
+    c->hme_l0_sa.sa_max.width = m->hme_l0_sa.sa_max.width; c->hme_l0_sa.sa_max.height = m->hme_l0_sa.sa_max.height;
+    c->hme_l1_sa.width = m->hme_l1_sa.width; c->hme_l1_sa.height = m->hme_l1_sa.height;
+    c->hme_l2_sa.width = m->hme_l2_sa.width; c->hme_l2_sa.height = m->hme_l2_sa.height;
+    c->num_hme_sa_w = m->num_hme_sa_w; c->num_hme_sa_h = m->num_hme_sa_h;
+    c->enable_hme_flag = m->enable_hme_flag;
+    c->enable_hme_level0_flag = m->enable_hme_level0_flag;
+    c->enable_hme_level1_flag = m->enable_hme_level1_flag;
+    c->enable_hme_level2_flag = m->enable_hme_level2_flag;
+    c->hme_search_method = m->hme_search_method;
+    c->me_search_method  = m->me_search_method;
+    c->prehme_enable = m->prehme_ctrl.enable;
+    if (m->prehme_ctrl.enable) {
+        c->prehme_skip_search_line = m->prehme_ctrl.skip_search_line;
+        c->prehme_l1_early_exit = m->prehme_ctrl.l1_early_exit;
+        for (int i = 0; i < 2; ++i) {
+            c->prehme_sa_cfg[i].sa_min.width  = m->prehme_ctrl.prehme_sa_cfg[i].sa_min.width;
+            c->prehme_sa_cfg[i].sa_min.height = m->prehme_ctrl.prehme_sa_cfg[i].sa_min.height;
+            c->prehme_sa_cfg[i].sa_max.width  = m->prehme_ctrl.prehme_sa_cfg[i].sa_max.width;
+            c->prehme_sa_cfg[i].sa_max.height = m->prehme_ctrl.prehme_sa_cfg[i].sa_max.height;
+        }
+    }
+    c->enable_me_hme_ref_pruning = m->me_hme_prune_ctrls.enable_me_hme_ref_pruning;
+    c->prune_ref_if_hme_sad_dev_bigger_than_th = m->me_hme_prune_ctrls.prune_ref_if_hme_sad_dev_bigger_than_th;
+    c->prune_ref_if_me_sad_dev_bigger_than_th  = m->me_hme_prune_ctrls.prune_ref_if_me_sad_dev_bigger_than_th;
+    if (c->enable_me_hme_ref_pruning) c->protect_closest_refs = m->me_hme_prune_ctrls.protect_closest_refs;
+    c->enable_me_sr_adjustment = m->me_sr_adjustment_ctrls.enable_me_sr_adjustment;
+    if (c->enable_me_sr_adjustment) {
+        c->distance_based_hme_resizing = m->me_sr_adjustment_ctrls.distance_based_hme_resizing;
+        c->reduce_me_sr_based_on_mv_length_th = m->me_sr_adjustment_ctrls.reduce_me_sr_based_on_mv_length_th;
+        c->stationary_hme_sad_abs_th = m->me_sr_adjustment_ctrls.stationary_hme_sad_abs_th;
+        c->stationary_me_sr_divisor = m->me_sr_adjustment_ctrls.stationary_me_sr_divisor;
+        c->reduce_me_sr_based_on_hme_sad_abs_th = m->me_sr_adjustment_ctrls.reduce_me_sr_based_on_hme_sad_abs_th;
+        c->me_sr_divisor_for_low_hme_sad = m->me_sr_adjustment_ctrls.me_sr_divisor_for_low_hme_sad;
+    }
+    c->reduce_hme_l0_sr_th_min = m->reduce_hme_l0_sr_th_min;
+    c->reduce_hme_l0_sr_th_max = m->reduce_hme_l0_sr_th_max;
+    c->stat_factor = m->stat_factor;
+    c->use_best_unipred_cand_only = m->use_best_unipred_cand_only;
+    c->prune_me_candidates_th = m->prune_me_candidates_th;
+    c->me_early_exit_th = m->me_early_exit_th;
+}
+
+static void setup_pic(const Job *job, uint32_t pi, PicState *st) {
+    const ref_job_pic *jp = &job->pics[pi];
+    const uint32_t     w = job->hdr.width, h = job->hdr.height;
+    SequenceControlSet      *scs = (SequenceControlSet *)calloc(1, sizeof(*scs));
+    PictureParentControlSet *pcs = (PictureParentControlSet *)calloc(1, sizeof(*pcs));
+    if (!scs || !pcs) die("out of memory");
+    st->scs = scs;
+    st->pcs = pcs;
+    st->b64_w = (w + 63) / 64;
+    st->b64_h = (h + 63) / 64;
+    st->n_b64 = st->b64_w * st->b64_h;
+
+    derive_input_resolution(&scs->input_resolution, w * h);
+    scs->static_config.frame_rate               = jp->frame_rate;
+    scs->static_config.restricted_motion_vector = 0;
+    scs->static_config.enc_mode                 = (int8_t)jp->enc_mode;
+    scs->sb_sz                                  = 64;
+    scs->ipp_pass_ctrls.bypass_zz_check         = 0;
+
+    pcs->scs_ptr        = scs;
+    pcs->picture_number = jp->picture_number;
+    pcs->aligned_width  = (uint16_t)w;
+    pcs->aligned_height = (uint16_t)h;
+    pcs->enc_mode       = (EbEncMode)jp->enc_mode;
+    pcs->sc_class1      = jp->sc_class1;
+    pcs->temporal_layer_index      = jp->temporal_layer;
+    pcs->is_used_as_reference_flag = jp->is_ref;
+    pcs->slice_type     = jp->n_list == 2 ? B_SLICE : P_SLICE;
+    pcs->ref_list0_count_try = jp->n_ref[0];
+    pcs->ref_list1_count_try = jp->n_ref[1];
+    pcs->sb_total_count = (uint16_t)st->n_b64;
+    pcs->max_number_of_pus_per_sb = SQUARE_PU_COUNT; /* EbResourceCoordinationProcess.c:720 */
+    /* HME level flags: signal_derivation_multi_processes_oq, EbPictureDecisionProcess.c:1797-1814 */
+    pcs->enable_hme_flag        = 1;
+    pcs->enable_hme_level0_flag = 1;
+    if (pcs->sc_class1 || pcs->enc_mode <= ENC_M6) {
+        pcs->enable_hme_level1_flag = 1;
+        pcs->enable_hme_level2_flag = 1;
+    } else if (pcs->enc_mode <= ENC_M13) {
+        pcs->enable_hme_level1_flag = 1;
+        pcs->enable_hme_level2_flag = 0;
+    } else {
+        pcs->enable_hme_level1_flag = 0;
+        pcs->enable_hme_level2_flag = 0;
+    }
+    pcs->use_best_me_unipred_cand_only = pcs->enc_mode <= ENC_M9 ? 0 : 1; /* :2058-2061 */
+    pcs->enable_me_8x8 = !get_disallow_below_16x16_picture_level(
+        pcs->enc_mode, scs->input_resolution, B_SLICE, 0, 1, 0); /* EbPictureControlSet.c:1533 */
+    pcs->enable_me_16x16 = get_enable_me_16x16(pcs->enc_mode);
+    pcs->gm_ctrls.enabled = jp->gm_enabled;
+    pcs->gm_ctrls.use_distance_based_active_th = jp->gm_dist_th;
+
+    pcs->sb_params_array = (SbParams *)calloc(st->n_b64, sizeof(SbParams));
+    for (uint32_t i = 0; i < st->n_b64; ++i) {
+        SbParams *sp = &pcs->sb_params_array[i];
+        uint32_t  bx = i % st->b64_w, by = i / st->b64_w;
+        sp->horizontal_index = (uint8_t)bx;
+        sp->vertical_index   = (uint8_t)by;
+        sp->origin_x = (uint16_t)(bx * 64);
+        sp->origin_y = (uint16_t)(by * 64);
+        sp->width  = (uint8_t)((w - bx * 64) < 64 ? (w - bx * 64) : 64);
+        sp->height = (uint8_t)((h - by * 64) < 64 ? (h - by * 64) : 64);
+        sp->tile_start_x = 0; sp->tile_start_y = 0; sp->tile_end_x = w; sp->tile_end_y = h;
+    }
+    scs->sb_params_array = pcs->sb_params_array;
+
+    pcs->rc_me_distortion            = (uint32_t *)calloc(st->n_b64, 4);
+    pcs->me_64x64_distortion         = (uint32_t *)calloc(st->n_b64, 4);
+    pcs->me_32x32_distortion         = (uint32_t *)calloc(st->n_b64, 4);
+    pcs->me_16x16_distortion         = (uint32_t *)calloc(st->n_b64, 4);
+    pcs->me_8x8_distortion           = (uint32_t *)calloc(st->n_b64, 4);
+    pcs->me_8x8_cost_variance        = (uint32_t *)calloc(st->n_b64, 4);
+    pcs->stationary_block_present_sb = (uint8_t *)calloc(st->n_b64, 1);
+    pcs->rc_me_allow_gm              = (uint8_t *)calloc(st->n_b64, 1);
+
+    MotionEstimationData *md = (MotionEstimationData *)calloc(1, sizeof(*md));
+    uint8_t max_refs, max_cand;
+    get_max_allocated_me_refs(job->hdr.ref_count_used_list0, job->hdr.ref_count_used_list1, &max_refs, &max_cand);
+    md->max_cand = max_cand;
+    md->max_refs = max_refs;
+    md->max_l0   = (uint8_t)job->hdr.ref_count_used_list0;
+    md->me_results = (MeSbResults **)calloc(st->n_b64, sizeof(MeSbResults *));
+    for (uint32_t i = 0; i < st->n_b64; ++i) {
+        MeSbResults *r = (MeSbResults *)calloc(1, sizeof(*r));
+        r->me_mv_array = (MvCandidate *)calloc((size_t)SQUARE_PU_COUNT * REF_DUMP_MAX_REFS, sizeof(MvCandidate));
+        r->me_candidate_array = (MeCandidate *)calloc((size_t)SQUARE_PU_COUNT * REF_DUMP_MAX_CAND, sizeof(MeCandidate));
+        r->total_me_candidate_index = (uint8_t *)calloc(SQUARE_PU_COUNT, 1);
+        md->me_results[i] = r;
+    }
+    pcs->pa_me_data = md;
+    st->me_data     = md;
+    st->out = (uint8_t *)calloc(1, sizeof(ref_pic_dump) + (size_t)st->n_b64 * sizeof(ref_b64_dump));
+    if (!st->out) die("out of memory");
+}
+
+static void free_pic(PicState *st) {
+    PictureParentControlSet *pcs = st->pcs;
+    for (uint32_t i = 0; i < st->n_b64; ++i) {
+        free(st->me_data->me_results[i]->me_mv_array);
+        free(st->me_data->me_results[i]->me_candidate_array);
+        free(st->me_data->me_results[i]->total_me_candidate_index);
+        free(st->me_data->me_results[i]);
+    }
+    free(st->me_data->me_results);
+    free(st->me_data);
+    free(pcs->sb_params_array);
+    free(pcs->rc_me_distortion); free(pcs->me_64x64_distortion); free(pcs->me_32x32_distortion);
+    free(pcs->me_16x16_distortion); free(pcs->me_8x8_distortion); free(pcs->me_8x8_cost_variance);
+    free(pcs->stationary_block_present_sb); free(pcs->rc_me_allow_gm);
+    free(pcs); free(st->scs); free(st->out);
+    memset(st, 0, sizeof(*st));
+}
+
+static void dump_b64(ref_b64_dump *d, const MeContext *m, const PicState *st, uint32_t b64) {
+    const PictureParentControlSet *pcs = st->pcs;
+    memcpy(d->best_sad, m->p_sb_best_sad, sizeof(d->best_sad));
+    memcpy(d->best_mv, m->p_sb_best_mv, sizeof(d->best_mv));
+    for (int l = 0; l < 2; ++l)
+        for (int r = 0; r < 4; ++r) {
+            d->hme_sc_x[l][r] = m->search_results[l][r].hme_sc_x;
+            d->hme_sc_y[l][r] = m->search_results[l][r].hme_sc_y;
+            d->hme_sad[l][r]  = m->search_results[l][r].hme_sad;
+            d->do_ref[l][r]   = m->search_results[l][r].do_ref;
+            d->zz_sad[l][r]   = m->zz_sad[l][r];
+            d->sr_divisor[l][r] = m->reduce_me_sr_divisor[l][r];
+            for (int a = 0; a < 2; ++a) {
+                for (int b = 0; b < 2; ++b) {
+                    d->l0_x[l][r][a][b] = m->x_hme_level0_search_center[l][r][a][b];
+                    d->l0_y[l][r][a][b] = m->y_hme_level0_search_center[l][r][a][b];
+                    d->l0_sad[l][r][a][b] = m->hme_level0_sad[l][r][a][b];
+                    d->l1_x[l][r][a][b] = m->x_hme_level1_search_center[l][r][a][b];
+                    d->l1_y[l][r][a][b] = m->y_hme_level1_search_center[l][r][a][b];
+                    d->l1_sad[l][r][a][b] = m->hme_level1_sad[l][r][a][b];
+                    d->l2_x[l][r][a][b] = m->x_hme_level2_search_center[l][r][a][b];
+                    d->l2_y[l][r][a][b] = m->y_hme_level2_search_center[l][r][a][b];
+                    d->l2_sad[l][r][a][b] = m->hme_level2_sad[l][r][a][b];
+                }
+                d->pre_x[l][r][a]   = m->prehme_data[l][r][a].best_mv.as_mv.col;
+                d->pre_y[l][r][a]   = m->prehme_data[l][r][a].best_mv.as_mv.row;
+                d->pre_sad[l][r][a] = m->prehme_data[l][r][a].sad;
+            }
+        }
+    memcpy(d->me_distortion, m->me_distortion, sizeof(d->me_distortion));
+    const MeSbResults *r = pcs->pa_me_data->me_results[b64];
+    memcpy(d->total_me_candidate_index, r->total_me_candidate_index, SQUARE_PU_COUNT);
+    memset(d->me_mv_array, 0, sizeof(d->me_mv_array));
+    memset(d->me_candidate_array, 0, sizeof(d->me_candidate_array));
+    memcpy(d->me_mv_array, r->me_mv_array, (size_t)SQUARE_PU_COUNT * pcs->pa_me_data->max_refs * 4);
+    memcpy(d->me_candidate_array, r->me_candidate_array, (size_t)SQUARE_PU_COUNT * pcs->pa_me_data->max_cand);
+    d->rc_me_distortion = pcs->rc_me_distortion[b64];
+    d->me_64x64_distortion = pcs->me_64x64_distortion[b64];
+    d->me_32x32_distortion = pcs->me_32x32_distortion[b64];
+    d->me_16x16_distortion = pcs->me_16x16_distortion[b64];
+    d->me_8x8_distortion   = pcs->me_8x8_distortion[b64];
+    d->me_8x8_cost_variance = pcs->me_8x8_cost_variance[b64];
+    d->stationary_block_present_sb = pcs->stationary_block_present_sb[b64];
+    d->rc_me_allow_gm = pcs->rc_me_allow_gm[b64];
+}
+
+typedef struct Worker {
+    const Job *job;
+    PicState  *st;
+    uint32_t   pi;
+    uint32_t   row_begin, row_end; /* b64 rows */
+    int        dump;
+} Worker;
+
+/* One ME thread: own MeContext (motion_estimation_context_ctor, EbMotionEstimationProcess.c:642-655), then the
+ * b64 loop of motion_estimation_kernel (:750-846). */
+static void *worker_main(void *arg) {
+    Worker                   *wk  = (Worker *)arg;
+    const Job                *job = wk->job;
+    PicState                 *st  = wk->st;
+    const ref_job_pic        *jp  = &job->pics[wk->pi];
+    PictureParentControlSet  *pcs = st->pcs;
+    SequenceControlSet       *scs = st->scs;
+    MotionEstimationContext_t mectx;
+    memset(&mectx, 0, sizeof(mectx));
+    MeContext *m = (MeContext *)calloc(1, sizeof(MeContext));
+    if (!m) die("out of memory");
+    me_context_ctor(m);
+    mectx.me_context_ptr = m;
+    m->me_type = ME_OPEN_LOOP;
+    signal_derivation_me_kernel_oq(scs, pcs, &mectx);
+
+    Planes *cur = &job->planes[jp->cur_frame];
+    if (wk->dump && wk->row_begin == 0) {
+        ref_pic_dump *pd = (ref_pic_dump *)st->out;
+        fill_controls(&pd->ctrl, m);
+        pd->enable_me_8x8   = pcs->enable_me_8x8;
+        pd->enable_me_16x16 = pcs->enable_me_16x16;
+        pd->max_cand = pcs->pa_me_data->max_cand;
+        pd->max_refs = pcs->pa_me_data->max_refs;
+        pd->max_l0   = pcs->pa_me_data->max_l0;
+        pd->input_resolution = (uint8_t)scs->input_resolution;
+        pd->n_b64 = st->n_b64;
+    }
+    for (uint32_t by = wk->row_begin; by < wk->row_end; ++by) {
+        for (uint32_t bx = 0; bx < st->b64_w; ++bx) {
+            uint32_t b64 = bx + by * st->b64_w;
+            uint32_t ox = bx * 64, oy = by * 64;
+            m->b64_src_ptr    = &cur->full.buffer_y[(cur->full.origin_y + oy) * cur->full.stride_y + cur->full.origin_x + ox];
+            m->b64_src_stride = cur->full.stride_y;
+            if (m->enable_hme_level1_flag) {
+                m->quarter_b64_buffer = &cur->quarter.buffer_y[(cur->quarter.origin_y + (oy >> 1)) * cur->quarter.stride_y +
+                                                               cur->quarter.origin_x + (ox >> 1)];
+                m->quarter_b64_buffer_stride = cur->quarter.stride_y;
+            }
+            if (m->enable_hme_level0_flag) {
+                m->sixteenth_b64_buffer = &cur->sixteenth.buffer_y[(cur->sixteenth.origin_y + (oy >> 2)) * cur->sixteenth.stride_y +
+                                                                   cur->sixteenth.origin_x + (ox >> 2)];
+                m->sixteenth_b64_buffer_stride = cur->sixteenth.stride_y;
+            }
+            m->me_type = ME_OPEN_LOOP;
+            m->num_of_list_to_search       = jp->n_list;
+            m->num_of_ref_pic_to_search[0] = jp->n_ref[0];
+            if (jp->n_list == 2) m->num_of_ref_pic_to_search[1] = jp->n_ref[1];
+            m->temporal_layer_index      = jp->temporal_layer;
+            m->is_used_as_reference_flag = jp->is_ref;
+            for (int l = 0; l < jp->n_list; ++l)
+                for (int r = 0; r < jp->n_ref[l]; ++r) {
+                    Planes *rp = &job->planes[jp->ref_frame[l][r]];
+                    m->me_ds_ref_array[l][r].picture_ptr           = &rp->full;
+                    m->me_ds_ref_array[l][r].quarter_picture_ptr   = &rp->quarter;
+                    m->me_ds_ref_array[l][r].sixteenth_picture_ptr = &rp->sixteenth;
+                    m->me_ds_ref_array[l][r].picture_number        = jp->ref_poc[l][r];
+                }
+            motion_estimation_b64(pcs, b64, ox, oy, m, &cur->full);
+            if (wk->dump)
+                dump_b64((ref_b64_dump *)(st->out + sizeof(ref_pic_dump)) + b64, m, st, b64);
+        }
+    }
+    free(m->p_eight_pos_sad16x16);
+    free(m);
+    return NULL;
+}
+
+static double now_s(void) {
+    struct timespec ts;
+    clock_gettime(CLOCK_MONOTONIC, &ts);
+    return ts.tv_sec + ts.tv_nsec * 1e-9;
+}
+
+static void run_pic(const Job *job, uint32_t pi, PicState *st, uint32_t threads, int dump) {
+    if (threads < 1) threads = 1;
+    if (threads > st->b64_h) threads = st->b64_h;
+    pthread_t *tid = (pthread_t *)calloc(threads, sizeof(pthread_t));
+    Worker    *wk  = (Worker *)calloc(threads, sizeof(Worker));
+    for (uint32_t t = 0; t < threads; ++t) {
+        wk[t].job = job; wk[t].st = st; wk[t].pi = pi; wk[t].dump = dump;
+        wk[t].row_begin = (uint32_t)((uint64_t)st->b64_h * t / threads);
+        wk[t].row_end   = (uint32_t)((uint64_t)st->b64_h * (t + 1) / threads);
+        if (threads == 1) worker_main(&wk[t]);
+        else pthread_create(&tid[t], NULL, worker_main, &wk[t]);
+    }
+    if (threads > 1)
+        for (uint32_t t = 0; t < threads; ++t) pthread_join(tid[t], NULL);
+    free(tid); free(wk);
+}
+
+int main(int argc, char **argv) {
+    if (argc < 3) die("usage: ref_me <job> <out>");
+    FILE *f = fopen(argv[1], "rb");
+    if (!f) die("cannot open job file");
+    Job job;
+    memset(&job, 0, sizeof(job));
+    if (fread(&job.hdr, sizeof(job.hdr), 1, f) != 1) die("short job header");
+    if (memcmp(job.hdr.magic, REF_JOB_MAGIC, 8)) die("bad job magic");
+    const uint32_t w = job.hdr.width, h = job.hdr.height;
+    if (w % 8 || h % 8 || w < 64 || h < 64) die("width/height must be multiples of 8 and >= 64");
+    size_t fsz = (size_t)w * h;
+    job.frames = (uint8_t *)malloc(fsz * job.hdr.n_frames);
+    job.pics   = (ref_job_pic *)calloc(job.hdr.n_pics ? job.hdr.n_pics : 1, sizeof(ref_job_pic));
+    if (fread(job.frames, fsz, job.hdr.n_frames, f) != job.hdr.n_frames) die("short frame data");
+    if (job.hdr.n_pics && fread(job.pics, sizeof(ref_job_pic), job.hdr.n_pics, f) != job.hdr.n_pics) die("short pic data");
+    fclose(f);
+
+    setup_common_rtcd_internal(0);
+    setup_rtcd_internal(0);
+    int use_avx2 = 0;
+#ifdef REF_HAVE_AVX2
+    if (job.hdr.use_avx2 && __builtin_cpu_supports("avx2")) {
+        svt_sad_loop_kernel                       = svt_sad_loop_kernel_avx2_intrin;
+        svt_ext_all_sad_calculation_8x8_16x16     = svt_ext_all_sad_calculation_8x8_16x16_avx2;
+        svt_ext_eight_sad_calculation_32x32_64x64 = svt_ext_eight_sad_calculation_32x32_64x64_avx2;
+        svt_ext_sad_calculation_8x8_16x16         = svt_ext_sad_calculation_8x8_16x16_avx2_intrin;
+        svt_nxm_sad_kernel                        = svt_nxm_sad_kernel_helper_avx2;
+        use_avx2 = 1;
+    }
+#endif
+
+    job.planes = (Planes *)calloc(job.hdr.n_frames, sizeof(Planes));
+    for (uint32_t i = 0; i < job.hdr.n_frames; ++i) build_planes(&job.planes[i], job.frames + fsz * i, w, h);
+
+    FILE *o = fopen(argv[2], "wb");
+    if (!o) die("cannot open output file");
+    ref_out_header oh;
+    memset(&oh, 0, sizeof(oh));
+    memcpy(oh.magic, REF_OUT_MAGIC, 8);
+    oh.n_pics = job.hdr.n_pics;
+    oh.n_b64  = ((w + 63) / 64) * ((h + 63) / 64);
+    oh.pic_dump_size = sizeof(ref_pic_dump);
+    oh.b64_dump_size = sizeof(ref_b64_dump);
+    oh.used_avx2 = (uint32_t)use_avx2;
+    oh.mode = job.hdr.mode;
+
+    if (job.hdr.mode == REF_MODE_PLANES) {
+        /* dump the padded planes of every frame: sixteenth, quarter, full */
+        oh.n_pics = job.hdr.n_frames;
+        fwrite(&oh, sizeof(oh), 1, o);
+        for (uint32_t i = 0; i < job.hdr.n_frames; ++i) {
+            EbPictureBufferDesc *d[3] = {&job.planes[i].sixteenth, &job.planes[i].quarter, &job.planes[i].full};
+            for (int k = 0; k < 3; ++k) {
+                uint32_t geo[4] = {d[k]->stride_y, d[k]->width, d[k]->height, d[k]->origin_x};
+                fwrite(geo, sizeof(geo), 1, o);
+                fwrite(d[k]->buffer_y, 1, d[k]->luma_size, o);
+            }
+        }
+    } else if (job.hdr.mode == REF_MODE_DUMP) {
+        fwrite(&oh, sizeof(oh), 1, o);
+        for (uint32_t pi = 0; pi < job.hdr.n_pics; ++pi) {
+            PicState st;
+            memset(&st, 0, sizeof(st));
+            setup_pic(&job, pi, &st);
+            run_pic(&job, pi, &st, job.hdr.threads, 1);
+            fwrite(st.out, 1, sizeof(ref_pic_dump) + (size_t)st.n_b64 * sizeof(ref_b64_dump), o);
+            free_pic(&st);
+        }
+    } else { /* REF_MODE_BENCH: time `reps` passes over all pictures, nothing dumped */
+        PicState *st = (PicState *)calloc(job.hdr.n_pics, sizeof(PicState));
+        for (uint32_t pi = 0; pi < job.hdr.n_pics; ++pi) setup_pic(&job, pi, &st[pi]);
+        for (uint32_t pi = 0; pi < job.hdr.n_pics && pi < 2; ++pi) run_pic(&job, pi, &st[pi], job.hdr.threads, 0); /* warm-up */
+        double   t0 = now_s();
+        uint32_t reps = job.hdr.reps ? job.hdr.reps : 1;
+        for (uint32_t r = 0; r < reps; ++r)
+            for (uint32_t pi = 0; pi < job.hdr.n_pics; ++pi) run_pic(&job, pi, &st[pi], job.hdr.threads, 0);
+        double t1 = now_s();
+        oh.bench_seconds  = t1 - t0;
+        oh.bench_pictures = (uint64_t)reps * job.hdr.n_pics;
+        fwrite(&oh, sizeof(oh), 1, o);
+        printf("{\"pictures\": %llu, \"seconds\": %.6f, \"threads\": %u, \"avx2\": %d}\n",
+               (unsigned long long)oh.bench_pictures, oh.bench_seconds, job.hdr.threads, use_avx2);
+        for (uint32_t pi = 0; pi < job.hdr.n_pics; ++pi) free_pic(&st[pi]);
+        free(st);
+    }
+    fclose(o);
+    return 0;
+}

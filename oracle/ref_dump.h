@@ -1,0 +1,95 @@
+/*
+ * ref_dump.h - TEST INFRASTRUCTURE: binary job / dump formats shared by oracle/ref_driver.c (the driver
+ * around the real reference), oracle/oracle_cli.c (the same job run through the restatement) and the Python
+ * readers in tests/. All fields little-endian, structs packed.
+ */
+#ifndef REF_DUMP_H
+#define REF_DUMP_H
+#include <stdint.h>
+#include "../include/svtme.h"
+
+#define REF_JOB_MAGIC "SVTMEJ01"
+#define REF_OUT_MAGIC "SVTMEO01"
+#define REF_MODE_DUMP 0
+#define REF_MODE_BENCH 1
+#define REF_MODE_PLANES 2
+#define REF_DUMP_MAX_REFS 7 /* MAX_PA_ME_MV, EbMotionEstimationLcuResults.h:23 */
+#define REF_DUMP_MAX_CAND 23 /* MAX_PA_ME_CAND, :24 */
+
+#pragma pack(push, 1)
+typedef struct ref_job_header {
+    char     magic[8];
+    uint32_t width, height; /* luma, multiples of 8 */
+    uint32_t n_frames; /* followed by n_frames * width * height luma bytes */
+    uint32_t n_pics; /* then n_pics ref_job_pic */
+    uint32_t mode;
+    uint32_t threads;
+    uint32_t use_avx2;
+    uint32_t reps;
+    uint32_t ref_count_used_list0; /* MRP maxima used to size me_results, EbPictureDecisionProcess.c:5075-5092 */
+    uint32_t ref_count_used_list1;
+} ref_job_header;
+
+typedef struct ref_job_pic {
+    uint32_t cur_frame;
+    uint32_t frame_rate; /* 16.16 */
+    uint64_t picture_number;
+    int32_t  enc_mode;
+    uint8_t  temporal_layer;
+    uint8_t  is_ref;
+    uint8_t  n_list;
+    uint8_t  n_ref[2];
+    uint8_t  sc_class1;
+    uint8_t  gm_enabled;
+    uint8_t  gm_dist_th;
+    uint32_t ref_frame[2][4];
+    uint64_t ref_poc[2][4];
+} ref_job_pic;
+
+typedef struct ref_out_header {
+    char     magic[8];
+    uint32_t n_pics;
+    uint32_t n_b64;
+    uint32_t pic_dump_size;
+    uint32_t b64_dump_size;
+    uint32_t used_avx2;
+    uint32_t mode;
+    double   bench_seconds;
+    uint64_t bench_pictures;
+} ref_out_header;
+
+typedef struct ref_pic_dump {
+    svtme_controls ctrl; /* MeContext controls after signal_derivation_me_kernel_oq */
+    uint8_t        enable_me_8x8, enable_me_16x16, max_cand, max_refs, max_l0, input_resolution;
+    uint8_t        pad[2];
+    uint32_t       n_b64;
+} ref_pic_dump;
+
+/* State of MeContext / pcs after motion_estimation_b64 returned for one b64. */
+typedef struct ref_b64_dump {
+    uint32_t best_sad[2][4][85];
+    uint32_t best_mv[2][4][85];
+    int16_t  hme_sc_x[2][4], hme_sc_y[2][4];
+    uint64_t hme_sad[2][4]; /* final, i.e. after me_prune_ref when that ran */
+    uint8_t  do_ref[2][4]; /* final */
+    uint32_t zz_sad[2][4];
+    uint32_t sr_divisor[2][4];
+    int16_t  l0_x[2][4][2][2], l0_y[2][4][2][2];
+    uint64_t l0_sad[2][4][2][2];
+    int16_t  l1_x[2][4][2][2], l1_y[2][4][2][2];
+    uint64_t l1_sad[2][4][2][2];
+    int16_t  l2_x[2][4][2][2], l2_y[2][4][2][2];
+    uint64_t l2_sad[2][4][2][2];
+    int16_t  pre_x[2][4][2], pre_y[2][4][2];
+    uint64_t pre_sad[2][4][2];
+    /* host tail */
+    uint32_t me_distortion[85];
+    uint8_t  total_me_candidate_index[85];
+    uint32_t me_mv_array[85 * REF_DUMP_MAX_REFS];
+    uint8_t  me_candidate_array[85 * REF_DUMP_MAX_CAND];
+    uint32_t rc_me_distortion, me_64x64_distortion, me_32x32_distortion, me_16x16_distortion,
+        me_8x8_distortion, me_8x8_cost_variance;
+    uint8_t stationary_block_present_sb, rc_me_allow_gm;
+} ref_b64_dump;
+#pragma pack(pop)
+#endif

@@ -1,0 +1,136 @@
+"""TEST INFRASTRUCTURE: writer for the job files and reader for the dump files of oracle/_ref/ref_me (the real
+reference ME behind a driver) and oracle/build/oracle_me (the restatement behind the same driver interface).
+Formats: oracle/ref_dump.h. Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg use this."""
+import os
+import struct
+import subprocess
+import tempfile
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+REF_BIN = os.path.join(HERE, "_ref", "ref_me")
+ORACLE_BIN = os.path.join(HERE, "build", "oracle_me")
+
+MODE_DUMP, MODE_BENCH, MODE_PLANES = 0, 1, 2
+
+SA = np.dtype([("width", "<u2"), ("height", "<u2")])
+SAMM = np.dtype([("sa_min", SA), ("sa_max", SA)])
+CONTROLS = np.dtype([
+    ("me_sa", SAMM), ("hme_l0_sa", SAMM), ("hme_l1_sa", SA), ("hme_l2_sa", SA),
+    ("num_hme_sa_w", "<u2"), ("num_hme_sa_h", "<u2"),
+    ("enable_hme_flag", "u1"), ("enable_hme_level0_flag", "u1"), ("enable_hme_level1_flag", "u1"),
+    ("enable_hme_level2_flag", "u1"), ("hme_search_method", "u1"), ("me_search_method", "u1"),
+    ("prehme_enable", "u1"), ("prehme_skip_search_line", "u1"), ("prehme_l1_early_exit", "u1"), ("reserved0", "u1"),
+    ("prehme_sa_cfg", SAMM, (2,)),
+    ("enable_me_hme_ref_pruning", "u1"), ("protect_closest_refs", "u1"),
+    ("prune_ref_if_hme_sad_dev_bigger_than_th", "<u2"), ("prune_ref_if_me_sad_dev_bigger_than_th", "<u2"),
+    ("enable_me_sr_adjustment", "u1"), ("distance_based_hme_resizing", "u1"),
+    ("reduce_me_sr_based_on_mv_length_th", "<u2"), ("stationary_hme_sad_abs_th", "<u2"),
+    ("stationary_me_sr_divisor", "<u2"), ("reduce_me_sr_based_on_hme_sad_abs_th", "<u2"),
+    ("me_sr_divisor_for_low_hme_sad", "<u2"),
+    ("reduce_hme_l0_sr_th_min", "u1"), ("reduce_hme_l0_sr_th_max", "u1"), ("stat_factor", "u1"),
+    ("use_best_unipred_cand_only", "u1"), ("prune_me_candidates_th", "<i4"), ("me_early_exit_th", "<u4"),
+])
+assert CONTROLS.itemsize == 84
+
+PIC_DUMP = np.dtype([
+    ("ctrl", CONTROLS), ("enable_me_8x8", "u1"), ("enable_me_16x16", "u1"), ("max_cand", "u1"),
+    ("max_refs", "u1"), ("max_l0", "u1"), ("input_resolution", "u1"), ("pad", "u1", (2,)), ("n_b64", "<u4"),
+])
+
+B64_DUMP = np.dtype([
+    ("best_sad", "<u4", (2, 4, 85)), ("best_mv", "<u4", (2, 4, 85)),
+    ("hme_sc_x", "<i2", (2, 4)), ("hme_sc_y", "<i2", (2, 4)), ("hme_sad", "<u8", (2, 4)),
+    ("do_ref", "u1", (2, 4)), ("zz_sad", "<u4", (2, 4)), ("sr_divisor", "<u4", (2, 4)),
+    ("l0_x", "<i2", (2, 4, 2, 2)), ("l0_y", "<i2", (2, 4, 2, 2)), ("l0_sad", "<u8", (2, 4, 2, 2)),
+    ("l1_x", "<i2", (2, 4, 2, 2)), ("l1_y", "<i2", (2, 4, 2, 2)), ("l1_sad", "<u8", (2, 4, 2, 2)),
+    ("l2_x", "<i2", (2, 4, 2, 2)), ("l2_y", "<i2", (2, 4, 2, 2)), ("l2_sad", "<u8", (2, 4, 2, 2)),
+    ("pre_x", "<i2", (2, 4, 2)), ("pre_y", "<i2", (2, 4, 2)), ("pre_sad", "<u8", (2, 4, 2)),
+    ("me_distortion", "<u4", (85,)), ("total_me_candidate_index", "u1", (85,)),
+    ("me_mv_array", "<u4", (85 * 7,)), ("me_candidate_array", "u1", (85 * 23,)),
+    ("rc_me_distortion", "<u4"), ("me_64x64_distortion", "<u4"), ("me_32x32_distortion", "<u4"),
+    ("me_16x16_distortion", "<u4"), ("me_8x8_distortion", "<u4"), ("me_8x8_cost_variance", "<u4"),
+    ("stationary_block_present_sb", "u1"), ("rc_me_allow_gm", "u1"),
+])
+
+_HDR = "<8sIIIIIIIIII"
+_PIC = "<IIQiBBBBBBBB8I8Q"
+_OUT = "<8sIIIIIIdQ"
+
+
+def write_job(path, frames, pics, enc_mode, *, mode=MODE_DUMP, threads=1, use_avx2=0, reps=1,
+              frame_rate=30 << 16, sc_class1=0, gm_enabled=0, gm_dist_th=0, ref_counts=(4, 3)):
+    """frames: uint8 [n, h, w]; pics: list of svtme.gop.Picture (refs are POCs = frame indices)."""
+    n, h, w = frames.shape
+    with open(path, "wb") as f:
+        f.write(struct.pack(_HDR, b"SVTMEJ01", w, h, n, len(pics), mode, threads, use_avx2, reps,
+                            ref_counts[0], ref_counts[1]))
+        f.write(np.ascontiguousarray(frames, dtype=np.uint8).tobytes())
+        for p in pics:
+            rf = [[0] * 4, [0] * 4]
+            for l in range(2):
+                for i, r in enumerate(p.refs[l][:4]):
+                    rf[l][i] = r
+            n_list = 2 if p.refs[1] else 1
+            f.write(struct.pack(_PIC, p.poc, frame_rate, p.poc, enc_mode, p.temporal_layer, p.is_ref, n_list,
+                                len(p.refs[0]), len(p.refs[1]), sc_class1, gm_enabled, gm_dist_th,
+                                *rf[0], *rf[1], *rf[0], *rf[1]))
+
+
+def read_dump(path):
+    """Returns (header dict, list of (pic_dump record, b64 record array))."""
+    with open(path, "rb") as f:
+        data = f.read()
+    hs = struct.calcsize(_OUT)
+    magic, n_pics, n_b64, pds, bds, avx2, mode, secs, npic = struct.unpack_from(_OUT, data, 0)
+    assert magic == b"SVTMEO01", magic
+    hdr = dict(n_pics=n_pics, n_b64=n_b64, used_avx2=avx2, mode=mode, bench_seconds=secs, bench_pictures=npic)
+    out = []
+    if mode == MODE_DUMP:
+        assert pds == PIC_DUMP.itemsize and bds == B64_DUMP.itemsize, (pds, PIC_DUMP.itemsize, bds, B64_DUMP.itemsize)
+        off = hs
+        for _ in range(n_pics):
+            pd = np.frombuffer(data, PIC_DUMP, 1, off)[0]
+            off += pds
+            bd = np.frombuffer(data, B64_DUMP, n_b64, off)
+            off += bds * n_b64
+            out.append((pd, bd))
+    elif mode == MODE_PLANES:
+        off = hs
+        for _ in range(n_pics):
+            planes = []
+            for _k in range(3):
+                stride, w, h, pad = struct.unpack_from("<4I", data, off)
+                off += 16
+                size = stride * (h + 2 * pad)
+                planes.append(np.frombuffer(data, np.uint8, size, off).reshape(h + 2 * pad, stride))
+                off += size
+            out.append(planes)
+    return hdr, out
+
+
+def run_binary(binary, frames, pics, enc_mode, **kw):
+    if not os.path.exists(binary):
+        raise FileNotFoundError(binary)
+    with tempfile.TemporaryDirectory(prefix="svtme_") as td:
+        job, out = os.path.join(td, "job.bin"), os.path.join(td, "out.bin")
+        write_job(job, frames, pics, enc_mode, **kw)
+        r = subprocess.run([binary, job, out], capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError("%s failed (%d): %s" % (binary, r.returncode, r.stderr[-2000:]))
+        hdr, recs = read_dump(out)
+        hdr["stdout"] = r.stdout
+        return hdr, recs
+
+
+def run_reference(frames, pics, enc_mode, **kw):
+    return run_binary(REF_BIN, frames, pics, enc_mode, **kw)
+
+
+def run_oracle(frames, pics, enc_mode, **kw):
+    return run_binary(ORACLE_BIN, frames, pics, enc_mode, **kw)
+
+
+def have_reference():
+    return os.path.exists(REF_BIN)
