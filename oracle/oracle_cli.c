@@ -109,14 +109,14 @@ int main(int argc, char **argv) {
                 fwrite(geo, sizeof(geo), 1, o);
                 fwrite(p->buf, 1, (size_t)p->stride * (p->height + 2 * p->pad), o);
             }
-    } else if (h.mode == REF_MODE_DUMP) {
+    } else if (h.mode == REF_MODE_DUMP || h.mode == REF_MODE_DUMP_NOTAIL) {
         fwrite(&oh, sizeof(oh), 1, o);
         ref_b64_dump *rec = (ref_b64_dump *)calloc(oh.n_b64, sizeof(ref_b64_dump));
         for (uint32_t pi = 0; pi < h.n_pics; ++pi) {
             orc_pic pic;
             fill_pic(&pic, &h, &pics[pi], planes);
             uint64_t ops[6];
-            orc_me_picture(&pic, rec, 1, (int)h.threads, ops);
+            orc_me_picture(&pic, rec, h.mode == REF_MODE_DUMP, (int)h.threads, ops);
             for (int i = 0; i < 6; ++i) ops_total[i] += ops[i];
             ref_pic_dump pd;
             memset(&pd, 0, sizeof(pd));

@@ -13,6 +13,7 @@
 #define REF_MODE_DUMP 0
 #define REF_MODE_BENCH 1
 #define REF_MODE_PLANES 2
+#define REF_MODE_DUMP_NOTAIL 3 /* restatement only: state right after integer_search_b64 (what the GPU engine hands over) */
 #define REF_DUMP_MAX_REFS 7 /* MAX_PA_ME_MV, EbMotionEstimationLcuResults.h:23 */
 #define REF_DUMP_MAX_CAND 23 /* MAX_PA_ME_CAND, :24 */
 

@@ -12,7 +12,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 REF_BIN = os.path.join(HERE, "_ref", "ref_me")
 ORACLE_BIN = os.path.join(HERE, "build", "oracle_me")
 
-MODE_DUMP, MODE_BENCH, MODE_PLANES = 0, 1, 2
+MODE_DUMP, MODE_BENCH, MODE_PLANES, MODE_DUMP_NOTAIL = 0, 1, 2, 3
 
 SA = np.dtype([("width", "<u2"), ("height", "<u2")])
 SAMM = np.dtype([("sa_min", SA), ("sa_max", SA)])
@@ -87,7 +87,7 @@ def read_dump(path):
     assert magic == b"SVTMEO01", magic
     hdr = dict(n_pics=n_pics, n_b64=n_b64, used_avx2=avx2, mode=mode, bench_seconds=secs, bench_pictures=npic)
     out = []
-    if mode == MODE_DUMP:
+    if mode in (MODE_DUMP, MODE_DUMP_NOTAIL):
         assert pds == PIC_DUMP.itemsize and bds == B64_DUMP.itemsize, (pds, PIC_DUMP.itemsize, bds, B64_DUMP.itemsize)
         off = hs
         for _ in range(n_pics):

@@ -1,0 +1,408 @@
+// engine.cpp - host side of the engine: device picture store, picture queue, C ABI (include/svtme.h).
+//
+// Two HIP streams: `s_store` carries the uploads and the store-building kernels, `s_me` the search kernels and
+// the result copies. A picture waits (on the device, through events) for the store slots it reads; a slot that is
+// rewritten waits for the last picture that read it. Nothing here blocks the host except svtme_picture_wait.
+#include <hip/hip_runtime.h>
+
+#include <mutex>
+#include <new>
+#include <stdio.h>
+#include <string.h>
+#include <vector>
+
+#include "svtme_device.h"
+
+using namespace svtme;
+
+#define HIP_TRY(expr)                                                                                     \
+    do {                                                                                                  \
+        hipError_t err__ = (expr);                                                                        \
+        if (err__ != hipSuccess) {                                                                        \
+            fprintf(stderr, "svtme: %s failed: %s (%s:%d)\n", #expr, hipGetErrorString(err__), __FILE__, __LINE__); \
+            return SVTME_ERR_DEVICE;                                                                      \
+        }                                                                                                 \
+    } while (0)
+
+namespace {
+
+constexpr int kPad[3] = {16, 32, 72}; // sixteenth, quarter, full: EbEncHandle.c:1331-1355, :3447-3460
+
+struct Slot {
+    bool       used = false;
+    bool       release_pending = false;
+    uint64_t   key = 0, picture_number = 0;
+    int        readers = 0; // submitted pictures that have not been waited for yet
+    uint32_t   width = 0, height = 0;
+    DevPicture pic{};
+    uint8_t   *mem = nullptr; // device
+    uint8_t   *host_stage = nullptr; // pinned
+    hipEvent_t ready = nullptr; // planes built (recorded on s_store)
+    hipEvent_t last_read = nullptr; // last search kernel that read the planes (recorded on s_me)
+    bool       read_recorded = false;
+};
+
+struct Flight {
+    bool                 busy = false, waited = false;
+    svtme_ticket         ticket = 0;
+    uint32_t             n_b64 = 0;
+    std::vector<int>     slots; // store slots referenced
+    // device
+    HmeRefOut           *d_hme = nullptr;
+    uint8_t             *d_res = nullptr; // best_sad | best_mv | search_results | zz | div
+    // pinned host mirror of d_res
+    uint8_t             *h_res = nullptr;
+    size_t               off_mv = 0, off_sr = 0, off_zz = 0, off_div = 0, res_bytes = 0;
+    hipEvent_t           ev[4] = {nullptr, nullptr, nullptr, nullptr}; // start, after HME, after ME, after D2H
+};
+
+} // namespace
+
+struct svtme_engine {
+    svtme_config        cfg{};
+    std::mutex          mu;
+    hipStream_t         s_store = nullptr, s_me = nullptr;
+    std::vector<Slot>   slots;
+    std::vector<Flight> flights;
+    svtme_ticket        next_ticket = 1;
+    size_t              slot_bytes = 0, max_b64 = 0;
+};
+
+namespace {
+
+size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+// Lays the three planes of a picture of w x h into one slot allocation.
+void layout_planes(uint8_t *mem, uint32_t w, uint32_t h, DevPicture *pic, size_t *bytes) {
+    size_t off = 0;
+    for (int lvl = 2; lvl >= 0; --lvl) {
+        const int      shift = 2 - lvl;
+        const uint32_t pw = w >> shift, ph = h >> shift, pad = kPad[lvl];
+        const size_t   stride = align_up(pw + 2 * pad, 64);
+        DevPlane      &p      = pic->lvl[lvl];
+        p.stride = (int32_t)stride;
+        p.width  = (int32_t)pw;
+        p.height = (int32_t)ph;
+        p.pad    = (int32_t)pad;
+        // pixel (0,0) on an 8-byte boundary: pad rows, then `pad` rounded up to 8 columns
+        const size_t x0 = align_up(pad, 8);
+        p.pix = mem ? mem + off + (size_t)pad * stride + x0 : nullptr;
+        off += align_up(stride * (ph + 2 * pad) + 256, 256); // slack: staging reads run a few bytes past a window
+    }
+    *bytes = off;
+}
+
+int find_slot(svtme_engine *e, uint64_t key) {
+    for (size_t i = 0; i < e->slots.size(); ++i)
+        if (e->slots[i].used && e->slots[i].key == key) return (int)i;
+    return -1;
+}
+
+void free_flight(Flight &f) {
+    if (f.d_hme) (void)hipFree(f.d_hme);
+    if (f.d_res) (void)hipFree(f.d_res);
+    if (f.h_res) (void)hipHostFree(f.h_res);
+    for (auto &ev : f.ev)
+        if (ev) (void)hipEventDestroy(ev);
+    f = Flight();
+}
+
+} // namespace
+
+extern "C" const char *svtme_version(void) { return "svtme 0.1 (gfx950)"; }
+
+extern "C" int svtme_create(const svtme_config *cfg, svtme_engine **out) {
+    if (!cfg || !out || cfg->max_width < 64 || cfg->max_height < 64 || cfg->max_width % 8 || cfg->max_height % 8 ||
+        cfg->max_width > 16384 || cfg->max_height > 16384 || cfg->store_slots < 2 || cfg->max_in_flight < 1)
+        return SVTME_ERR_BAD_ARG;
+    int n_dev = 0;
+    if (hipGetDeviceCount(&n_dev) != hipSuccess || cfg->device < 0 || cfg->device >= n_dev) {
+        fprintf(stderr, "svtme: no HIP device %d (found %d)\n", cfg->device, n_dev);
+        return SVTME_ERR_DEVICE;
+    }
+    HIP_TRY(hipSetDevice(cfg->device));
+    svtme_engine *e = new (std::nothrow) svtme_engine();
+    if (!e) return SVTME_ERR_NO_RESOURCES;
+    e->cfg = *cfg;
+    auto fail = [&](int code) {
+        svtme_destroy(e);
+        return code;
+    };
+    if (hipStreamCreateWithFlags(&e->s_store, hipStreamNonBlocking) != hipSuccess ||
+        hipStreamCreateWithFlags(&e->s_me, hipStreamNonBlocking) != hipSuccess)
+        return fail(SVTME_ERR_DEVICE);
+    DevPicture tmp;
+    layout_planes(nullptr, cfg->max_width, cfg->max_height, &tmp, &e->slot_bytes);
+    e->max_b64 = (size_t)((cfg->max_width + 63) / 64) * ((cfg->max_height + 63) / 64);
+    e->slots.resize(cfg->store_slots);
+    for (auto &s : e->slots) {
+        if (hipMalloc((void **)&s.mem, e->slot_bytes) != hipSuccess ||
+            hipHostMalloc((void **)&s.host_stage, (size_t)cfg->max_width * cfg->max_height, hipHostMallocDefault) != hipSuccess ||
+            hipEventCreateWithFlags(&s.ready, hipEventDisableTiming) != hipSuccess ||
+            hipEventCreateWithFlags(&s.last_read, hipEventDisableTiming) != hipSuccess)
+            return fail(SVTME_ERR_NO_RESOURCES);
+    }
+    e->flights.resize(cfg->max_in_flight);
+    for (auto &f : e->flights) {
+        const size_t n = e->max_b64 * SVTME_MAX_LISTS * SVTME_MAX_REFS;
+        f.off_mv  = n * SVTME_PU_COUNT * 4;
+        f.off_sr  = f.off_mv * 2;
+        f.off_zz  = f.off_sr + n * sizeof(svtme_search_result);
+        f.off_div = f.off_zz + n * 4;
+        f.res_bytes = f.off_div + n * 4;
+        if (hipMalloc((void **)&f.d_hme, n * sizeof(HmeRefOut)) != hipSuccess || hipMalloc((void **)&f.d_res, f.res_bytes) != hipSuccess ||
+            hipHostMalloc((void **)&f.h_res, f.res_bytes, hipHostMallocDefault) != hipSuccess)
+            return fail(SVTME_ERR_NO_RESOURCES);
+        for (auto &ev : f.ev)
+            if (hipEventCreate(&ev) != hipSuccess) return fail(SVTME_ERR_NO_RESOURCES);
+    }
+    *out = e;
+    return SVTME_OK;
+}
+
+extern "C" void svtme_destroy(svtme_engine *e) {
+    if (!e) return;
+    (void)hipSetDevice(e->cfg.device);
+    if (e->s_me) (void)hipStreamSynchronize(e->s_me);
+    if (e->s_store) (void)hipStreamSynchronize(e->s_store);
+    for (auto &s : e->slots) {
+        if (s.mem) (void)hipFree(s.mem);
+        if (s.host_stage) (void)hipHostFree(s.host_stage);
+        if (s.ready) (void)hipEventDestroy(s.ready);
+        if (s.last_read) (void)hipEventDestroy(s.last_read);
+    }
+    for (auto &f : e->flights) free_flight(f);
+    if (e->s_me) (void)hipStreamDestroy(e->s_me);
+    if (e->s_store) (void)hipStreamDestroy(e->s_store);
+    delete e;
+}
+
+extern "C" int svtme_store_put(svtme_engine *e, uint64_t key, uint64_t picture_number, const uint8_t *luma, uint32_t stride,
+                               uint32_t width, uint32_t height) {
+    if (!e || !luma || width < 64 || height < 64 || width % 8 || height % 8 || width > e->cfg.max_width ||
+        height > e->cfg.max_height || stride < width)
+        return SVTME_ERR_BAD_ARG;
+    std::lock_guard<std::mutex> lock(e->mu);
+    HIP_TRY(hipSetDevice(e->cfg.device));
+    int si = find_slot(e, key);
+    if (si < 0) {
+        for (size_t i = 0; i < e->slots.size(); ++i)
+            if (!e->slots[i].used) {
+                si = (int)i;
+                break;
+            }
+        if (si < 0) return SVTME_ERR_NO_RESOURCES;
+    }
+    Slot &s = e->slots[si];
+    if (s.used && s.read_recorded) HIP_TRY(hipStreamWaitEvent(e->s_store, s.last_read, 0)); // rewrite after the readers
+    if (s.used) HIP_TRY(hipEventSynchronize(s.ready)); // the pinned staging buffer of this slot is free again
+    s.used = true;
+    s.release_pending = false;
+    s.key = key;
+    s.picture_number = picture_number;
+    s.width = width;
+    s.height = height;
+    size_t bytes;
+    layout_planes(s.mem, width, height, &s.pic, &bytes);
+    for (uint32_t y = 0; y < height; ++y) memcpy(s.host_stage + (size_t)y * width, luma + (size_t)y * stride, width);
+    const DevPlane &f = s.pic.lvl[2];
+    HIP_TRY(hipMemcpy2DAsync(f.pix, f.stride, s.host_stage, width, width, height, hipMemcpyHostToDevice, e->s_store));
+    launch_store_build(f.pix, f.stride, s.pic, 1, e->s_store);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipEventRecord(s.ready, e->s_store));
+    return SVTME_OK;
+}
+
+extern "C" int svtme_store_release(svtme_engine *e, uint64_t key) {
+    if (!e) return SVTME_ERR_BAD_ARG;
+    std::lock_guard<std::mutex> lock(e->mu);
+    const int si = find_slot(e, key);
+    if (si < 0) return SVTME_ERR_NOT_FOUND;
+    Slot &s = e->slots[si];
+    if (s.readers > 0) s.release_pending = true;
+    else s.used = false;
+    return SVTME_OK;
+}
+
+extern "C" int svtme_store_read(svtme_engine *e, uint64_t key, int level, uint8_t *dst, size_t dst_size, uint32_t *stride,
+                                uint32_t *width, uint32_t *height, uint32_t *pad) {
+    if (!e || level < 0 || level > 2 || !dst) return SVTME_ERR_BAD_ARG;
+    std::lock_guard<std::mutex> lock(e->mu);
+    HIP_TRY(hipSetDevice(e->cfg.device));
+    const int si = find_slot(e, key);
+    if (si < 0) return SVTME_ERR_NOT_FOUND;
+    const DevPlane &p  = e->slots[si].pic.lvl[level];
+    const uint32_t  os = (uint32_t)(p.width + 2 * p.pad), rows = (uint32_t)(p.height + 2 * p.pad);
+    if (dst_size < (size_t)os * rows) return SVTME_ERR_BAD_ARG;
+    HIP_TRY(hipEventSynchronize(e->slots[si].ready));
+    HIP_TRY(hipMemcpy2D(dst, os, p.pix - (ptrdiff_t)p.pad * p.stride - p.pad, p.stride, os, rows, hipMemcpyDeviceToHost));
+    if (stride) *stride = os;
+    if (width) *width = (uint32_t)p.width;
+    if (height) *height = (uint32_t)p.height;
+    if (pad) *pad = (uint32_t)p.pad;
+    return SVTME_OK;
+}
+
+extern "C" int svtme_picture_submit(svtme_engine *e, const svtme_picture *pic, svtme_ticket *ticket) {
+    if (!e || !pic || !ticket) return SVTME_ERR_BAD_ARG;
+    const svtme_controls &k = pic->ctrl;
+    if (pic->num_of_list_to_search < 1 || pic->num_of_list_to_search > 2 || pic->num_of_ref_pic_to_search[0] < 1 ||
+        pic->num_of_ref_pic_to_search[0] > SVTME_MAX_REFS ||
+        (pic->num_of_list_to_search == 2 && (pic->num_of_ref_pic_to_search[1] < 1 || pic->num_of_ref_pic_to_search[1] > SVTME_MAX_REFS)) ||
+        k.num_hme_sa_w < 1 || k.num_hme_sa_w > 2 || k.num_hme_sa_h < 1 || k.num_hme_sa_h > 2)
+        return SVTME_ERR_BAD_ARG;
+    // not implemented on the device: full-SAD integer search (no preset selects it) and the screen-content rule
+    // that shrinks later references' windows from the first reference's 64x64 result (EbMotionEstimation.c:1390-1399)
+    if (k.me_search_method != 0 || (k.enable_me_sr_adjustment == 2 && k.me_early_exit_th == 0)) return SVTME_ERR_UNSUPPORTED;
+
+    std::lock_guard<std::mutex> lock(e->mu);
+    HIP_TRY(hipSetDevice(e->cfg.device));
+    Flight *f = nullptr;
+    for (auto &c : e->flights)
+        if (!c.busy) {
+            f = &c;
+            break;
+        }
+    if (!f) return SVTME_ERR_NO_RESOURCES;
+
+    PicParams p;
+    memset(&p, 0, sizeof(p));
+    std::vector<int> used;
+    const int        ci = find_slot(e, pic->cur_key);
+    if (ci < 0) return SVTME_ERR_NOT_FOUND;
+    const Slot &cs = e->slots[ci];
+    if (cs.width != pic->width || cs.height != pic->height) return SVTME_ERR_BAD_ARG;
+    p.cur = cs.pic;
+    used.push_back(ci);
+    p.n_list   = pic->num_of_list_to_search;
+    p.n_ref[0] = pic->num_of_ref_pic_to_search[0];
+    p.n_ref[1] = p.n_list == 2 ? pic->num_of_ref_pic_to_search[1] : 0;
+    for (int l = 0; l < p.n_list; ++l)
+        for (int r = 0; r < p.n_ref[l]; ++r) {
+            const int ri = find_slot(e, pic->ref_key[l][r]);
+            if (ri < 0) return SVTME_ERR_NOT_FOUND;
+            if (e->slots[ri].width != pic->width || e->slots[ri].height != pic->height) return SVTME_ERR_BAD_ARG;
+            p.ref[l][r] = e->slots[ri].pic;
+            const int64_t d = (int64_t)pic->picture_number - (int64_t)pic->ref_picture_number[l][r];
+            p.dist[l][r] = (uint16_t)(int16_t)(d < 0 ? -d : d);
+            used.push_back(ri);
+        }
+    p.ctrl = k;
+    p.width  = (int32_t)pic->width;
+    p.height = (int32_t)pic->height;
+    p.b64_w  = (int32_t)((pic->width + 63) / 64);
+    p.b64_h  = (int32_t)((pic->height + 63) / 64);
+    p.temporal_layer = pic->temporal_layer_index;
+    p.is_ref = pic->is_used_as_reference_flag;
+    // a reference depends on an earlier one: pre-HME list-1 early exit (:1758-1768) and the HME level-0 area
+    // rescaling from the first reference's vector (:1837-1851)
+    p.serial_refs = (k.prehme_enable && k.prehme_l1_early_exit && p.n_list == 2) ||
+        (k.enable_me_sr_adjustment && k.distance_based_hme_resizing && k.reduce_hme_l0_sr_th_min && k.reduce_hme_l0_sr_th_max);
+    const size_t n_b64 = (size_t)p.b64_w * p.b64_h;
+    if (n_b64 > e->max_b64) return SVTME_ERR_BAD_ARG;
+    p.hme_out        = f->d_hme;
+    p.best_sad       = reinterpret_cast<uint32_t *>(f->d_res);
+    p.best_mv        = reinterpret_cast<uint32_t *>(f->d_res + f->off_mv);
+    p.search_results = reinterpret_cast<svtme_search_result *>(f->d_res + f->off_sr);
+    p.zz_sad         = reinterpret_cast<uint32_t *>(f->d_res + f->off_zz);
+    p.sr_divisor     = reinterpret_cast<uint32_t *>(f->d_res + f->off_div);
+
+    for (int si : used) HIP_TRY(hipStreamWaitEvent(e->s_me, e->slots[si].ready, 0));
+    HIP_TRY(hipEventRecord(f->ev[0], e->s_me));
+    // unsearched / pruned references read as zero
+    HIP_TRY(hipMemsetAsync(f->d_res, 0, f->off_sr, e->s_me));
+    launch_hme(p, e->s_me);
+    HIP_TRY(hipEventRecord(f->ev[1], e->s_me));
+    launch_me(p, e->s_me);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipEventRecord(f->ev[2], e->s_me));
+    for (int si : used) {
+        HIP_TRY(hipEventRecord(e->slots[si].last_read, e->s_me));
+        e->slots[si].read_recorded = true;
+        e->slots[si].readers++;
+    }
+    // results back to pinned host memory (compacted to this picture's n_b64)
+    const size_t n = n_b64 * SVTME_MAX_LISTS * SVTME_MAX_REFS;
+    HIP_TRY(hipMemcpyAsync(f->h_res, f->d_res, n * SVTME_PU_COUNT * 4, hipMemcpyDeviceToHost, e->s_me));
+    HIP_TRY(hipMemcpyAsync(f->h_res + f->off_mv, f->d_res + f->off_mv, n * SVTME_PU_COUNT * 4, hipMemcpyDeviceToHost, e->s_me));
+    HIP_TRY(hipMemcpyAsync(f->h_res + f->off_sr, f->d_res + f->off_sr, n * sizeof(svtme_search_result), hipMemcpyDeviceToHost, e->s_me));
+    HIP_TRY(hipMemcpyAsync(f->h_res + f->off_zz, f->d_res + f->off_zz, n * 4, hipMemcpyDeviceToHost, e->s_me));
+    HIP_TRY(hipMemcpyAsync(f->h_res + f->off_div, f->d_res + f->off_div, n * 4, hipMemcpyDeviceToHost, e->s_me));
+    HIP_TRY(hipEventRecord(f->ev[3], e->s_me));
+    f->busy   = true;
+    f->waited = false;
+    f->n_b64  = (uint32_t)n_b64;
+    f->slots  = used;
+    f->ticket = e->next_ticket++;
+    *ticket   = f->ticket;
+    return SVTME_OK;
+}
+
+static Flight *find_flight(svtme_engine *e, svtme_ticket t) {
+    for (auto &f : e->flights)
+        if (f.busy && f.ticket == t) return &f;
+    return nullptr;
+}
+
+extern "C" int svtme_picture_wait(svtme_engine *e, svtme_ticket ticket, svtme_results *out) {
+    if (!e || !out) return SVTME_ERR_BAD_ARG;
+    Flight *f;
+    {
+        std::lock_guard<std::mutex> lock(e->mu);
+        f = find_flight(e, ticket);
+        if (!f) return SVTME_ERR_NOT_FOUND;
+    }
+    HIP_TRY(hipSetDevice(e->cfg.device));
+    HIP_TRY(hipEventSynchronize(f->ev[3]));
+    std::lock_guard<std::mutex> lock(e->mu);
+    if (!f->waited) {
+        f->waited = true;
+        for (int si : f->slots) {
+            Slot &s = e->slots[si];
+            if (--s.readers == 0 && s.release_pending) {
+                s.used = false;
+                s.release_pending = false;
+            }
+        }
+    }
+    out->n_b64                = f->n_b64;
+    out->p_sb_best_sad        = reinterpret_cast<const uint32_t *>(f->h_res);
+    out->p_sb_best_mv         = reinterpret_cast<const uint32_t *>(f->h_res + f->off_mv);
+    out->search_results       = reinterpret_cast<const svtme_search_result *>(f->h_res + f->off_sr);
+    out->zz_sad               = reinterpret_cast<const uint32_t *>(f->h_res + f->off_zz);
+    out->reduce_me_sr_divisor = reinterpret_cast<const uint32_t *>(f->h_res + f->off_div);
+    return SVTME_OK;
+}
+
+extern "C" int svtme_picture_done(svtme_engine *e, svtme_ticket ticket) {
+    if (!e) return SVTME_ERR_BAD_ARG;
+    std::lock_guard<std::mutex> lock(e->mu);
+    Flight *f = find_flight(e, ticket);
+    if (!f) return SVTME_ERR_NOT_FOUND;
+    if (!f->waited) return SVTME_ERR_BAD_ARG;
+    f->busy = false;
+    return SVTME_OK;
+}
+
+extern "C" int svtme_picture_timing(svtme_engine *e, svtme_ticket ticket, float ms[3]) {
+    if (!e || !ms) return SVTME_ERR_BAD_ARG;
+    std::lock_guard<std::mutex> lock(e->mu);
+    Flight *f = find_flight(e, ticket);
+    if (!f || !f->waited) return SVTME_ERR_NOT_FOUND;
+    HIP_TRY(hipEventElapsedTime(&ms[0], f->ev[0], f->ev[1]));
+    HIP_TRY(hipEventElapsedTime(&ms[1], f->ev[1], f->ev[2]));
+    HIP_TRY(hipEventElapsedTime(&ms[2], f->ev[0], f->ev[3]));
+    return SVTME_OK;
+}
+
+extern "C" int svtme_unpack_b64(const svtme_results *res, uint32_t b64_index, uint32_t *p_sb_best_sad, uint32_t *p_sb_best_mv,
+                                svtme_search_result *search_results, uint32_t *zz_sad, uint32_t *reduce_me_sr_divisor) {
+    if (!res || b64_index >= res->n_b64) return SVTME_ERR_BAD_ARG;
+    const size_t n = SVTME_MAX_LISTS * SVTME_MAX_REFS;
+    if (p_sb_best_sad) memcpy(p_sb_best_sad, res->p_sb_best_sad + (size_t)b64_index * n * SVTME_PU_COUNT, n * SVTME_PU_COUNT * 4);
+    if (p_sb_best_mv) memcpy(p_sb_best_mv, res->p_sb_best_mv + (size_t)b64_index * n * SVTME_PU_COUNT, n * SVTME_PU_COUNT * 4);
+    if (search_results) memcpy(search_results, res->search_results + (size_t)b64_index * n, n * sizeof(svtme_search_result));
+    if (zz_sad) memcpy(zz_sad, res->zz_sad + (size_t)b64_index * n, n * 4);
+    if (reduce_me_sr_divisor) memcpy(reduce_me_sr_divisor, res->reduce_me_sr_divisor + (size_t)b64_index * n, n * 4);
+    return SVTME_OK;
+}

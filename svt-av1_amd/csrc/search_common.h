@@ -1,0 +1,76 @@
+// search_common.h - device helpers shared by the HME and integer-search kernels.
+#pragma once
+#include "svtme_device.h"
+
+namespace svtme {
+
+typedef unsigned long long u64;
+
+// get_scaled_picture_distance, Source/Lib/Encoder/Codec/EbMotionEstimation.c:1276-1280
+__device__ __forceinline__ int scaled_dist(int dist) { return (uint16_t)(((dist * 5) / 8) + ((dist % 8) ? 1 : 0)); }
+
+// A reference takes part in zz-SAD / pre-HME / HME unless it is a list-1 reference of a base-layer picture
+// (`temporal_layer_index > 0 || list_index == 0`, :1786, :1936, :2024, :2087, :2148, :2325).
+__device__ __forceinline__ bool ref_searched(const PicParams &p, int l) { return p.temporal_layer > 0 || l == 0; }
+
+// The per-axis window correction all stages share (:875-907, :976-1009, :1077-1105, :1441-1460, :1502-1520,
+// :1638-1682): a window starting below `lo` is shifted, not shrunk (the size correction is computed from the
+// already corrected origin and is therefore zero); at the far side the origin is clamped to dim-1 and the size cut
+// so that the window ends at dim, but never below 1. int16_t arithmetic as in the reference.
+__device__ __forceinline__ void clip_axis(int o, int16_t &org, int16_t &size, int lo, int dim) {
+    if (o + org < lo) {
+        org  = (int16_t)(lo - o);
+        size = (int16_t)(size - (lo - (o + org)));
+    }
+    if (o + org > dim - 1) org = (int16_t)(org - ((o + org) - (dim - 1)));
+    if (o + org + size > dim) size = (int16_t)max(1, size - ((o + org + size) - dim));
+}
+
+// 4 bytes at an arbitrary byte address, from two aligned dword loads.
+__device__ __forceinline__ uint32_t load_u32_any(const uint8_t *p) {
+    const uintptr_t a  = reinterpret_cast<uintptr_t>(p);
+    const uint32_t *q  = reinterpret_cast<const uint32_t *>(a & ~(uintptr_t)3);
+    const uint32_t  lo = q[0], hi = q[1];
+    return __builtin_amdgcn_alignbyte(hi, lo, (uint32_t)(a & 3));
+}
+
+__device__ __forceinline__ uint32_t wave_sum(uint32_t v) {
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m);
+    return v;
+}
+
+__device__ __forceinline__ u64 wave_min_u64(u64 v) {
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) {
+        const u64 o = __shfl_xor(v, m);
+        v = o < v ? o : v;
+    }
+    return v;
+}
+
+// SAD of the (bw x rows) block of `cur` at (ox, oy) against `ref` at (ox + dx, oy + dy), every `step`-th row:
+// svt_nxm_sad_kernel as get_zz_sad (:1720-1742) and check_00_center (:1170-1243) call it (stride << 1, height >> 1).
+// Whole workgroup takes part; `red` is one LDS word; returns the same sum in every thread. bw is a multiple of 4.
+__device__ uint32_t wg_block_sad(const DevPlane &cur, const DevPlane &ref, int ox, int oy, int dx, int dy, int bw,
+                                 int rows, int step, uint32_t *red) {
+    const int bwd = bw >> 2;
+    const int n   = rows * bwd;
+    if (threadIdx.x == 0) *red = 0;
+    __syncthreads();
+    uint32_t acc = 0;
+    for (int i = threadIdx.x; i < n; i += blockDim.x) {
+        const int      r = i / bwd, d = i - r * bwd;
+        const uint32_t s = *reinterpret_cast<const uint32_t *>(cur.pix + (ptrdiff_t)(oy + r * step) * cur.stride + ox + 4 * d);
+        const uint32_t f = load_u32_any(ref.pix + (ptrdiff_t)(oy + dy + r * step) * ref.stride + ox + dx + 4 * d);
+        acc = __builtin_amdgcn_sad_u8(s, f, acc);
+    }
+    acc = wave_sum(acc);
+    if ((threadIdx.x & 63) == 0 && acc) atomicAdd(red, acc);
+    __syncthreads();
+    const uint32_t total = *red;
+    __syncthreads();
+    return total;
+}
+
+} // namespace svtme

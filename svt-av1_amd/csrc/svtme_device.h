@@ -1,0 +1,67 @@
+// svtme_device.h - device-side data layout shared by the HIP kernels and the host engine.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "../../include/svtme.h"
+
+namespace svtme {
+
+// One padded 8-bit plane of the device picture store. `pix` points at pixel (0,0); rows -pad..height+pad-1 and
+// columns -pad..width+pad-1 are valid. stride is a multiple of 64 bytes and `pix` is 4-byte aligned, so a row's
+// byte alignment is the same for every row.
+struct DevPlane {
+    uint8_t *pix;
+    int32_t  stride;
+    int32_t  width;
+    int32_t  height;
+    int32_t  pad;
+};
+
+// lvl[0] = sixteenth, lvl[1] = quarter, lvl[2] = full: get_me_reference's level numbering
+// (Source/Lib/Encoder/Codec/EbMotionEstimation.c:1247-1273).
+struct DevPicture {
+    DevPlane lvl[3];
+};
+
+// HME results of one (b64, list, ref). Region index = sr_w * 2 + sr_h, i.e. the memory order of the reference's
+// [EB_HME_SEARCH_AREA_COLUMN_MAX_COUNT][EB_HME_SEARCH_AREA_ROW_MAX_COUNT] arrays (EbMotionEstimationContext.h:404-427).
+struct HmeRefOut {
+    int16_t  lx[3][4];
+    int16_t  ly[3][4];
+    uint32_t lsad[3][4];
+    int16_t  pre_x[2];
+    int16_t  pre_y[2];
+    uint32_t pre_sad[2];
+    uint32_t zz_sad;
+    uint32_t valid; // bit0: HME ran for this reference (not a base-layer list-1 reference)
+};
+
+// Everything a picture's kernels need, passed by value as the kernel argument.
+struct PicParams {
+    DevPicture     cur;
+    DevPicture     ref[SVTME_MAX_LISTS][SVTME_MAX_REFS];
+    int32_t        dist[SVTME_MAX_LISTS][SVTME_MAX_REFS]; // |poc - ref poc| as uint16 (get_me_reference :1269)
+    svtme_controls ctrl;
+    int32_t        width, height; // input_ptr->width/height == pcs->aligned_width/height
+    int32_t        b64_w, b64_h;
+    int32_t        n_list;
+    int32_t        n_ref[SVTME_MAX_LISTS];
+    int32_t        temporal_layer;
+    int32_t        is_ref;
+    int32_t        serial_refs; // 1: one workgroup walks all references of a b64 in order (cross-reference dependencies)
+    // outputs
+    HmeRefOut           *hme_out; // [n_b64][2][4]
+    uint32_t            *best_sad; // [n_b64][2][4][85]
+    uint32_t            *best_mv; // [n_b64][2][4][85]
+    svtme_search_result *search_results; // [n_b64][2][4]
+    uint32_t            *zz_sad; // [n_b64][2][4]
+    uint32_t            *sr_divisor; // [n_b64][2][4]
+};
+
+// store kernels (store_kernels.hip)
+void launch_store_build(const uint8_t *luma, int luma_stride, const DevPicture &pic, int hme_level1, hipStream_t s);
+// search kernels
+void launch_hme(const PicParams &p, hipStream_t s);
+void launch_me(const PicParams &p, hipStream_t s);
+
+} // namespace svtme

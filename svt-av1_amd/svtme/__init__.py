@@ -1,0 +1,243 @@
+"""Python binding (ctypes) of the MI355X open-loop motion-estimation engine's C ABI (include/svtme.h).
+
+The product is the shared library `libsvtme.so` (HIP kernels + host engine, built by svt-av1_amd/build.sh);
+this module only mirrors the C structs and wraps the entry points for the tests and bench.py. There is no CPU
+fallback: loading fails loudly when the library is missing, and every call fails when no GPU is present.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libsvtme.so")
+
+MAX_LISTS, MAX_REFS, PU_COUNT = 2, 4, 85
+OK, ERR_BAD_ARG, ERR_NO_RESOURCES, ERR_NOT_FOUND, ERR_DEVICE, ERR_UNSUPPORTED = 0, -1, -2, -3, -4, -5
+
+
+class SvtmeError(RuntimeError):
+    def __init__(self, code, what):
+        super().__init__("%s failed with svtme status %d" % (what, code))
+        self.code = code
+
+
+class Sa(C.Structure):
+    _fields_ = [("width", C.c_uint16), ("height", C.c_uint16)]
+
+
+class SaMinMax(C.Structure):
+    _fields_ = [("sa_min", Sa), ("sa_max", Sa)]
+
+
+class Controls(C.Structure):
+    _fields_ = [
+        ("me_sa", SaMinMax), ("hme_l0_sa", SaMinMax), ("hme_l1_sa", Sa), ("hme_l2_sa", Sa),
+        ("num_hme_sa_w", C.c_uint16), ("num_hme_sa_h", C.c_uint16),
+        ("enable_hme_flag", C.c_uint8), ("enable_hme_level0_flag", C.c_uint8), ("enable_hme_level1_flag", C.c_uint8),
+        ("enable_hme_level2_flag", C.c_uint8), ("hme_search_method", C.c_uint8), ("me_search_method", C.c_uint8),
+        ("prehme_enable", C.c_uint8), ("prehme_skip_search_line", C.c_uint8), ("prehme_l1_early_exit", C.c_uint8),
+        ("reserved0", C.c_uint8), ("prehme_sa_cfg", SaMinMax * 2),
+        ("enable_me_hme_ref_pruning", C.c_uint8), ("protect_closest_refs", C.c_uint8),
+        ("prune_ref_if_hme_sad_dev_bigger_than_th", C.c_uint16), ("prune_ref_if_me_sad_dev_bigger_than_th", C.c_uint16),
+        ("enable_me_sr_adjustment", C.c_uint8), ("distance_based_hme_resizing", C.c_uint8),
+        ("reduce_me_sr_based_on_mv_length_th", C.c_uint16), ("stationary_hme_sad_abs_th", C.c_uint16),
+        ("stationary_me_sr_divisor", C.c_uint16), ("reduce_me_sr_based_on_hme_sad_abs_th", C.c_uint16),
+        ("me_sr_divisor_for_low_hme_sad", C.c_uint16),
+        ("reduce_hme_l0_sr_th_min", C.c_uint8), ("reduce_hme_l0_sr_th_max", C.c_uint8), ("stat_factor", C.c_uint8),
+        ("use_best_unipred_cand_only", C.c_uint8), ("prune_me_candidates_th", C.c_int32), ("me_early_exit_th", C.c_uint32),
+    ]
+
+
+assert C.sizeof(Controls) == 84
+
+
+class PresetKey(C.Structure):
+    _fields_ = [("enc_mode", C.c_int8), ("sc_class1", C.c_uint8), ("input_resolution", C.c_uint8),
+                ("reserved", C.c_uint8), ("frame_rate", C.c_uint32)]
+
+
+class Config(C.Structure):
+    _fields_ = [("device", C.c_int32), ("max_width", C.c_uint32), ("max_height", C.c_uint32),
+                ("store_slots", C.c_uint32), ("max_in_flight", C.c_uint32)]
+
+
+class Picture(C.Structure):
+    _fields_ = [
+        ("cur_key", C.c_uint64), ("picture_number", C.c_uint64), ("width", C.c_uint32), ("height", C.c_uint32),
+        ("temporal_layer_index", C.c_uint8), ("is_used_as_reference_flag", C.c_uint8),
+        ("num_of_list_to_search", C.c_uint8), ("num_of_ref_pic_to_search", C.c_uint8 * 2), ("reserved", C.c_uint8 * 3),
+        ("ref_key", (C.c_uint64 * MAX_REFS) * MAX_LISTS), ("ref_picture_number", (C.c_uint64 * MAX_REFS) * MAX_LISTS),
+        ("ctrl", Controls),
+    ]
+
+
+class SearchResult(C.Structure):
+    _fields_ = [("hme_sc_x", C.c_int16), ("hme_sc_y", C.c_int16), ("do_ref", C.c_uint8), ("list_i", C.c_uint8),
+                ("ref_i", C.c_uint8), ("reserved", C.c_uint8), ("hme_sad", C.c_uint64)]
+
+
+SEARCH_RESULT_DTYPE = np.dtype([("hme_sc_x", "<i2"), ("hme_sc_y", "<i2"), ("do_ref", "u1"), ("list_i", "u1"),
+                                ("ref_i", "u1"), ("reserved", "u1"), ("hme_sad", "<u8")])
+assert SEARCH_RESULT_DTYPE.itemsize == C.sizeof(SearchResult) == 16
+
+
+class Results(C.Structure):
+    _fields_ = [("n_b64", C.c_uint32), ("p_sb_best_sad", C.POINTER(C.c_uint32)), ("p_sb_best_mv", C.POINTER(C.c_uint32)),
+                ("search_results", C.POINTER(SearchResult)), ("zz_sad", C.POINTER(C.c_uint32)),
+                ("reduce_me_sr_divisor", C.POINTER(C.c_uint32))]
+
+
+EXPORTS = ("svtme_version", "svtme_derive_controls", "svtme_input_resolution", "svtme_create", "svtme_destroy",
+           "svtme_store_put", "svtme_store_release", "svtme_store_read", "svtme_picture_submit", "svtme_picture_wait",
+           "svtme_picture_done", "svtme_picture_timing", "svtme_unpack_b64")
+
+_lib = None
+
+
+def load_library():
+    """Loads libsvtme.so (no GPU needed to load it or to resolve its symbols)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError("%s is missing: run svt-av1_amd/build.sh (or __graft_entry__.build())" % LIB_PATH)
+    lib = C.CDLL(LIB_PATH)
+    lib.svtme_version.restype = C.c_char_p
+    lib.svtme_derive_controls.argtypes = [C.POINTER(PresetKey), C.POINTER(Controls)]
+    lib.svtme_input_resolution.argtypes = [C.c_uint32, C.c_uint32]
+    lib.svtme_input_resolution.restype = C.c_uint8
+    lib.svtme_create.argtypes = [C.POINTER(Config), C.POINTER(C.c_void_p)]
+    lib.svtme_destroy.argtypes = [C.c_void_p]
+    lib.svtme_destroy.restype = None
+    lib.svtme_store_put.argtypes = [C.c_void_p, C.c_uint64, C.c_uint64, C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32]
+    lib.svtme_store_release.argtypes = [C.c_void_p, C.c_uint64]
+    lib.svtme_store_read.argtypes = [C.c_void_p, C.c_uint64, C.c_int, C.c_void_p, C.c_size_t] + [C.POINTER(C.c_uint32)] * 4
+    lib.svtme_picture_submit.argtypes = [C.c_void_p, C.POINTER(Picture), C.POINTER(C.c_uint64)]
+    lib.svtme_picture_wait.argtypes = [C.c_void_p, C.c_uint64, C.POINTER(Results)]
+    lib.svtme_picture_done.argtypes = [C.c_void_p, C.c_uint64]
+    lib.svtme_picture_timing.argtypes = [C.c_void_p, C.c_uint64, C.POINTER(C.c_float * 3)]
+    lib.svtme_unpack_b64.argtypes = [C.POINTER(Results), C.c_uint32] + [C.c_void_p] * 5
+    _lib = lib
+    return lib
+
+
+def input_resolution(width, height):
+    return int(load_library().svtme_input_resolution(width, height))
+
+
+def derive_controls(enc_mode, width, height, sc_class1=0, frame_rate=30 << 16):
+    key = PresetKey(enc_mode, sc_class1, input_resolution(width, height), 0, frame_rate)
+    c = Controls()
+    rc = load_library().svtme_derive_controls(C.byref(key), C.byref(c))
+    if rc:
+        raise SvtmeError(rc, "svtme_derive_controls")
+    return c
+
+
+class Engine:
+    """One engine = one GPU. Pictures are put into the device store once and referenced by key afterwards."""
+
+    def __init__(self, max_width, max_height, store_slots=24, max_in_flight=4, device=0):
+        self.lib = load_library()
+        self.h = C.c_void_p()
+        cfg = Config(device, max_width, max_height, store_slots, max_in_flight)
+        rc = self.lib.svtme_create(C.byref(cfg), C.byref(self.h))
+        if rc:
+            raise SvtmeError(rc, "svtme_create")
+
+    def close(self):
+        if self.h:
+            self.lib.svtme_destroy(self.h)
+            self.h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def store_put(self, key, picture_number, luma):
+        luma = np.ascontiguousarray(luma, dtype=np.uint8)
+        h, w = luma.shape
+        rc = self.lib.svtme_store_put(self.h, key, picture_number, luma.ctypes.data, w, w, h)
+        if rc:
+            raise SvtmeError(rc, "svtme_store_put")
+
+    def store_release(self, key):
+        rc = self.lib.svtme_store_release(self.h, key)
+        if rc:
+            raise SvtmeError(rc, "svtme_store_release")
+
+    def store_read(self, key, level, shape_hint):
+        h, w = shape_hint
+        buf = np.zeros((h + 144) * (w + 144), np.uint8)
+        st, pw, ph, pad = C.c_uint32(), C.c_uint32(), C.c_uint32(), C.c_uint32()
+        rc = self.lib.svtme_store_read(self.h, key, level, buf.ctypes.data, buf.size, C.byref(st), C.byref(pw),
+                                       C.byref(ph), C.byref(pad))
+        if rc:
+            raise SvtmeError(rc, "svtme_store_read")
+        rows = ph.value + 2 * pad.value
+        return buf[:rows * st.value].reshape(rows, st.value).copy()
+
+    def make_picture(self, width, height, poc, temporal_layer, is_ref, refs, ctrl, key_of=lambda poc: poc):
+        """refs: [[pocs of list 0], [pocs of list 1]]."""
+        p = Picture()
+        p.cur_key = key_of(poc)
+        p.picture_number = poc
+        p.width, p.height = width, height
+        p.temporal_layer_index = temporal_layer
+        p.is_used_as_reference_flag = is_ref
+        p.num_of_list_to_search = 2 if refs[1] else 1
+        for l in range(2):
+            p.num_of_ref_pic_to_search[l] = len(refs[l])
+            for i, r in enumerate(refs[l]):
+                p.ref_key[l][i] = key_of(r)
+                p.ref_picture_number[l][i] = r
+        p.ctrl = ctrl
+        return p
+
+    def submit(self, pic):
+        t = C.c_uint64()
+        rc = self.lib.svtme_picture_submit(self.h, C.byref(pic), C.byref(t))
+        if rc:
+            raise SvtmeError(rc, "svtme_picture_submit")
+        return t.value
+
+    def wait(self, ticket, copy=True):
+        """Returns a dict of numpy arrays shaped [n_b64, 2, 4, ...]."""
+        r = Results()
+        rc = self.lib.svtme_picture_wait(self.h, ticket, C.byref(r))
+        if rc:
+            raise SvtmeError(rc, "svtme_picture_wait")
+        n = r.n_b64
+        out = {
+            "best_sad": np.ctypeslib.as_array(r.p_sb_best_sad, (n, 2, 4, 85)),
+            "best_mv": np.ctypeslib.as_array(r.p_sb_best_mv, (n, 2, 4, 85)),
+            "zz_sad": np.ctypeslib.as_array(r.zz_sad, (n, 2, 4)),
+            "sr_divisor": np.ctypeslib.as_array(r.reduce_me_sr_divisor, (n, 2, 4)),
+        }
+        sr = np.frombuffer(C.string_at(r.search_results, n * 8 * 16), SEARCH_RESULT_DTYPE).reshape(n, 2, 4)
+        out["search_results"] = sr
+        if copy:
+            out = {k: np.array(v) for k, v in out.items()}
+        return out
+
+    def timing(self, ticket):
+        ms = (C.c_float * 3)()
+        rc = self.lib.svtme_picture_timing(self.h, ticket, C.byref(ms))
+        if rc:
+            raise SvtmeError(rc, "svtme_picture_timing")
+        return list(ms)
+
+    def done(self, ticket):
+        rc = self.lib.svtme_picture_done(self.h, ticket)
+        if rc:
+            raise SvtmeError(rc, "svtme_picture_done")
+
+    def run_picture(self, pic):
+        t = self.submit(pic)
+        out = self.wait(t)
+        out["timing_ms"] = self.timing(t)
+        self.done(t)
+        return out
