@@ -1,0 +1,209 @@
+#!/usr/bin/env python3
+"""Open-loop ME throughput of the MI355X engine (pictures/s), one process per GPU.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload NAME]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+A step = the ME of one mini-GOP (all its pictures x all their references) over synthetic pictures that are already
+resident in the device picture store when the timed region starts; results (best SAD / MV per partition, search
+centres) are copied back to pinned host memory inside the timed region. Pictures are independent, so every rank
+runs its own mini-GOPs (weak scaling, no data-path collective); rank 0 prints one JSON line.
+"""
+import argparse
+import json
+import os
+import subprocess
+import sys
+import tempfile
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+for _p in ("svt-av1_amd", "oracle", "tests"):
+    sys.path.insert(0, os.path.join(ROOT, _p))
+
+import numpy as np  # noqa: E402
+
+# BASELINE.json configs -> shapes. "1080p_ra_m3" is configs[2]: 1080p random access, mini-GOP 16, HME L0/L1/L2 + full-pel
+# search, up to 4+3 references (preset 3 = MRP level 3), the single-GPU 1080p configuration the metric is quoted on.
+WORKLOADS = {
+    "1080p_ra_m3": dict(width=1920, height=1080, enc_mode=3, structure="ra", n_frames=17, bit_depth=8),
+    "1080p_ra_m8": dict(width=1920, height=1080, enc_mode=8, structure="ra", n_frames=17, bit_depth=8),
+    "720p_ld_m12": dict(width=1280, height=720, enc_mode=12, structure="ldp", n_frames=17, bit_depth=8),
+    "4k_ra_m8": dict(width=3840, height=2160, enc_mode=8, structure="ra", n_frames=17, bit_depth=10),
+    "8k_ra_m2": dict(width=7680, height=4320, enc_mode=2, structure="ra", n_frames=17, bit_depth=8),
+}
+STAGES = ["zz_centre", "prehme", "hme_l0", "hme_l1", "hme_l2", "integer_search"]
+# Packed-SAD peak of gfx950: 256 CUs x 4 SIMDs x 16 lanes/clk (v_sad_u8 / v_qsad_pk_u16_u8 issue at a quarter of the
+# lane rate, measured in profiles/r01_probe_sad_rates.txt: 146 T/s sustained) x 4 byte differences x 2.4 GHz.
+PEAK_SAD_TOPS = 256 * 4 * 16 * 4 * 2.4e9 / 1e12
+PEAK_HBM_GBS = 8000.0
+
+
+def make_pictures(wl, seed):
+    from svtme import gop, synth
+    frames = synth.synth_sequence(wl["width"], wl["height"], wl["n_frames"], seed=seed, bit_depth=wl["bit_depth"])
+    if wl["structure"] == "ra":
+        pics = gop.random_access(wl["n_frames"], wl["enc_mode"])
+    else:
+        pics = gop.low_delay(wl["n_frames"], wl["enc_mode"], n_list=1 if wl["structure"] == "ldp" else 2)
+    return frames, pics
+
+
+def cpu_baseline(wl, frames, pics, budget_s=20.0):
+    """Times the CPU path on this machine's host cores over a bounded sample of the same workload: the real reference
+    ME with its AVX2 kernels (oracle/_ref/ref_me) when that binary is present, else the scalar oracle port."""
+    import refio
+    from svtme import gop
+    threads = max(1, min(16, os.cpu_count() or 1))
+    b0, b1, n0, n1 = gop.mrp_counts(wl["enc_mode"])
+    rc = (max(b0, n0), max(b1, n1))
+    kind, binary, avx2 = ("reference", refio.REF_BIN, 1) if os.path.exists(refio.REF_BIN) else ("port", refio.ORACLE_BIN, 0)
+    sample = pics[:4] if kind == "port" else pics
+    with tempfile.TemporaryDirectory(prefix="svtme_bench_") as td:
+        job, out = os.path.join(td, "job.bin"), os.path.join(td, "out.bin")
+
+        def run(reps):
+            refio.write_job(job, frames, sample, wl["enc_mode"], mode=refio.MODE_BENCH, threads=threads, use_avx2=avx2,
+                            reps=reps, ref_counts=rc)
+            r = subprocess.run([binary, job, out], capture_output=True, text=True, timeout=600)
+            if r.returncode != 0:
+                raise RuntimeError(r.stderr[-500:])
+            hdr, _ = refio.read_dump(out)
+            return hdr
+        hdr = run(1)
+        per_pass = max(hdr["bench_seconds"], 1e-3)
+        reps = int(min(20, max(1, (budget_s / threads) / per_pass)))
+        if reps > 1:
+            hdr = run(reps)
+    used_avx2 = bool(hdr.get("used_avx2", 0))
+    return {
+        "value": hdr["bench_pictures"] / hdr["bench_seconds"], "unit": "pictures/s", "cores": threads, "kind": kind,
+        "sample": "%d pictures x %d passes of the same %s workload, %s, %d threads over b64 rows" %
+                  (len(sample), hdr["bench_pictures"] // max(1, len(sample)), wl["name"],
+                   "reference C control code + its AVX2 SAD kernels" if (kind == "reference" and used_avx2)
+                   else ("reference C-only kernels" if kind == "reference" else "scalar C restatement"), threads),
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=8)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--workload", default="1080p_ra_m3", choices=sorted(WORKLOADS))
+    ap.add_argument("--in-flight", type=int, default=6)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    import torch
+    import torch.distributed as dist
+    if not torch.cuda.is_available():
+        sys.exit("bench.py needs a GPU: the engine has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    import svtme
+    wl = dict(WORKLOADS[args.workload], name=args.workload)
+    frames, pics = make_pictures(wl, seed=1000 + rank)
+    n, h, w = frames.shape
+    eng = svtme.Engine(w, h, store_slots=n + 1, max_in_flight=args.in_flight, device=local_rank)
+    for i in range(n):
+        eng.store_put(i, i, frames[i])  # inputs resident in HBM before the timed region
+    ctrl = svtme.derive_controls(wl["enc_mode"], w, h)
+    descs = [eng.make_picture(w, h, p.poc, p.temporal_layer, p.is_ref, p.refs, ctrl) for p in pics]
+    n_refs = sum(len(p.refs[0]) + len(p.refs[1]) for p in pics)
+
+    stats = {"hme_ms": 0.0, "me_ms": 0.0, "pic_ms": 0.0, "launches": 0, "ops": np.zeros(6, np.float64)}
+
+    def step(collect):
+        tickets = []
+        for d in descs:
+            if len(tickets) == args.in_flight:
+                finish(tickets.pop(0), collect)
+            tickets.append(eng.submit(d))
+        while tickets:
+            finish(tickets.pop(0), collect)
+
+    def finish(t, collect):
+        eng.wait(t, copy=False)
+        if collect:
+            ms = eng.timing(t)
+            stats["hme_ms"] += ms[0]
+            stats["me_ms"] += ms[1]
+            stats["pic_ms"] += ms[2]
+            stats["launches"] += 1
+            stats["ops"] += np.array(eng.ops(t), np.float64)
+        eng.done(t)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step(False)
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step(True)
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    barrier()
+    if world > 1:
+        tt = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+
+    if rank == 0:
+        pictures = len(descs) * args.steps * world
+        L = max(1, stats["launches"])
+        ops = stats["ops"] / L  # per picture = per launch of each kernel
+        hme_ops, me_ops = float(ops[0:5].sum()), float(ops[5])
+        hme_ms, me_ms = stats["hme_ms"] / L, stats["me_ms"] / L
+        dominant = ("me_kernel", me_ops, me_ms) if stats["me_ms"] >= stats["hme_ms"] else ("hme_kernel", hme_ops, hme_ms)
+        achieved = dominant[1] / (dominant[2] * 1e-3) / 1e12 if dominant[2] > 0 else 0.0
+        # algorithmic HBM bytes of one picture: each needed plane once + results
+        refs_per_pic = n_refs / len(pics)
+        plane_bytes = w * h * (1 + 0.25 + 0.0625)
+        alg_bytes = (1 + refs_per_pic) * plane_bytes + (w // 64) * ((h + 63) // 64) * refs_per_pic * 85 * 8
+        out = {
+            "metric": "open-loop ME pictures/s", "value": pictures / elapsed, "unit": "pictures/s", "n_gpus": world,
+            "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u8", "data": "synthetic",
+            "config": {"workload": args.workload, "width": w, "height": h, "preset": wl["enc_mode"],
+                       "pred_structure": wl["structure"], "pictures_per_step": len(descs),
+                       "refs_per_picture": round(refs_per_pic, 2), "bit_depth": wl["bit_depth"],
+                       "parallelism": "pictures sharded over %d GPU(s), no data-path collective" % world},
+            "roofline": {
+                "bound": "valu", "kernel": dominant[0], "achieved": achieved, "peak": PEAK_SAD_TOPS,
+                "unit": "T abs-diff-acc/s", "frac": achieved / PEAK_SAD_TOPS, "traffic": None,
+                "ops_per_launch": dominant[1], "avg_launch_ms": dominant[2],
+                "hbm_view": {"algorithmic_bytes_per_picture": alg_bytes,
+                             "achieved_GBps": alg_bytes / ((hme_ms + me_ms) * 1e-3) / 1e9 if hme_ms + me_ms > 0 else 0.0,
+                             "peak_GBps": PEAK_HBM_GBS},
+            },
+            "kernels": {"hme_kernel": {"avg_ms": hme_ms, "ops_per_launch": hme_ops,
+                                       "tops": hme_ops / (hme_ms * 1e-3) / 1e12 if hme_ms > 0 else 0.0},
+                        "me_kernel": {"avg_ms": me_ms, "ops_per_launch": me_ops,
+                                      "tops": me_ops / (me_ms * 1e-3) / 1e12 if me_ms > 0 else 0.0},
+                        "ops_by_stage": dict(zip(STAGES, [float(v) for v in ops])),
+                        "picture_ms_incl_d2h": stats["pic_ms"] / L},
+        }
+        if not args.no_cpu_baseline:
+            try:
+                out["cpu_baseline"] = cpu_baseline(wl, frames, pics)
+            except Exception as ex:  # the baseline is a reported number, never a reason to lose the GPU line
+                out["cpu_baseline"] = {"value": None, "unit": "pictures/s", "cores": 0, "kind": "port", "sample": "failed: %r" % (ex,)}
+        print(json.dumps(out), flush=True)
+    eng.close()
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -201,6 +201,11 @@ int svtme_picture_done(svtme_engine *e, svtme_ticket ticket);
  * [0] = HME kernel, [1] = integer-search kernel, [2] = whole picture incl. D2H. Diagnostic only. */
 int svtme_picture_timing(svtme_engine *e, svtme_ticket ticket, float ms[3]);
 
+/* Number of abs-diff-accumulate operations the waited picture's searches performed (after clipping, early exits
+ * and pruning): [0] zero-MV / search-centre SADs, [1] pre-HME, [2] HME L0, [3] L1, [4] L2, [5] integer search.
+ * Diagnostic: the numerator of the roofline figures. */
+int svtme_picture_ops(svtme_engine *e, svtme_ticket ticket, uint64_t ops[6]);
+
 /* Copies one b64's results into caller arrays shaped like MeContext's
  * (p_sb_best_sad[2][4][85], p_sb_best_mv[2][4][85], search_results[2][4], zz_sad[2][4],
  * reduce_me_sr_divisor[2][4]); this is what the shim in motion_estimation_kernel() calls per b64

@@ -52,7 +52,7 @@ struct Flight {
     uint8_t             *d_res = nullptr; // best_sad | best_mv | search_results | zz | div
     // pinned host mirror of d_res
     uint8_t             *h_res = nullptr;
-    size_t               off_mv = 0, off_sr = 0, off_zz = 0, off_div = 0, res_bytes = 0;
+    size_t               off_mv = 0, off_sr = 0, off_zz = 0, off_div = 0, off_ops = 0, res_bytes = 0;
     hipEvent_t           ev[4] = {nullptr, nullptr, nullptr, nullptr}; // start, after HME, after ME, after D2H
 };
 
@@ -149,7 +149,8 @@ extern "C" int svtme_create(const svtme_config *cfg, svtme_engine **out) {
         f.off_sr  = f.off_mv * 2;
         f.off_zz  = f.off_sr + n * sizeof(svtme_search_result);
         f.off_div = f.off_zz + n * 4;
-        f.res_bytes = f.off_div + n * 4;
+        f.off_ops = (f.off_div + n * 4 + 63) / 64 * 64;
+        f.res_bytes = f.off_ops + 64;
         if (hipMalloc((void **)&f.d_hme, n * sizeof(HmeRefOut)) != hipSuccess || hipMalloc((void **)&f.d_res, f.res_bytes) != hipSuccess ||
             hipHostMalloc((void **)&f.h_res, f.res_bytes, hipHostMallocDefault) != hipSuccess)
             return fail(SVTME_ERR_NO_RESOURCES);
@@ -306,11 +307,13 @@ extern "C" int svtme_picture_submit(svtme_engine *e, const svtme_picture *pic, s
     p.search_results = reinterpret_cast<svtme_search_result *>(f->d_res + f->off_sr);
     p.zz_sad         = reinterpret_cast<uint32_t *>(f->d_res + f->off_zz);
     p.sr_divisor     = reinterpret_cast<uint32_t *>(f->d_res + f->off_div);
+    p.ops            = reinterpret_cast<unsigned long long *>(f->d_res + f->off_ops);
 
     for (int si : used) HIP_TRY(hipStreamWaitEvent(e->s_me, e->slots[si].ready, 0));
     HIP_TRY(hipEventRecord(f->ev[0], e->s_me));
     // unsearched / pruned references read as zero
     HIP_TRY(hipMemsetAsync(f->d_res, 0, f->off_sr, e->s_me));
+    HIP_TRY(hipMemsetAsync(f->d_res + f->off_ops, 0, 64, e->s_me));
     launch_hme(p, e->s_me);
     HIP_TRY(hipEventRecord(f->ev[1], e->s_me));
     launch_me(p, e->s_me);
@@ -328,6 +331,7 @@ extern "C" int svtme_picture_submit(svtme_engine *e, const svtme_picture *pic, s
     HIP_TRY(hipMemcpyAsync(f->h_res + f->off_sr, f->d_res + f->off_sr, n * sizeof(svtme_search_result), hipMemcpyDeviceToHost, e->s_me));
     HIP_TRY(hipMemcpyAsync(f->h_res + f->off_zz, f->d_res + f->off_zz, n * 4, hipMemcpyDeviceToHost, e->s_me));
     HIP_TRY(hipMemcpyAsync(f->h_res + f->off_div, f->d_res + f->off_div, n * 4, hipMemcpyDeviceToHost, e->s_me));
+    HIP_TRY(hipMemcpyAsync(f->h_res + f->off_ops, f->d_res + f->off_ops, 64, hipMemcpyDeviceToHost, e->s_me));
     HIP_TRY(hipEventRecord(f->ev[3], e->s_me));
     f->busy   = true;
     f->waited = false;
@@ -392,6 +396,15 @@ extern "C" int svtme_picture_timing(svtme_engine *e, svtme_ticket ticket, float 
     HIP_TRY(hipEventElapsedTime(&ms[0], f->ev[0], f->ev[1]));
     HIP_TRY(hipEventElapsedTime(&ms[1], f->ev[1], f->ev[2]));
     HIP_TRY(hipEventElapsedTime(&ms[2], f->ev[0], f->ev[3]));
+    return SVTME_OK;
+}
+
+extern "C" int svtme_picture_ops(svtme_engine *e, svtme_ticket ticket, uint64_t ops[6]) {
+    if (!e || !ops) return SVTME_ERR_BAD_ARG;
+    std::lock_guard<std::mutex> lock(e->mu);
+    Flight *f = find_flight(e, ticket);
+    if (!f || !f->waited) return SVTME_ERR_NOT_FOUND;
+    memcpy(ops, f->h_res + f->off_ops, 6 * sizeof(uint64_t));
     return SVTME_OK;
 }
 

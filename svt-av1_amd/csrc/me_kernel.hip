@@ -168,6 +168,7 @@ __global__ void __launch_bounds__(ME_THREADS, 2) me_kernel(PicParams p) {
             if (b64y + cy > ref.height - 1) cy = (int16_t)(cy - ((b64y + cy) - (ref.height - 1)));
             const uint32_t hme_sad = wg_block_sad(cur, ref, b64x, b64y, cx, cy, block_w, block_h >> 1, 2, &S.red) << 1;
             best_hme_sad           = hme_sad;
+            if (tid == 0) atomicAdd(&p.ops[0], 2ull * (block_h >> 1) * block_w);
             if (zero_sad <= hme_sad) cx = cy = 0;
             if (cx == 0 && cy == 0) accurate = 0;
         }
@@ -185,6 +186,7 @@ __global__ void __launch_bounds__(ME_THREADS, 2) me_kernel(PicParams p) {
     clip_axis(b64y, org_y, h, -63, p.height);
 
     // ---- open_loop_me_fullpel_search_sblock
+    if (tid == 0) atomicAdd(&p.ops[5], (unsigned long long)w * h * 2048ull);
     if (tid < SVTME_PU_COUNT) S.best[tid] = ~0ull;
     for (int i = tid; i < 32 * 16; i += ME_THREADS) {
         const int r = i >> 4, d = i & 15;

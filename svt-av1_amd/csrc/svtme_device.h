@@ -56,6 +56,9 @@ struct PicParams {
     svtme_search_result *search_results; // [n_b64][2][4]
     uint32_t            *zz_sad; // [n_b64][2][4]
     uint32_t            *sr_divisor; // [n_b64][2][4]
+    // abs-diff-accumulate operations actually performed: [0] zero-MV / centre checks, [1] pre-HME, [2..4] HME L0..L2,
+    // [5] integer search
+    unsigned long long  *ops;
 };
 
 // store kernels (store_kernels.hip)

@@ -90,7 +90,7 @@ class Results(C.Structure):
 
 EXPORTS = ("svtme_version", "svtme_derive_controls", "svtme_input_resolution", "svtme_create", "svtme_destroy",
            "svtme_store_put", "svtme_store_release", "svtme_store_read", "svtme_picture_submit", "svtme_picture_wait",
-           "svtme_picture_done", "svtme_picture_timing", "svtme_unpack_b64")
+           "svtme_picture_done", "svtme_picture_timing", "svtme_picture_ops", "svtme_unpack_b64")
 
 _lib = None
 
@@ -117,6 +117,7 @@ def load_library():
     lib.svtme_picture_wait.argtypes = [C.c_void_p, C.c_uint64, C.POINTER(Results)]
     lib.svtme_picture_done.argtypes = [C.c_void_p, C.c_uint64]
     lib.svtme_picture_timing.argtypes = [C.c_void_p, C.c_uint64, C.POINTER(C.c_float * 3)]
+    lib.svtme_picture_ops.argtypes = [C.c_void_p, C.c_uint64, C.POINTER(C.c_uint64 * 6)]
     lib.svtme_unpack_b64.argtypes = [C.POINTER(Results), C.c_uint32] + [C.c_void_p] * 5
     _lib = lib
     return lib
@@ -230,6 +231,13 @@ class Engine:
             raise SvtmeError(rc, "svtme_picture_timing")
         return list(ms)
 
+    def ops(self, ticket):
+        ops = (C.c_uint64 * 6)()
+        rc = self.lib.svtme_picture_ops(self.h, ticket, C.byref(ops))
+        if rc:
+            raise SvtmeError(rc, "svtme_picture_ops")
+        return [int(v) for v in ops]
+
     def done(self, ticket):
         rc = self.lib.svtme_picture_done(self.h, ticket)
         if rc:
@@ -239,5 +247,6 @@ class Engine:
         t = self.submit(pic)
         out = self.wait(t)
         out["timing_ms"] = self.timing(t)
+        out["ops"] = self.ops(t)
         self.done(t)
         return out

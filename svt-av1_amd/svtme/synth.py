@@ -57,8 +57,8 @@ def synth_sequence(width, height, n_frames, seed=1, motion=(3, -2), noise=2, bit
         f = canvas[oy:oy + height, ox:ox + width].copy()
         for o in range(n_objects):
             p = par[o]
-            ow = 24 + (p[0] % 96)
-            oh = 24 + (p[1] % 96)
+            ow = min(24 + (p[0] % 96), max(8, width // 2))
+            oh = min(24 + (p[1] % 96), max(8, height // 2))
             vx = (p[2] % 15) - 7
             vy = (p[3] % 9) - 4
             x0 = (p[4] * 256 + p[5]) % max(1, width - ow) + vx * k
@@ -68,8 +68,8 @@ def synth_sequence(width, height, n_frames, seed=1, motion=(3, -2), noise=2, bit
             if x1 <= x0c or y1 <= y0c:
                 continue
             # the object carries its own texture: a shifted view of the canvas
-            sy = (m + (p[8] % 64) + (y0c - y0)) % (hh - oh)
-            sx = (m + (p[9] % 64) + (x0c - x0)) % (ww - ow)
+            sy = (m + (p[8] % 64) + (y0c - y0)) % max(1, hh - oh)
+            sx = (m + (p[9] % 64) + (x0c - x0)) % max(1, ww - ow)
             patch = canvas[sy:sy + (y1 - y0c), sx:sx + (x1 - x0c)]
             f[y0c:y1, x0c:x1] = 255 - patch
         if noise:

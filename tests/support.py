@@ -5,6 +5,13 @@ import numpy as np
 import refio
 from svtme import gop, synth
 
+# fields of a b64 record that do not depend on which ME thread processed the previous b64 (the reference keeps
+# per-thread scratch between b64s; see compare_records)
+HANDOVER_FIELDS = ["zz_sad", "sr_divisor", "hme_sc_x", "hme_sc_y"]
+TAIL_FIELDS = ["do_ref", "hme_sad", "me_distortion", "total_me_candidate_index", "me_mv_array", "me_candidate_array",
+               "rc_me_distortion", "me_64x64_distortion", "me_32x32_distortion", "me_16x16_distortion",
+               "me_8x8_distortion", "me_8x8_cost_variance", "stationary_block_present_sb", "rc_me_allow_gm"]
+
 
 def make_job(width, height, n_frames, enc_mode, seed=1, structure="ra", kind="synth", motion=(3, -2)):
     if kind == "synth":
@@ -91,3 +98,28 @@ def engine_vs_oracle(width, height, n_frames, enc_mode, seed=1, structure="ra", 
         if len(msgs) >= max_msgs:
             break
     return msgs
+
+
+MAX_SAD_VALUE = 128 * 128 * 255
+
+
+def searched_mask(bd, pic, pruning_enabled):
+    """[n_b64, 2, 4] bool: references whose integer search ran, reconstructed from a FINAL reference dump:
+    me_prune_ref (EbMotionEstimation.c:1583-1588) marks the references HME had pruned with hme_sad = MAX_SAD_VALUE*64."""
+    n_ref = [len(pic.refs[0]), len(pic.refs[1])]
+    have = np.zeros((1, 2, 4), bool)
+    for l in range(2):
+        have[0, l, :n_ref[l]] = True
+    m = np.broadcast_to(have, bd["hme_sad"].shape).copy()
+    if pruning_enabled:
+        m &= bd["hme_sad"] != MAX_SAD_VALUE * 64
+    return m
+
+
+def canonical(bd, pic, pruning_enabled):
+    """The thread-independent content of a final dump: best SAD / MV only where the search ran."""
+    m = searched_mask(bd, pic, pruning_enabled)[:, :, :, None]
+    out = {f: np.ascontiguousarray(bd[f]) for f in HANDOVER_FIELDS + TAIL_FIELDS}
+    out["best_sad"] = np.where(m, bd["best_sad"], 0).astype(np.uint32)
+    out["best_mv"] = np.where(m, bd["best_mv"], 0).astype(np.uint32)
+    return out

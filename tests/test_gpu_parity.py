@@ -1,0 +1,229 @@
+"""Parity tests proper: the HIP engine, called through its C ABI (libsvtme.so via ctypes), against the oracle and
+against the reference goldens, bit-exact. Everything here needs a real MI355X."""
+import hashlib
+import json
+import os
+
+import numpy as np
+import pytest
+
+import refio
+import support
+import svtme
+
+pytestmark = pytest.mark.gpu
+HERE = os.path.dirname(os.path.abspath(__file__))
+GOLDEN = os.path.join(HERE, "golden")
+
+
+def _golden_mod():
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("make_golden", os.path.join(GOLDEN, "make_golden.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
+
+
+MOD = _golden_mod()
+# the engine refuses the screen-content presets whose later references depend on the first one's 64x64 result
+GPU_CASES = sorted(n for n in MOD.CASES if n != "m4_sc_128x128")
+
+
+@pytest.mark.parametrize("name", GPU_CASES)
+def test_engine_matches_reference_goldens(name):
+    """Engine output vs the dump of the real reference ME (tests/golden/*.npz) on the fields it hands over."""
+    c = MOD.CASES[name]
+    g = np.load(os.path.join(GOLDEN, name + ".npz"))
+    frames, pics, _ = support.make_job(c["width"], c["height"], c["n_frames"], c["enc_mode"], c["seed"],
+                                       c.get("structure", "ra"), c.get("kind", "synth"))
+    outs = support.run_engine_job(frames, pics, c["enc_mode"], c.get("sc_class1", 0), c.get("frame_rate", 30 << 16))
+    for i, (p, out) in enumerate(zip(pics, outs)):
+        bd = g["b64"][i]
+        pruning = bool(g["pic"][i]["ctrl"]["enable_me_hme_ref_pruning"])
+        m = support.searched_mask(bd, p, pruning)
+        for f in ("zz_sad", "sr_divisor"):
+            assert np.array_equal(out[f], bd[f]), (name, p.poc, f)
+        sr = out["search_results"]
+        assert np.array_equal(sr["hme_sc_x"], bd["hme_sc_x"]) and np.array_equal(sr["hme_sc_y"], bd["hme_sc_y"]), (name, p.poc)
+        # references the engine searched == references whose integer search ran in the reference
+        n_ref = [len(p.refs[0]), len(p.refs[1])]
+        have = np.zeros((1, 2, 4), bool)
+        for l in range(2):
+            have[0, l, :n_ref[l]] = True
+        assert np.array_equal((sr["do_ref"] == 1) & have, m), (name, p.poc, "do_ref")
+        mm = np.broadcast_to(m[:, :, :, None], out["best_sad"].shape)
+        assert np.array_equal(out["best_sad"][mm], bd["best_sad"][mm]), (name, p.poc, "best_sad")
+        assert np.array_equal(out["best_mv"][mm], bd["best_mv"][mm]), (name, p.poc, "best_mv")
+
+
+@pytest.mark.parametrize("w,h,n,mode,structure", [
+    (320, 192, 17, 8, "ra"), (328, 200, 17, 12, "ra"), (264, 136, 17, 3, "ra"), (256, 192, 6, 12, "ldp"),
+    (320, 192, 9, 10, "ldb"), (200, 136, 17, 13, "ra"), (192, 128, 9, 1, "ra"), (128, 128, 4, -2, "ldb"),
+])
+def test_engine_matches_oracle_small(w, h, n, mode, structure):
+    msgs = support.engine_vs_oracle(w, h, n, mode, seed=100 + mode, structure=structure)
+    assert not msgs, "\n".join(msgs)
+
+
+@pytest.mark.parametrize("kind", ["noise", "max", "flat"])
+def test_engine_matches_oracle_on_extreme_inputs(kind):
+    msgs = support.engine_vs_oracle(256, 192, 9, 8, seed=7, kind=kind)
+    assert not msgs, "\n".join(msgs)
+
+
+def test_engine_matches_oracle_screen_content_fast_presets():
+    msgs = support.engine_vs_oracle(256, 192, 9, 9, seed=9, sc_class1=1)
+    assert not msgs, "\n".join(msgs)
+
+
+def test_engine_rejects_what_it_does_not_implement():
+    frames, pics, _ = support.make_job(128, 128, 5, 4, seed=1)
+    with pytest.raises(svtme.SvtmeError) as ei:
+        support.run_engine_job(frames, pics, 4, sc_class1=1)
+    assert ei.value.code == svtme.ERR_UNSUPPORTED
+
+
+@pytest.mark.parametrize("name", sorted(MOD.DIGEST_CASES))
+def test_engine_matches_reference_digests_at_full_size(name):
+    """1080p preset 8 / 720p preset 12 / 360p preset 3: sha256 of the engine's masked best SAD / MV arrays and
+    search centres against digests of the real reference's output (tests/golden/digests.json)."""
+    with open(os.path.join(GOLDEN, "digests.json")) as f:
+        dig = json.load(f)["digests"][name]
+    c = MOD.DIGEST_CASES[name]
+    frames, pics, _ = support.make_job(c["width"], c["height"], c["n_frames"], c["enc_mode"], c["seed"], c["structure"])
+    assert hashlib.sha256(frames.tobytes()).hexdigest() == dig["frames_sha256"]
+    outs = support.run_engine_job(frames, pics, c["enc_mode"])
+    for i, (p, out) in enumerate(zip(pics, outs)):
+        sr = out["search_results"]
+        n_ref = [len(p.refs[0]), len(p.refs[1])]
+        have = np.zeros((1, 2, 4, 1), bool)
+        for l in range(2):
+            have[0, l, :n_ref[l]] = True
+        m = have & (sr["do_ref"][:, :, :, None] == 1)
+        fields = {
+            "zz_sad": out["zz_sad"], "sr_divisor": out["sr_divisor"],
+            "hme_sc_x": np.ascontiguousarray(sr["hme_sc_x"]), "hme_sc_y": np.ascontiguousarray(sr["hme_sc_y"]),
+            "best_sad": np.where(m, out["best_sad"], 0).astype(np.uint32),
+            "best_mv": np.where(m, out["best_mv"], 0).astype(np.uint32),
+        }
+        for f, v in fields.items():
+            assert hashlib.sha256(np.ascontiguousarray(v).tobytes()).hexdigest() == dig["pictures"][i][f], (name, i, p.poc, f)
+
+
+def test_device_store_planes_match_oracle():
+    frames, pics, rc = support.make_job(200, 136, 3, 8, seed=5)
+    _, planes = refio.run_oracle(frames, [], 8, mode=refio.MODE_PLANES, ref_counts=rc)
+    eng = svtme.Engine(256, 192, store_slots=4)
+    try:
+        for i, fr in enumerate(frames):
+            eng.store_put(10 + i, i, fr)
+        for i in range(len(frames)):
+            for level in range(3):
+                got = eng.store_read(10 + i, level, frames[i].shape)
+                assert np.array_equal(got, planes[i][level]), (i, level)
+        # overwrite a slot (what temporal filtering does to a picture) and read it back
+        eng.store_put(10, 0, frames[2])
+        assert np.array_equal(eng.store_read(10, 2, frames[0].shape), planes[2][2])
+        eng.store_release(11)
+        with pytest.raises(svtme.SvtmeError):
+            eng.store_read(11, 2, frames[0].shape)
+    finally:
+        eng.close()
+
+
+def test_pictures_in_flight_and_unpack():
+    """Several pictures queued before the first wait give the same results as one at a time; svtme_unpack_b64
+    copies the MeContext-shaped arrays of one block."""
+    import ctypes as C
+    frames, pics, _ = support.make_job(320, 192, 17, 8, seed=21)
+    ref_outs = support.run_engine_job(frames, pics, 8)
+    n, h, w = frames.shape
+    eng = svtme.Engine(w, h, store_slots=n + 1, max_in_flight=4)
+    try:
+        for i in range(n):
+            eng.store_put(i, i, frames[i])
+        ctrl = svtme.derive_controls(8, w, h)
+        tickets = []
+        outs = []
+        for p in pics:
+            if len(tickets) == 4:
+                t = tickets.pop(0)
+                outs.append(eng.wait(t))
+                eng.done(t)
+            tickets.append(eng.submit(eng.make_picture(w, h, p.poc, p.temporal_layer, p.is_ref, p.refs, ctrl)))
+        while tickets:
+            t = tickets.pop(0)
+            outs.append(eng.wait(t))
+            if not tickets:
+                r = svtme.Results()
+                assert eng.lib.svtme_picture_wait(eng.h, t, C.byref(r)) == 0
+                sad = np.zeros((2, 4, 85), np.uint32)
+                mv = np.zeros((2, 4, 85), np.uint32)
+                assert eng.lib.svtme_unpack_b64(C.byref(r), 3, sad.ctypes.data, mv.ctypes.data, None, None, None) == 0
+                assert np.array_equal(sad, outs[-1]["best_sad"][3]) and np.array_equal(mv, outs[-1]["best_mv"][3])
+            eng.done(t)
+        with pytest.raises(svtme.SvtmeError):
+            eng.submit(eng.make_picture(w, h, 5, 0, 1, [[999], []], ctrl))  # unknown reference key
+    finally:
+        eng.close()
+    for a, b in zip(ref_outs, outs):
+        for f in ("best_sad", "best_mv", "zz_sad", "sr_divisor"):
+            assert np.array_equal(a[f], b[f])
+        assert a["search_results"].tobytes() == b["search_results"].tobytes()
+
+
+def test_identical_pictures_give_zero_vectors():
+    """Size-independent property at a full-size picture: a picture searched against a copy of itself has SAD 0 and
+    the zero vector for every partition (first position in raster order with SAD 0 is not necessarily (0,0), so the
+    property is checked on i.i.d. noise, where the match is unique)."""
+    w, h = 1920, 1080
+    fr = support.synth.extreme_sequence(w, h, 1, "noise", seed=3)[0]
+    eng = svtme.Engine(w, h, store_slots=3, max_in_flight=1)
+    try:
+        eng.store_put(0, 0, fr)
+        eng.store_put(1, 1, fr)
+        ctrl = svtme.derive_controls(6, w, h)  # preset 6: no zero-MV early exit, full HME chain
+        out = eng.run_picture(eng.make_picture(w, h, 1, 1, 1, [[0], []], ctrl))
+    finally:
+        eng.close()
+    assert out["best_sad"].shape[0] == 30 * 17
+    assert (out["best_sad"][:, 0, 0, :] == 0).all()
+    # the last b64 row is 56 pixels high: its lower partitions lie in the replicated border, where an earlier
+    # position (one row up) matches just as well - in the reference too - so vectors are checked above it only
+    assert (out["best_mv"][:16 * 30, 0, 0, :] == 0).all()
+    assert (out["search_results"]["do_ref"][:, 0, 0] == 1).all()
+
+
+def test_global_translation_is_recovered():
+    """A picture that is a pure translation of its reference: every interior block finds exactly that vector with
+    SAD 0 (noise content makes the match unique); checked at 1080p through the whole HME + integer-search chain."""
+    w, h, dx, dy = 1920, 1080, 8, -4
+    big = support.synth.extreme_sequence(w + 64, h + 64, 1, "noise", seed=8)[0]
+    ref = big[32:32 + h, 32:32 + w]
+    cur = big[32 + dy:32 + dy + h, 32 + dx:32 + dx + w]  # cur(x, y) = ref(x + dx, y + dy)
+    eng = svtme.Engine(w, h, store_slots=3, max_in_flight=1)
+    try:
+        eng.store_put(0, 0, ref)
+        eng.store_put(1, 1, cur)
+        ctrl = svtme.derive_controls(6, w, h)
+        out = eng.run_picture(eng.make_picture(w, h, 1, 1, 1, [[0], []], ctrl))
+    finally:
+        eng.close()
+    sad = out["best_sad"][:, 0, 0, :].reshape(17, 30, 85)
+    mv = out["best_mv"][:, 0, 0, :].reshape(17, 30, 85)
+    expect = ((dy * 4) & 0xFFFF) << 16 | ((dx * 4) & 0xFFFF)
+    assert (sad[1:-1, 1:-1] == 0).all()
+    assert (mv[1:-1, 1:-1] == expect).all()
+
+
+def test_operation_counts_match_oracle():
+    """The device-side abs-diff operation counters (the numerator of bench.py's roofline figure) equal the counts the
+    oracle logs for the same job, stage by stage."""
+    import json as _json
+    for mode in (8, 3, 12):
+        frames, pics, rc = support.make_job(320, 192, 9, mode, seed=40 + mode)
+        hdr, _ = refio.run_oracle(frames, pics, mode, mode=refio.MODE_DUMP_NOTAIL, threads=4, ref_counts=rc)
+        want = _json.loads(hdr["stdout"].strip().splitlines()[-1])["ops"]
+        outs = support.run_engine_job(frames, pics, mode)
+        got = [sum(o["ops"][i] for o in outs) for i in range(6)]
+        assert got == want, (mode, got, want)
