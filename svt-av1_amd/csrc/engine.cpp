@@ -5,6 +5,8 @@
 // rewritten waits for the last picture that read it. Nothing here blocks the host except svtme_picture_wait.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
+
 #include <mutex>
 #include <new>
 #include <stdio.h>
@@ -49,6 +51,8 @@ struct Flight {
     std::vector<int>     slots; // store slots referenced
     // device
     HmeRefOut           *d_hme = nullptr;
+    MeJob               *d_jobs = nullptr;
+    unsigned long long  *d_keys = nullptr;
     uint8_t             *d_res = nullptr; // best_sad | best_mv | search_results | zz | div
     // pinned host mirror of d_res
     uint8_t             *h_res = nullptr;
@@ -100,6 +104,8 @@ int find_slot(svtme_engine *e, uint64_t key) {
 
 void free_flight(Flight &f) {
     if (f.d_hme) (void)hipFree(f.d_hme);
+    if (f.d_jobs) (void)hipFree(f.d_jobs);
+    if (f.d_keys) (void)hipFree(f.d_keys);
     if (f.d_res) (void)hipFree(f.d_res);
     if (f.h_res) (void)hipHostFree(f.h_res);
     for (auto &ev : f.ev)
@@ -150,8 +156,10 @@ extern "C" int svtme_create(const svtme_config *cfg, svtme_engine **out) {
         f.off_zz  = f.off_sr + n * sizeof(svtme_search_result);
         f.off_div = f.off_zz + n * 4;
         f.off_ops = (f.off_div + n * 4 + 63) / 64 * 64;
-        f.res_bytes = f.off_ops + 64;
+        f.res_bytes = f.off_ops + SVTME_OPS_BYTES;
         if (hipMalloc((void **)&f.d_hme, n * sizeof(HmeRefOut)) != hipSuccess || hipMalloc((void **)&f.d_res, f.res_bytes) != hipSuccess ||
+            hipMalloc((void **)&f.d_jobs, n * sizeof(MeJob)) != hipSuccess ||
+            hipMalloc((void **)&f.d_keys, n * SVTME_PU_COUNT * sizeof(unsigned long long)) != hipSuccess ||
             hipHostMalloc((void **)&f.h_res, f.res_bytes, hipHostMallocDefault) != hipSuccess)
             return fail(SVTME_ERR_NO_RESOURCES);
         for (auto &ev : f.ev)
@@ -302,6 +310,15 @@ extern "C" int svtme_picture_submit(svtme_engine *e, const svtme_picture *pic, s
     const size_t n_b64 = (size_t)p.b64_w * p.b64_h;
     if (n_b64 > e->max_b64) return SVTME_ERR_BAD_ARG;
     p.hme_out        = f->d_hme;
+    p.me_jobs        = f->d_jobs;
+    p.me_keys        = f->d_keys;
+    {
+        // search work items per (b64, ref): 64-position column chunks x groups of 8 rows of the largest window the
+        // controls allow (integer_search_b64 :1319-1345 caps the window at sa_max, rounds the width up to 8 and keeps
+        // the height >= 3)
+        const int w_max = (std::max<int>(k.me_sa.sa_max.width, 1) + 7) & ~7, h_max = std::max<int>(k.me_sa.sa_max.height, 3);
+        p.me_max_items  = ((w_max + 63) / 64) * ((h_max + 7) / 8);
+    }
     p.best_sad       = reinterpret_cast<uint32_t *>(f->d_res);
     p.best_mv        = reinterpret_cast<uint32_t *>(f->d_res + f->off_mv);
     p.search_results = reinterpret_cast<svtme_search_result *>(f->d_res + f->off_sr);
@@ -311,9 +328,7 @@ extern "C" int svtme_picture_submit(svtme_engine *e, const svtme_picture *pic, s
 
     for (int si : used) HIP_TRY(hipStreamWaitEvent(e->s_me, e->slots[si].ready, 0));
     HIP_TRY(hipEventRecord(f->ev[0], e->s_me));
-    // unsearched / pruned references read as zero
-    HIP_TRY(hipMemsetAsync(f->d_res, 0, f->off_sr, e->s_me));
-    HIP_TRY(hipMemsetAsync(f->d_res + f->off_ops, 0, 64, e->s_me));
+    HIP_TRY(hipMemsetAsync(f->d_res + f->off_ops, 0, SVTME_OPS_BYTES, e->s_me));
     launch_hme(p, e->s_me);
     HIP_TRY(hipEventRecord(f->ev[1], e->s_me));
     launch_me(p, e->s_me);
@@ -331,7 +346,7 @@ extern "C" int svtme_picture_submit(svtme_engine *e, const svtme_picture *pic, s
     HIP_TRY(hipMemcpyAsync(f->h_res + f->off_sr, f->d_res + f->off_sr, n * sizeof(svtme_search_result), hipMemcpyDeviceToHost, e->s_me));
     HIP_TRY(hipMemcpyAsync(f->h_res + f->off_zz, f->d_res + f->off_zz, n * 4, hipMemcpyDeviceToHost, e->s_me));
     HIP_TRY(hipMemcpyAsync(f->h_res + f->off_div, f->d_res + f->off_div, n * 4, hipMemcpyDeviceToHost, e->s_me));
-    HIP_TRY(hipMemcpyAsync(f->h_res + f->off_ops, f->d_res + f->off_ops, 64, hipMemcpyDeviceToHost, e->s_me));
+    HIP_TRY(hipMemcpyAsync(f->h_res + f->off_ops, f->d_res + f->off_ops, SVTME_OPS_BYTES, hipMemcpyDeviceToHost, e->s_me));
     HIP_TRY(hipEventRecord(f->ev[3], e->s_me));
     f->busy   = true;
     f->waited = false;
@@ -369,6 +384,12 @@ extern "C" int svtme_picture_wait(svtme_engine *e, svtme_ticket ticket, svtme_re
             }
         }
     }
+    {
+        // the search kernels flag a work-item grid smaller than a window needs (a sizing bug, never a data condition)
+        const uint64_t *slots = reinterpret_cast<const uint64_t *>(f->h_res + f->off_ops);
+        for (int s = 0; s < SVTME_OPS_SLOTS; ++s)
+            if (slots[s * 8 + 7]) return SVTME_ERR_DEVICE;
+    }
     out->n_b64                = f->n_b64;
     out->p_sb_best_sad        = reinterpret_cast<const uint32_t *>(f->h_res);
     out->p_sb_best_mv         = reinterpret_cast<const uint32_t *>(f->h_res + f->off_mv);
@@ -404,7 +425,11 @@ extern "C" int svtme_picture_ops(svtme_engine *e, svtme_ticket ticket, uint64_t 
     std::lock_guard<std::mutex> lock(e->mu);
     Flight *f = find_flight(e, ticket);
     if (!f || !f->waited) return SVTME_ERR_NOT_FOUND;
-    memcpy(ops, f->h_res + f->off_ops, 6 * sizeof(uint64_t));
+    const uint64_t *slots = reinterpret_cast<const uint64_t *>(f->h_res + f->off_ops);
+    for (int k = 0; k < 6; ++k) {
+        ops[k] = 0;
+        for (int s = 0; s < SVTME_OPS_SLOTS; ++s) ops[k] += slots[s * 8 + k];
+    }
     return SVTME_OK;
 }
 

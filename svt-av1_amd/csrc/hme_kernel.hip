@@ -61,7 +61,7 @@ __device__ void stage_src(HmeShared &S, const DevPlane &plane, int ox, int oy, i
 // Exhaustive searches S.sub[0..n_sub) of the staged source block (bw x bh_rows, reference rows `row_step` apart)
 // -> S.key[i] = min over positions of (SAD << 32 | y * sa_w + x); ~0 when no position was evaluated.
 __device__ void wg_search(HmeShared &S, uint8_t *win, int n_sub, int bw, int bh_rows, int row_step, int chunk_log2,
-                          unsigned long long *ops) {
+                          const PicParams &p, int ops_k) {
     const int tid  = threadIdx.x;
     const int bwd  = bw >> 2; // whole source dwords per row
     const int tail = bw & 3; // 0 or 2 leftover source bytes (sixteenth-resolution edge blocks only)
@@ -101,7 +101,7 @@ __device__ void wg_search(HmeShared &S, uint8_t *win, int n_sub, int bw, int bh_
         }
         S.n_band  = nb;
         S.n_batch = nb ? batch + 1 : 0;
-        if (n_ops) atomicAdd(ops, n_ops);
+        if (n_ops) count_ops(p, ops_k, n_ops);
     }
     __syncthreads();
     const int n_band = S.n_band, n_batch = S.n_batch;
@@ -295,7 +295,7 @@ __device__ void hme_level(const PicParams &p, HmeShared &S, uint8_t *win, int le
     stage_src(S, cur, ox, oy, bw, rows, step);
     __syncthreads();
     const int chunk_log2 = rows >= 32 ? 3 : (rows >= 16 ? 2 : 0);
-    wg_search(S, win, nw * nh, bw, rows, step, chunk_log2, &p.ops[2 + level]);
+    wg_search(S, win, nw * nh, bw, rows, step, chunk_log2, p, 2 + level);
     if (threadIdx.x == 0) {
         const int scale = level == 0 ? 4 : (level == 1 ? 2 : 1);
         for (int sh = 0; sh < nh; ++sh)
@@ -334,7 +334,7 @@ __device__ void hme_one_ref(const PicParams &p, HmeShared &S, uint8_t *win, int 
     if (k.me_early_exit_th && searched)
         zz = wg_block_sad(p.cur.lvl[2], p.ref[l][r].lvl[2], b64x, b64y, 0, 0, block_w, block_h >> 1, 2, &S.red) << 1;
     if (threadIdx.x == 0) {
-        if (k.me_early_exit_th && searched) atomicAdd(&p.ops[0], (unsigned long long)(block_h >> 1) * block_w);
+        if (k.me_early_exit_th && searched) count_ops(p, 0, (unsigned long long)(block_h >> 1) * block_w);
         S.cur.zz_sad = zz;
         S.cur.valid  = searched ? 1u : 0u;
     }
@@ -393,7 +393,7 @@ __device__ void hme_one_ref(const PicParams &p, HmeShared &S, uint8_t *win, int 
             if (n_sub) {
                 stage_src(S, cur, ox, oy, bw, rows, step);
                 __syncthreads();
-                wg_search(S, win, n_sub, bw, rows, step, 0, &p.ops[1]);
+                wg_search(S, win, n_sub, bw, rows, step, 0, p, 1);
                 if (threadIdx.x == 0)
                     for (int s = 0; s < 2; ++s)
                         if (slot[s] >= 0)

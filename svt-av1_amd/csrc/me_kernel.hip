@@ -8,23 +8,33 @@
 // svt_ext_eight_sad_calculation_32x32_64x64 :395-451, the single-position forms :122-229,
 // svt_initialize_buffer_32bits (EbMeSadCalculation.c:14).
 //
-// Mapping: one 256-thread workgroup per (b64, reference). The search window ((w+63) x (h+63) bytes) and the
-// 64x64 source block are staged in LDS. A quad of lanes owns 4 horizontally adjacent search positions; each lane
-// of the quad owns one 16-pixel column of the block and walks a run of up to 8 search rows. Per row it issues
-// 128 v_qsad_pk_u16_u8 (4 positions x 4 pixels each) into sixteen packed 4x16-bit accumulators = its 16 8x8 SADs
-// (rows 0,2,4,6 of each 8x8, as the reference's sub-sampled search does; doubled at the end). 16x16 SADs are summed
-// in-lane, 32x32 and 64x64 across the quad with DPP-style lane exchanges. Running minima carry the row number in the
-// low key bits, so the reference's tie rule (first strictly smaller SAD in raster order) is reproduced exactly;
-// at the end of a run every lane merges its minima into 85 workgroup-wide 64-bit keys (SAD, y, x) with LDS atomics.
+// Three kernels per picture:
+//  me_plan_kernel   one wave per (b64, reference): search centre, pruning, search-range divisor, the zero-vs-HME
+//                   centre check and the clipped search window -> one MeJob; resets that reference's 85 keys.
+//  me_search_kernel one wave per work item = up to 16 "runs" (4 adjacent positions x 8 rows) of one window. Windows
+//                   range from 8x3 to 64x64 positions and more, so a picture's few thousand (b64, reference) pairs are
+//                   cut into ~10^4 items of similar cost that fill the chip evenly; items of one window merge through
+//                   64-bit atomic minima in global memory. The item's reference rows (<= 134 rows x 128 bytes) and the
+//                   sampled source rows sit in LDS. A quad of lanes owns a run; each lane of the quad owns one
+//                   16-pixel column of the block. The 4 same-parity rows of a pass are walked together, staggered by
+//                   one sampled source row, so each reference row is read from LDS once for 16 positions:
+//                   512 v_qsad_pk_u16_u8 (4 positions x 4 pixels each) per pass feed packed 16-bit accumulators = the
+//                   8x8 SADs (rows 0,2,4,6 of each 8x8, as the reference's sub-sampled search does; doubled at the
+//                   end). 16x16 SADs are summed in-lane, 32x32 and 64x64 across the quad with DPP lane exchanges.
+//                   Running minima carry the row number in the low key bits, so the reference's tie rule (first
+//                   strictly smaller SAD in raster order) is reproduced exactly: keys order by (SAD, y, x).
+//  me_finish_kernel keys -> p_sb_best_sad / p_sb_best_mv.
 #include <type_traits>
 
 #include "search_common.h"
 
 namespace svtme {
 
-constexpr int ME_THREADS   = 256;
-constexpr int ME_WIN_BYTES = 40 * 1024;
-constexpr int ME_RUN       = 8; // search rows per lane run; the row-in-run number needs 3 key bits
+constexpr int ME_THREADS   = 64;
+constexpr int ME_PD        = 32; // dwords per staged window row: 64 positions + 63 more pixels, rounded up
+constexpr int ME_TILE      = 64; // search positions per tile side
+constexpr int ME_WIN_ROWS  = ME_TILE + 70; // 62 rows under the last position + the staggered walk's overrun
+constexpr int ME_WIN_BYTES = ME_WIN_ROWS * ME_PD * 4;
 
 struct MeShared {
     __align__(16) uint32_t src[32 * 16]; // rows 0,2,..,62 of the source block, 16 dwords each
@@ -33,6 +43,7 @@ struct MeShared {
     uint32_t               div[8];
     int16_t                sc_x[8], sc_y[8];
     uint8_t                do_ref[8];
+    uint8_t                cand[8]; // this entry has an HME result of its own
     uint32_t               red;
     int                    zero; // always 0, but only known at run time
 };
@@ -55,14 +66,43 @@ __device__ __forceinline__ uint32_t quad_xor1(uint32_t v) { return (uint32_t)__b
 __device__ __forceinline__ uint32_t quad_xor2(uint32_t v) { return (uint32_t)__builtin_amdgcn_mov_dpp((int)v, 0x4E, 0xF, 0xF, true); }
 
 typedef unsigned short us2 __attribute__((ext_vector_type(2)));
-// v_pk_min_u16 / v_pk_add_u16 / v_pk_lshlrev_b16 on two 16-bit fields
+// v_pk_min_u16 / v_pk_add_u16 on two 16-bit fields
 __device__ __forceinline__ uint32_t pk_min_u16(uint32_t a, uint32_t b) {
     return __builtin_bit_cast(uint32_t, __builtin_elementwise_min(__builtin_bit_cast(us2, a), __builtin_bit_cast(us2, b)));
 }
+__device__ __forceinline__ uint32_t pk_add_u16(uint32_t a, uint32_t b) {
+    return __builtin_bit_cast(uint32_t, (us2)(__builtin_bit_cast(us2, a) + __builtin_bit_cast(us2, b)));
+}
 
-__global__ void __launch_bounds__(ME_THREADS, 2) me_kernel(PicParams p) {
-    __shared__ MeShared                   S;
-    extern __shared__ __align__(16) uint8_t win[];
+// min over 4 keys with the index of the first minimum
+__device__ __forceinline__ void min4(const uint32_t (&k)[4], uint32_t &best, uint32_t &idx) {
+    best = k[0];
+    idx  = 0;
+#pragma unroll
+    for (uint32_t i = 1; i < 4; ++i)
+        if (k[i] < best) {
+            best = k[i];
+            idx  = i;
+        }
+}
+
+// Runs (4 adjacent positions x 8 rows) per work item in a column chunk of n_xg position quads: at most 16 (one per
+// quad of lanes), and few enough that an item never spans more than 8 row groups = the 64 search rows LDS holds.
+__device__ __forceinline__ int me_runs_per_item(int n_xg) { return min(16, 7 * n_xg); }
+
+// Work items of a w x h window: per 64-position column chunk, ceil(runs / runs per item).
+__device__ __forceinline__ int me_item_count(int w, int h) {
+    const int n_yg = (h + 7) >> 3;
+    int       n    = 0;
+    for (int tx0 = 0; tx0 < w; tx0 += ME_TILE) {
+        const int n_xg = (min(ME_TILE, w - tx0) + 3) >> 2, cap = me_runs_per_item(n_xg);
+        n += (n_xg * n_yg + cap - 1) / cap;
+    }
+    return n;
+}
+
+__global__ void __launch_bounds__(ME_THREADS) me_plan_kernel(PicParams p) {
+    __shared__ MeShared S;
     const svtme_controls &k   = p.ctrl;
     const int             tid = threadIdx.x;
     const int             b64 = blockIdx.x;
@@ -75,38 +115,51 @@ __global__ void __launch_bounds__(ME_THREADS, 2) me_kernel(PicParams p) {
         my_l = 1;
     }
 
-    // ---- set_final_seach_centre_sb (:2117-2316): one thread walks the references in order; the running
-    // centre / SAD are not reset between references (base-layer list-1 references inherit the previous SAD).
+    // ---- set_final_seach_centre_sb (:2117-2316). Lanes 0-7 fetch the best HME region of one (list, ref) each; lane 0
+    // then walks them in order: the running centre / SAD are not reset between references (base-layer list-1
+    // references inherit the previous SAD).
     const HmeRefOut *hme = &p.hme_out[b64 * SVTME_MAX_LISTS * SVTME_MAX_REFS];
-    if (tid == 0) {
-        for (int i = 0; i < 8; ++i) { // init_me_hme_data :2913-2923
-            S.sc_x[i] = S.sc_y[i] = 0;
-            S.hsad[i]             = 0xFFFFFFFFull;
-            S.do_ref[i]           = 1;
-            S.div[i]              = 1;
+    int              level = -1;
+    if (k.enable_hme_level0_flag && !k.enable_hme_level1_flag && !k.enable_hme_level2_flag) level = 0;
+    if (k.enable_hme_level1_flag && !k.enable_hme_level2_flag) level = 1;
+    if (k.enable_hme_level2_flag) level = 2;
+    if (tid < 8) {
+        const int l = tid >> 2, r = tid & 3;
+        int16_t   hx = 0, hy = 0;
+        u64       hsad = 0;
+        bool      cand = false;
+        if (l < p.n_list && r < p.n_ref[l] && ref_searched(p, l) && k.enable_hme_flag && level >= 0) {
+            const HmeRefOut &h = hme[tid];
+            cand = true;
+            hx   = h.lx[level][0];
+            hy   = h.ly[level][0];
+            hsad = h.lsad[level][0];
+            for (int sh = 0; sh < k.num_hme_sa_h; ++sh)
+                for (int sw = (sh == 0 ? 1 : 0); sw < k.num_hme_sa_w; ++sw)
+                    if (h.lsad[level][sw * 2 + sh] < hsad) {
+                        hx   = h.lx[level][sw * 2 + sh];
+                        hy   = h.ly[level][sw * 2 + sh];
+                        hsad = h.lsad[level][sw * 2 + sh];
+                    }
         }
+        S.sc_x[tid] = hx;
+        S.sc_y[tid] = hy;
+        S.hsad[tid] = hsad;
+        S.cand[tid] = cand;
+    }
+    __syncthreads();
+    if (tid == 0) {
         int16_t hx = 0, hy = 0, cx = 0, cy = 0;
         u64     hsad = 0;
-        int     level = -1;
-        if (k.enable_hme_level0_flag && !k.enable_hme_level1_flag && !k.enable_hme_level2_flag) level = 0;
-        if (k.enable_hme_level1_flag && !k.enable_hme_level2_flag) level = 1;
-        if (k.enable_hme_level2_flag) level = 2;
-        for (int l = 0; l < p.n_list; ++l)
-            for (int r = 0; r < p.n_ref[l]; ++r) {
+        for (int i = 0; i < 8; ++i) {
+            const int l = i >> 2, r = i & 3;
+            if (l < p.n_list && r < p.n_ref[l]) {
                 if (ref_searched(p, l)) {
                     if (k.enable_hme_flag) {
-                        if (level >= 0) {
-                            const HmeRefOut &h = hme[l * SVTME_MAX_REFS + r];
-                            hx   = h.lx[level][0];
-                            hy   = h.ly[level][0];
-                            hsad = h.lsad[level][0];
-                            for (int sh = 0; sh < k.num_hme_sa_h; ++sh)
-                                for (int sw = (sh == 0 ? 1 : 0); sw < k.num_hme_sa_w; ++sw)
-                                    if (h.lsad[level][sw * 2 + sh] < hsad) {
-                                        hx   = h.lx[level][sw * 2 + sh];
-                                        hy   = h.ly[level][sw * 2 + sh];
-                                        hsad = h.lsad[level][sw * 2 + sh];
-                                    }
+                        if (S.cand[i]) {
+                            hx   = S.sc_x[i];
+                            hy   = S.sc_y[i];
+                            hsad = S.hsad[i];
                         }
                         cx = hx;
                         cy = hy;
@@ -114,10 +167,16 @@ __global__ void __launch_bounds__(ME_THREADS, 2) me_kernel(PicParams p) {
                 } else {
                     cx = cy = 0;
                 }
-                S.sc_x[l * 4 + r] = cx;
-                S.sc_y[l * 4 + r] = cy;
-                S.hsad[l * 4 + r] = hsad;
+                S.sc_x[i] = cx;
+                S.sc_y[i] = cy;
+                S.hsad[i] = hsad;
+            } else { // init_me_hme_data :2913-2923
+                S.sc_x[i] = S.sc_y[i] = 0;
+                S.hsad[i]             = 0xFFFFFFFFull;
             }
+            S.do_ref[i] = 1;
+            S.div[i]    = 1;
+        }
         // ---- hme_prune_ref_and_adjust_sr (:2373-2410), over all 2x4 entries
         if (k.enable_hme_flag && (k.enable_me_sr_adjustment || k.enable_me_hme_ref_pruning)) {
             u64 best = ~0ull;
@@ -155,7 +214,12 @@ __global__ void __launch_bounds__(ME_THREADS, 2) me_kernel(PicParams p) {
         p.zz_sad[b64 * 8 + tid] = have ? hme[tid].zz_sad : ~0u;
     }
     const int my = my_l * 4 + my_r;
-    if (!S.do_ref[my]) return;
+    MeJob    *job = &p.me_jobs[b64 * 8 + my];
+    for (int pu = tid; pu < SVTME_PU_COUNT; pu += ME_THREADS) p.me_keys[(size_t)(b64 * 8 + my) * SVTME_PU_COUNT + pu] = ~0ull;
+    if (!S.do_ref[my]) {
+        if (tid == 0) *job = MeJob{0, 0, 0, 0};
+        return;
+    }
 
     // ---- integer_search_b64 for (my_l, my_r)
     const DevPlane &cur = p.cur.lvl[2];
@@ -166,7 +230,6 @@ __global__ void __launch_bounds__(ME_THREADS, 2) me_kernel(PicParams p) {
     int16_t         h = (int16_t)min((int)(int16_t)k.me_sa.sa_min.height * dist, (int)k.me_sa.sa_max.height);
     w = (int16_t)((max(1, (int)((uint32_t)w / S.div[my])) + 7) & ~0x07);
     h = (int16_t)max(3, (int)((uint32_t)h / S.div[my]));
-    const int16_t h0 = h, w0 = w;
     const uint32_t zz = hme[my_l * SVTME_MAX_REFS + my_r].zz_sad;
     if (k.me_early_exit_th) {
         if (zz < k.me_early_exit_th / 6) w = h = 1;
@@ -182,7 +245,7 @@ __global__ void __launch_bounds__(ME_THREADS, 2) me_kernel(PicParams p) {
             if (b64y + cy > ref.height - 1) cy = (int16_t)(cy - ((b64y + cy) - (ref.height - 1)));
             const uint32_t hme_sad = wg_block_sad(cur, ref, b64x, b64y, cx, cy, block_w, block_h >> 1, 2, &S.red) << 1;
             best_hme_sad           = hme_sad;
-            if (tid == 0) atomicAdd(&p.ops[0], 2ull * (block_h >> 1) * block_w);
+            if (tid == 0) count_ops(p, 0, 2ull * (block_h >> 1) * block_w);
             if (zero_sad <= hme_sad) cx = cy = 0;
             if (cx == 0 && cy == 0) accurate = 0;
         }
@@ -192,241 +255,303 @@ __global__ void __launch_bounds__(ME_THREADS, 2) me_kernel(PicParams p) {
             // rejected by the host for now)
         }
     }
-    (void)h0;
-    (void)w0;
     int16_t org_x = (int16_t)(cx - (w >> 1)), org_y = (int16_t)(cy - (h >> 1));
     clip_axis(b64x, org_x, w, -63, p.width);
     w = (int16_t)(w < 8 ? w : (w & ~0x07));
     clip_axis(b64y, org_y, h, -63, p.height);
 
+    if (tid == 0) {
+        *job = MeJob{org_x, org_y, w, h};
+        count_ops(p, 5, (unsigned long long)w * h * 2048ull);
+        if (me_item_count(w, h) > p.me_max_items) count_ops(p, 7, 1); // cannot happen: the host sized the grid from sa_max
+    }
+}
+
+__global__ void __launch_bounds__(ME_THREADS, 2) me_search_kernel(PicParams p) {
+    __shared__ MeShared               S;
+    __shared__ __align__(16) uint32_t win[ME_WIN_BYTES / 4];
+    const int tid = threadIdx.x;
+    const int b64 = blockIdx.x;
+    const int b64x = (b64 % p.b64_w) * 64, b64y = (b64 / p.b64_w) * 64;
+    int       my_l = 0, my_r = blockIdx.y;
+    if (my_r >= p.n_ref[0]) {
+        my_r -= p.n_ref[0];
+        my_l = 1;
+    }
+    const int   my  = my_l * 4 + my_r;
+    const MeJob job = p.me_jobs[b64 * 8 + my];
+    const int   w = job.w, h = job.h, org_x = job.org_x, org_y = job.org_y;
+    if (w <= 0) return;
+    // ---- which runs are this item's: column chunks of 64 positions, each cut into items of <= 16 runs
+    const int n_yg = (h + 7) >> 3;
+    int       item = blockIdx.z, tx0 = 0, n_xg = 0, r0 = 0, r1 = 0;
+    bool      found = false;
+    for (; tx0 < w; tx0 += ME_TILE) {
+        n_xg               = (min(ME_TILE, w - tx0) + 3) >> 2;
+        const int n_run    = n_xg * n_yg;
+        const int cap      = me_runs_per_item(n_xg);
+        const int n_item   = (n_run + cap - 1) / cap;
+        if (item < n_item) {
+            const int per = (n_run + n_item - 1) / n_item;
+            r0            = item * per;
+            r1            = min(n_run, r0 + per);
+            found         = r0 < r1;
+            break;
+        }
+        item -= n_item;
+    }
+    if (!found) return;
+    const int yg0 = r0 / n_xg, yg1 = (r1 - 1) / n_xg;
+    const int ty0 = yg0 * 8, rows = min(h, yg1 * 8 + 8) - ty0; // search rows staged for this item
+
+    const DevPlane &cur = p.cur.lvl[2];
+    const DevPlane &ref = p.ref[my_l][my_r].lvl[2];
+    if (tid == 0) S.zero = 0;
     // ---- open_loop_me_fullpel_search_sblock
-    if (tid == 0) atomicAdd(&p.ops[5], (unsigned long long)w * h * 2048ull);
-    if (tid < SVTME_PU_COUNT) S.best[tid] = ~0ull;
+    for (int i = tid; i < SVTME_PU_COUNT; i += ME_THREADS) S.best[i] = ~0ull;
+#pragma unroll
     for (int i = tid; i < 32 * 16; i += ME_THREADS) {
         const int r = i >> 4, d = i & 15;
         S.src[i] = *reinterpret_cast<const uint32_t *>(cur.pix + (ptrdiff_t)(b64y + 2 * r) * cur.stride + b64x + 4 * d);
     }
-    const int n_xg  = (w + 3) >> 2;
-    const int pitch = n_xg * 4 + 64; // bytes per staged window row
-    const int pd    = pitch >> 2;
-    // search rows per LDS band: a position reads rows y .. y+62, and the staggered walk runs up to 8 rows past that
-    // for positions that are then discarded
-    int       band_rows = ME_WIN_BYTES / pitch - 70;
-    if (band_rows < 1) band_rows = 1;
-    const int quad = tid >> 2, col = tid & 3;
+    const int       quad = tid >> 2, col = tid & 3;
     const uint32_t *sbase = &S.src[col * 4];
-    if (tid == 0) S.zero = 0;
-    __syncthreads();
-    const int opaque_zero = S.zero;
 
-    for (int y0 = 0; y0 < h; y0 += band_rows) {
-        const int rows = min(band_rows, h - y0);
-        __syncthreads();
+    {
         {
-            uint32_t *dst = reinterpret_cast<uint32_t *>(win);
-            const int n   = pd * (rows + 62);
-            for (int i = tid; i < n; i += ME_THREADS) {
-                const int r = i / pd, d = i - r * pd;
-                dst[i] = load_u32_any(ref.pix + (ptrdiff_t)(b64y + org_y + y0 + r) * ref.stride + b64x + org_x + 4 * d);
-            }
-        }
-        __syncthreads();
-        const int n_run   = (rows + ME_RUN - 1) / ME_RUN;
-        const int run_len = (rows + n_run - 1) / n_run;
-        const int n_unit  = n_xg * n_run;
-        for (int ub = 0; ub < n_unit; ub += ME_THREADS / 4) {
-            const int  u     = ub + quad;
-            const bool valid = u < n_unit;
-            const int  run   = valid ? u / n_xg : 0;
-            const int  xg    = valid ? u - run * n_xg : 0;
-            const int  ya    = run * run_len, yb = min(rows, ya + run_len);
-            // running minima of this lane: key = SAD * 8 + row-in-run (8x8: packed 16-bit; larger: 32-bit)
-            uint32_t b8[8][2][2];
-            uint32_t b16[4][4], b32[2][4], b64k[4];
-#pragma unroll
-            for (int a = 0; a < 8; ++a)
-#pragma unroll
-                for (int c = 0; c < 2; ++c) b8[a][c][0] = b8[a][c][1] = 0xFFFFFFFFu;
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-#pragma unroll
-                for (int a = 0; a < 4; ++a) b16[a][i] = 0xFFFFFFFFu;
-                b32[0][i] = b32[1][i] = b64k[i] = 0xFFFFFFFFu;
-            }
-            // Two passes per run: its even rows, then its odd rows. The (up to) 4 rows of a pass are walked together,
-            // staggered by one sampled source row: position t meets source row m at step s = t + m, while the lane holds
-            // reference row (first row of the pass + 2 s) in registers. Every reference row is read from LDS once for 4
-            // positions and every source row once (kept for 4 steps).
-            for (int par = 0; par < 2; ++par) {
-                const int yfirst = ya + par;
-                const int n_pos  = valid ? min(4, max(0, (yb - yfirst + 1) >> 1)) : 0; // same in the 4 lanes of a quad
-                if (__ballot(n_pos > 0) == 0) continue;
-                const uint32_t *wrow = reinterpret_cast<const uint32_t *>(win) + yfirst * pd + xg + col * 4;
-                const uint32_t *wrow_odd = wrow + 1 + opaque_zero;
-                u64             acc0[4], acc1[4], t16[4];
-                uint32_t        half[4][4], topv[4][4], sw[4][4];
-#pragma unroll
-                for (int t = 0; t < 4; ++t) {
-                    acc0[t] = acc1[t] = t16[t] = 0;
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) half[t][i] = topv[t][i] = 0;
-                }
-                static_for<0, 35>([&](auto s_c) {
-                    constexpr int   s  = decltype(s_c)::value;
-                    // the four 8-byte operands overlap by a dword. The odd pairs are read through a second pointer the
-                    // compiler cannot prove equal to the first (+ a zero it only sees at run time), so every pair lands in its
-                    // own aligned register pair straight from LDS instead of being assembled with register copies.
-                    const uint32_t *rr = wrow + (2 * s) * pd, *rq = wrow_odd + (2 * s) * pd;
-                    const u64 p01 = ((u64)rr[1] << 32) | rr[0], p12 = ((u64)rq[1] << 32) | rq[0];
-                    const u64 p23 = ((u64)rr[3] << 32) | rr[2], p34 = ((u64)rq[3] << 32) | rq[2];
-                    if constexpr (s < 32) {
-                        const uint4 v = *reinterpret_cast<const uint4 *>(sbase + s * 16);
-                        sw[s & 3][0] = v.x, sw[s & 3][1] = v.y, sw[s & 3][2] = v.z, sw[s & 3][3] = v.w;
+            __syncthreads();
+            {
+                // stage the window: 2 rows per trip, lane = dword within the row (unaligned 4-byte loads)
+                const int      ndw = n_xg + 16, nrow = rows + 62, d = tid & 31;
+                const uint8_t *g = ref.pix + (ptrdiff_t)(b64y + org_y + ty0 + (tid >> 5)) * ref.stride + (b64x + org_x + tx0 + 4 * d);
+                uint32_t      *dst = win + (tid >> 5) * ME_PD + d;
+                if (d < ndw) {
+#pragma unroll 4
+                    for (int r = tid >> 5; r < nrow; r += 2) {
+                        uint32_t v;
+                        __builtin_memcpy(&v, g, 4);
+                        *dst = v;
+                        g += 2 * (ptrdiff_t)ref.stride;
+                        dst += 2 * ME_PD;
                     }
-                    static_for<0, 4>([&](auto t_c) {
-                        constexpr int t = decltype(t_c)::value;
-                        constexpr int m = s - t; // sampled source row (source row 2m) of position t at this step
-                        if constexpr (m >= 0 && m <= 31) {
-                            acc0[t] = __builtin_amdgcn_qsad_pk_u16_u8(p01, sw[m & 3][0], acc0[t]);
-                            acc0[t] = __builtin_amdgcn_qsad_pk_u16_u8(p12, sw[m & 3][1], acc0[t]);
-                            acc1[t] = __builtin_amdgcn_qsad_pk_u16_u8(p23, sw[m & 3][2], acc1[t]);
-                            acc1[t] = __builtin_amdgcn_qsad_pk_u16_u8(p34, sw[m & 3][3], acc1[t]);
-                            if constexpr ((m & 3) == 3) {
-                                // an 8x8 block row of position t is complete
-                                constexpr int  by  = m >> 2, a = by >> 1;
-                                const bool     on  = t < n_pos;
-                                const uint32_t yr  = (uint32_t)(par + 2 * t);
-                                const uint32_t ypk = yr | (yr << 16);
-                                if (on) {
-                                    // 8x8: key16 = sad * 8 + yr (sad <= 8160: fits 16 bits, the add never carries), two positions per dword
+                }
+            }
+            __syncthreads();
+            const int opaque_zero = S.zero;
+            // few runs: each parity of a run gets its own quad
+            const bool split  = r1 - r0 <= ME_THREADS / 8;
+            const int  n_unit = split ? 2 * (r1 - r0) : r1 - r0;
+            const int  n_it   = split ? 1 : 2;
+            {
+                const int  u     = quad;
+                const bool valid = u < n_unit;
+                const int  run   = r0 + (valid ? (split ? u >> 1 : u) : 0);
+                const int  par0  = split ? (u & 1) : 0;
+                const int  yg    = run / n_xg;
+                const int  xg    = run - yg * n_xg;
+                const int  ya    = yg * 8 - ty0, yb = min(rows, ya + 8);
+                // running minima of this lane. 8x8: packed 16-bit keys SAD * 8 + row-in-run, two positions per dword;
+                // 16x16: SAD << 16 | row; larger: SAD << 3 | row. A position that does not exist carries an all-ones row
+                // mask, which makes its keys all ones.
+                uint32_t b8[8][2][2];
+                uint32_t b16[4][4], b32[2][4], b64k[4];
 #pragma unroll
-                                    for (int c = 0; c < 2; ++c)
+                for (int a = 0; a < 8; ++a)
 #pragma unroll
-                                        for (int hw = 0; hw < 2; ++hw) {
-                                            const uint32_t v  = (uint32_t)((c ? acc1[t] : acc0[t]) >> (32 * hw));
-                                            b8[by][c][hw]     = pk_min_u16(b8[by][c][hw], (v << 3) + ypk);
+                    for (int c = 0; c < 2; ++c) b8[a][c][0] = b8[a][c][1] = 0xFFFFFFFFu;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+#pragma unroll
+                    for (int a = 0; a < 4; ++a) b16[a][i] = 0xFFFFFFFFu;
+                    b32[0][i] = b32[1][i] = b64k[i] = 0xFFFFFFFFu;
+                }
+                // The 4 same-parity rows of a pass are walked together, staggered by one sampled source row: position t
+                // meets source row m at step s = t + m, while the lane holds reference row (first row of the pass + 2 s) in
+                // registers. Every reference row is read from LDS once for 4 positions and every source row once (kept
+                // for 4 steps).
+                for (int it = 0; it < n_it; ++it) {
+                    const int par    = par0 + it;
+                    const int yfirst = ya + par;
+                    const int n_pos  = valid ? min(4, max(0, (yb - yfirst + 1) >> 1)) : 0; // same in the 4 lanes of a quad
+                    if (__ballot(n_pos > 0) == 0) continue;
+                    const uint32_t *wrow = win + yfirst * ME_PD + xg + col * 4;
+                    // The four 8-byte operands of a step overlap by a dword. The odd pairs are read through a second
+                    // pointer the compiler cannot prove equal to the first (+ a zero it only sees at run time), so every
+                    // pair lands in its own aligned register pair straight from LDS instead of being assembled with copies.
+                    const uint32_t *wodd = wrow + 1 + opaque_zero;
+                    uint32_t        ypk[4], yrk[4];
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) {
+                        const uint32_t yr = (uint32_t)(par + 2 * t);
+                        ypk[t]            = t < n_pos ? yr * 0x10001u : 0xFFFFFFFFu;
+                        yrk[t]            = t < n_pos ? yr : 0xFFFFFFFFu;
+                    }
+                    u64      acc0[4], acc1[4];
+                    uint32_t t16[4][2], half[4][2], topv[4][2], sw[4][4];
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) {
+                        acc0[t] = acc1[t] = 0;
+                        t16[t][0] = t16[t][1] = half[t][0] = half[t][1] = topv[t][0] = topv[t][1] = 0;
+                    }
+                    static_for<0, 35>([&](auto s_c) {
+                        constexpr int   s  = decltype(s_c)::value;
+                        const uint32_t *rr = wrow + (2 * s) * ME_PD, *rq = wodd + (2 * s) * ME_PD;
+                        const u64 p01 = ((u64)rr[1] << 32) | rr[0], p12 = ((u64)rq[1] << 32) | rq[0];
+                        const u64 p23 = ((u64)rr[3] << 32) | rr[2], p34 = ((u64)rq[3] << 32) | rq[2];
+                        if constexpr (s < 32) {
+                            const uint4 v = *reinterpret_cast<const uint4 *>(sbase + s * 16);
+                            sw[s & 3][0] = v.x, sw[s & 3][1] = v.y, sw[s & 3][2] = v.z, sw[s & 3][3] = v.w;
+                        }
+                        static_for<0, 4>([&](auto t_c) {
+                            constexpr int t = decltype(t_c)::value;
+                            constexpr int m = s - t; // sampled source row (source row 2m) of position t at this step
+                            if constexpr (m >= 0 && m <= 31) {
+                                acc0[t] = __builtin_amdgcn_qsad_pk_u16_u8(p01, sw[m & 3][0], acc0[t]);
+                                acc0[t] = __builtin_amdgcn_qsad_pk_u16_u8(p12, sw[m & 3][1], acc0[t]);
+                                acc1[t] = __builtin_amdgcn_qsad_pk_u16_u8(p23, sw[m & 3][2], acc1[t]);
+                                acc1[t] = __builtin_amdgcn_qsad_pk_u16_u8(p34, sw[m & 3][3], acc1[t]);
+                                if constexpr ((m & 3) == 3) {
+                                    // an 8x8 block row of position t is complete (SAD <= 8160: the shifted key fits its 16 bits)
+                                    constexpr int  by = m >> 2, a = by >> 1;
+                                    const uint32_t l0 = (uint32_t)acc0[t], h0 = (uint32_t)(acc0[t] >> 32);
+                                    const uint32_t l1 = (uint32_t)acc1[t], h1 = (uint32_t)(acc1[t] >> 32);
+                                    b8[by][0][0] = pk_min_u16(b8[by][0][0], (l0 << 3) | ypk[t]);
+                                    b8[by][0][1] = pk_min_u16(b8[by][0][1], (h0 << 3) | ypk[t]);
+                                    b8[by][1][0] = pk_min_u16(b8[by][1][0], (l1 << 3) | ypk[t]);
+                                    b8[by][1][1] = pk_min_u16(b8[by][1][1], (h1 << 3) | ypk[t]);
+                                    acc0[t] = acc1[t] = 0;
+                                    if constexpr ((by & 1) == 0) {
+                                        t16[t][0] = pk_add_u16(l0, l1);
+                                        t16[t][1] = pk_add_u16(h0, h1);
+                                    } else {
+                                        // a row of 16x16 partitions is complete (SAD <= 32640)
+                                        const uint32_t d0 = pk_add_u16(t16[t][0], pk_add_u16(l0, l1));
+                                        const uint32_t d1 = pk_add_u16(t16[t][1], pk_add_u16(h0, h1));
+                                        b16[a][0] = min(b16[a][0], (d0 << 16) | yrk[t]);
+                                        b16[a][1] = min(b16[a][1], (d0 & 0xFFFF0000u) | yrk[t]);
+                                        b16[a][2] = min(b16[a][2], (d1 << 16) | yrk[t]);
+                                        b16[a][3] = min(b16[a][3], (d1 & 0xFFFF0000u) | yrk[t]);
+                                        if constexpr ((a & 1) == 0) { // 32-row column sums still fit 16 bits (<= 65280)
+                                            half[t][0] = d0;
+                                            half[t][1] = d1;
+                                        } else {
+                                            half[t][0] = pk_add_u16(half[t][0], d0);
+                                            half[t][1] = pk_add_u16(half[t][1], d1);
                                         }
-                                }
-                                t16[t] += acc0[t] + acc1[t]; // 16-bit fields stay <= 32640
-                                acc0[t] = acc1[t] = 0;
-                                if constexpr ((by & 1) == 1) {
-                                    // a 16-row band (one row of 16x16 partitions) is complete: 32-bit sums per position from here on
-#pragma unroll
-                                    for (int i = 0; i < 4; ++i) {
-                                        const uint32_t sv = (uint32_t)(t16[t] >> (16 * i)) & 0xFFFFu;
-                                        if (on) b16[a][i] = min(b16[a][i], (sv << 3) | yr);
-                                        half[t][i] += sv;
-                                    }
-                                    t16[t] = 0;
-                                    if constexpr (a == 1) {
-#pragma unroll
-                                        for (int i = 0; i < 4; ++i) {
-                                            topv[t][i] = half[t][i];
-                                            half[t][i] = 0;
+                                        if constexpr (a == 1) {
+                                            topv[t][0] = half[t][0];
+                                            topv[t][1] = half[t][1];
                                         }
-                                    }
-                                    if constexpr (a == 3) { // the whole block: 32x32 and 64x64 sums across the quad
+                                        if constexpr (a == 3) { // the whole block: 32x32 and 64x64 sums across the quad
 #pragma unroll
-                                        for (int i = 0; i < 4; ++i) {
-                                            uint32_t tp = topv[t][i], bt = half[t][i];
-                                            tp += quad_xor1(tp);
-                                            bt += quad_xor1(bt);
-                                            uint32_t all = tp + bt;
-                                            all += quad_xor2(all);
-                                            if (on) {
-                                                b32[0][i] = min(b32[0][i], (tp << 3) | yr);
-                                                b32[1][i] = min(b32[1][i], (bt << 3) | yr);
-                                                b64k[i]   = min(b64k[i], (all << 3) | yr);
+                                            for (int i = 0; i < 4; ++i) {
+                                                const uint32_t tw_ = topv[t][i >> 1], bw_ = half[t][i >> 1];
+                                                uint32_t       tp = (i & 1) ? tw_ >> 16 : tw_ & 0xFFFFu;
+                                                uint32_t       bt = (i & 1) ? bw_ >> 16 : bw_ & 0xFFFFu;
+                                                tp += quad_xor1(tp);
+                                                bt += quad_xor1(bt);
+                                                uint32_t all = tp + bt;
+                                                all += quad_xor2(all);
+                                                b32[0][i] = min(b32[0][i], (tp << 3) | yrk[t]);
+                                                b32[1][i] = min(b32[1][i], (bt << 3) | yrk[t]);
+                                                b64k[i]   = min(b64k[i], (all << 3) | yrk[t]);
                                             }
-                                            half[t][i] = 0;
                                         }
                                     }
                                 }
                             }
-                        }
+                        });
                     });
-                });
-            }
-            // merge this lane's minima into the workgroup keys: (SAD << 32) | (y << 16) | x, window-relative
-            if (valid && ya < yb) {
-                const int ybase = y0 + ya;
-#pragma unroll
-                for (int by = 0; by < 8; ++by)
-#pragma unroll
-                    for (int c = 0; c < 2; ++c) {
-                        u64 best = ~0ull;
-#pragma unroll
-                        for (int i = 0; i < 4; ++i) {
-                            const uint32_t k16 = (b8[by][c][i >> 1] >> (16 * (i & 1))) & 0xFFFFu;
-                            const int      x   = xg * 4 + i;
-                            if (x < w) {
-                                const u64 kk = ((u64)(k16 >> 3) << 32) | ((uint32_t)(ybase + (k16 & 7)) << 16) | (uint32_t)x;
-                                best         = kk < best ? kk : best;
-                            }
-                        }
-                        const int bx8 = col * 2 + c; // 8x8 block column
-                        const int pu  = 21 + z16(by >> 1, bx8 >> 1) * 4 + ((by & 1) << 1) + (bx8 & 1);
-                        atomicMin(&S.best[pu], best);
-                    }
-#pragma unroll
-                for (int a = 0; a < 4; ++a) {
-                    u64 best = ~0ull;
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) {
-                        const int x = xg * 4 + i;
-                        if (x < w) {
-                            const u64 kk = ((u64)(b16[a][i] >> 3) << 32) | ((uint32_t)(ybase + (b16[a][i] & 7)) << 16) | (uint32_t)x;
-                            best         = kk < best ? kk : best;
-                        }
-                    }
-                    atomicMin(&S.best[5 + z16(a, col)], best);
                 }
-                if ((col & 1) == 0) {
+                // merge this lane's minima into the workgroup keys: (SAD << 32) | (y << 16) | x, window-relative.
+                // Within the lane the 4 positions differ in x only, so the first minimum wins ties.
+                if (valid && ya < yb) {
+                    const uint32_t ybase = (uint32_t)(ty0 + ya), xbase = (uint32_t)(tx0 + xg * 4);
+                    // positions at or beyond the window's right edge (widths below 8 only) never win
+                    uint32_t xoff[4];
 #pragma unroll
-                    for (int a = 0; a < 2; ++a) {
-                        u64 best = ~0ull;
+                    for (int i = 0; i < 4; ++i) xoff[i] = (int)(xbase + i) < w ? 0u : 0xFFFFFFFFu;
 #pragma unroll
-                        for (int i = 0; i < 4; ++i) {
-                            const int x = xg * 4 + i;
-                            if (x < w) {
-                                const u64 kk = ((u64)(b32[a][i] >> 3) << 32) | ((uint32_t)(ybase + (b32[a][i] & 7)) << 16) | (uint32_t)x;
-                                best         = kk < best ? kk : best;
-                            }
+                    for (int by = 0; by < 8; ++by)
+#pragma unroll
+                        for (int c = 0; c < 2; ++c) {
+                            uint32_t kk[4], best, idx;
+                            kk[0] = (b8[by][c][0] & 0xFFFFu) | xoff[0];
+                            kk[1] = (b8[by][c][0] >> 16) | xoff[1];
+                            kk[2] = (b8[by][c][1] & 0xFFFFu) | xoff[2];
+                            kk[3] = (b8[by][c][1] >> 16) | xoff[3];
+                            min4(kk, best, idx);
+                            const u64 key = ((u64)(best >> 3) << 32) | ((ybase + (best & 7)) << 16) | (xbase + idx);
+                            const int bx8 = col * 2 + c; // 8x8 block column
+                            const int pu  = 21 + z16(by >> 1, bx8 >> 1) * 4 + ((by & 1) << 1) + (bx8 & 1);
+                            atomicMin(&S.best[pu], best == 0xFFFFFFFFu ? ~0ull : key);
                         }
-                        atomicMin(&S.best[1 + a * 2 + (col >> 1)], best);
-                    }
-                }
-                if (col == 0) {
-                    u64 best = ~0ull;
 #pragma unroll
-                    for (int i = 0; i < 4; ++i) {
-                        const int x = xg * 4 + i;
-                        if (x < w) {
-                            const u64 kk = ((u64)(b64k[i] >> 3) << 32) | ((uint32_t)(ybase + (b64k[i] & 7)) << 16) | (uint32_t)x;
-                            best         = kk < best ? kk : best;
+                    for (int a = 0; a < 4; ++a) {
+                        uint32_t kk[4], best, idx;
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) kk[i] = b16[a][i] | xoff[i];
+                        min4(kk, best, idx);
+                        const u64 key = ((u64)(best >> 16) << 32) | ((ybase + (best & 7)) << 16) | (xbase + idx);
+                        atomicMin(&S.best[5 + z16(a, col)], best == 0xFFFFFFFFu ? ~0ull : key);
+                    }
+                    if ((col & 1) == 0) {
+#pragma unroll
+                        for (int a = 0; a < 2; ++a) {
+                            uint32_t kk[4], best, idx;
+#pragma unroll
+                            for (int i = 0; i < 4; ++i) kk[i] = b32[a][i] | xoff[i];
+                            min4(kk, best, idx);
+                            const u64 key = ((u64)(best >> 3) << 32) | ((ybase + (best & 7)) << 16) | (xbase + idx);
+                            atomicMin(&S.best[1 + a * 2 + (col >> 1)], best == 0xFFFFFFFFu ? ~0ull : key);
                         }
                     }
-                    atomicMin(&S.best[0], best);
+                    if (col == 0) {
+                        uint32_t kk[4], best, idx;
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) kk[i] = b64k[i] | xoff[i];
+                        min4(kk, best, idx);
+                        const u64 key = ((u64)(best >> 3) << 32) | ((ybase + (best & 7)) << 16) | (xbase + idx);
+                        atomicMin(&S.best[0], best == 0xFFFFFFFFu ? ~0ull : key);
+                    }
                 }
             }
         }
     }
     __syncthreads();
-    // ---- results: p_sb_best_sad / p_sb_best_mv of (my_l, my_r). SADs were taken on every other row: x2 (:248-305).
-    if (tid < SVTME_PU_COUNT) {
-        const u64      key = S.best[tid];
-        const size_t   o   = ((size_t)(b64 * SVTME_MAX_LISTS + my_l) * SVTME_MAX_REFS + my_r) * SVTME_PU_COUNT + tid;
-        const int      py = (int)((key >> 16) & 0xFFFF) + org_y, px = (int)(key & 0xFFFF) + org_x;
-        const uint32_t sad = (uint32_t)(key >> 32);
-        p.best_sad[o] = k.me_search_method == 0 ? sad << 1 : sad;
-        p.best_mv[o]  = ((uint32_t)(uint16_t)py << 18) | (uint16_t)((uint16_t)px << 2); // :474-476
+    // ---- this item's minima join the window's
+    for (int pu = tid; pu < SVTME_PU_COUNT; pu += ME_THREADS) {
+        const u64 key = S.best[pu];
+        if (key != ~0ull) atomicMin(&p.me_keys[(size_t)(b64 * 8 + my) * SVTME_PU_COUNT + pu], key);
     }
+}
+
+// ---- results: p_sb_best_sad / p_sb_best_mv. SADs were taken on every other row: x2 (:248-305). References that were
+// not searched (absent or pruned) read as zero.
+__global__ void __launch_bounds__(256) me_finish_kernel(PicParams p) {
+    const int n = p.b64_w * p.b64_h * 8 * SVTME_PU_COUNT;
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const int   j   = i / SVTME_PU_COUNT;
+    const MeJob job = p.me_jobs[j];
+    const u64   key = p.me_keys[i];
+    uint32_t    sad = 0, mv = 0;
+    const int   l = (j >> 2) & 1, r = j & 3;
+    if (l < p.n_list && r < p.n_ref[l] && job.w > 0) {
+        const int py = (int)((key >> 16) & 0xFFFF) + job.org_y, px = (int)(key & 0xFFFF) + job.org_x;
+        sad = (uint32_t)(key >> 32) << 1;
+        mv  = ((uint32_t)(uint16_t)py << 18) | (uint16_t)((uint16_t)px << 2); // :474-476
+    }
+    p.best_sad[i] = sad;
+    p.best_mv[i]  = mv;
 }
 
 void launch_me(const PicParams &p, hipStream_t s) {
     const int n_refs = p.n_ref[0] + (p.n_list == 2 ? p.n_ref[1] : 0);
-    dim3      grid(p.b64_w * p.b64_h, n_refs);
-    hipLaunchKernelGGL(me_kernel, grid, dim3(ME_THREADS), ME_WIN_BYTES + 64, s, p);
+    const int n_b64  = p.b64_w * p.b64_h;
+    hipLaunchKernelGGL(me_plan_kernel, dim3(n_b64, n_refs), dim3(ME_THREADS), 0, s, p);
+    hipLaunchKernelGGL(me_search_kernel, dim3(n_b64, n_refs, p.me_max_items), dim3(ME_THREADS), 0, s, p);
+    hipLaunchKernelGGL(me_finish_kernel, dim3((n_b64 * 8 * SVTME_PU_COUNT + 255) / 256), dim3(256), 0, s, p);
 }
 
 } // namespace svtme

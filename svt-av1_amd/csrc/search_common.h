@@ -26,6 +26,11 @@ __device__ __forceinline__ void clip_axis(int o, int16_t &org, int16_t &size, in
     if (o + org + size > dim) size = (int16_t)max(1, size - ((o + org + size) - dim));
 }
 
+// Adds n to operation counter k of this workgroup's partial-sum slot.
+__device__ __forceinline__ void count_ops(const PicParams &p, int k, unsigned long long n) {
+    atomicAdd(&p.ops[((blockIdx.x + 5 * blockIdx.y) & (SVTME_OPS_SLOTS - 1)) * 8 + k], n);
+}
+
 // 4 bytes at an arbitrary byte address, from two aligned dword loads.
 __device__ __forceinline__ uint32_t load_u32_any(const uint8_t *p) {
     const uintptr_t a  = reinterpret_cast<uintptr_t>(p);

@@ -36,6 +36,11 @@ struct HmeRefOut {
     uint32_t valid; // bit0: HME ran for this reference (not a base-layer list-1 reference)
 };
 
+// Integer-search window of one (b64, list, ref), window origin relative to the b64 origin; w == 0: not searched.
+struct MeJob {
+    int16_t org_x, org_y, w, h;
+};
+
 // Everything a picture's kernels need, passed by value as the kernel argument.
 struct PicParams {
     DevPicture     cur;
@@ -49,6 +54,10 @@ struct PicParams {
     int32_t        temporal_layer;
     int32_t        is_ref;
     int32_t        serial_refs; // 1: one workgroup walks all references of a b64 in order (cross-reference dependencies)
+    int32_t        me_max_items; // upper bound of search work items per (b64, ref) for this picture's controls
+    // intermediates
+    MeJob              *me_jobs; // [n_b64][2][4]
+    unsigned long long *me_keys; // [n_b64][2][4][85] running minima (SAD << 32 | y << 16 | x), window-relative
     // outputs
     HmeRefOut           *hme_out; // [n_b64][2][4]
     uint32_t            *best_sad; // [n_b64][2][4][85]
@@ -56,10 +65,14 @@ struct PicParams {
     svtme_search_result *search_results; // [n_b64][2][4]
     uint32_t            *zz_sad; // [n_b64][2][4]
     uint32_t            *sr_divisor; // [n_b64][2][4]
-    // abs-diff-accumulate operations actually performed: [0] zero-MV / centre checks, [1] pre-HME, [2..4] HME L0..L2,
-    // [5] integer search
+    // abs-diff-accumulate operations actually performed, as SVTME_OPS_SLOTS partial sums of 8 counters each (spread so
+    // that the workgroups of a picture do not all hit one address): [0] zero-MV / centre checks, [1] pre-HME,
+    // [2..4] HME L0..L2, [5] integer search
     unsigned long long  *ops;
 };
+
+constexpr int SVTME_OPS_SLOTS = 64;
+constexpr int SVTME_OPS_BYTES = SVTME_OPS_SLOTS * 8 * 8;
 
 // store kernels (store_kernels.hip)
 void launch_store_build(const uint8_t *luma, int luma_stride, const DevPicture &pic, int hme_level1, hipStream_t s);
