@@ -1,0 +1,482 @@
+// hme_items.hip - zero-MV SAD, pre-HME and HME levels 0/1/2 of one picture as two kernels of single-wave work items.
+//
+// Same reference code as hme_kernel.hip (Source/Lib/Encoder/Codec/EbMotionEstimation.c: init_zz_sad :2318-2333,
+// prehme_b64 / prehme_core :1773-1823 / :1621-1719, hme_level0_b64 / hme_level_0 / get_hme_l0_search_area :1899-2004 /
+// :847-947 / :1827-1894, hme_level1_b64 / hme_level_1 :2009-2068 / :950-1049, hme_level2_b64 / hme_level_2 :2073-2112 /
+// :1052-1140, svt_sad_loop_kernel EbComputeSAD_C.c:58-103), for the common case in which no reference depends on
+// another one's result, so that every search of a picture can run at the same time:
+//
+//  hme_l0_kernel   one wave per (b64, reference, search), search = one of the 2 pre-HME shapes or one of the 2x2
+//                  level-0 regions: ~15 000 items per 1080p picture. The 16x16 block of the sixteenth-resolution
+//                  picture (8 sampled rows x 4 dwords) sits in registers; the reference window is staged in LDS. A lane
+//                  owns 4 horizontally adjacent positions x T same-parity search rows and walks them together, staggered
+//                  by one sampled source row, so each reference row is read from LDS once for 4 T positions: 32 T
+//                  v_qsad_pk_u16_u8 per unit into T packed accumulators.
+//  hme_l12_kernel  one wave per (b64, reference, region): replaces the worst level-0 region by a better pre-HME result,
+//                  then searches level 1 around the level-0 vector and level 2 around the level-1 vector. Few positions
+//                  (8x3) of a large block (32x32, 64x64): the block's rows are split over 8 lanes per position quad.
+//
+// The argmin is exact under the reference's rule (strict '<' in raster order): 64-bit keys (SAD << 32 | raster index).
+#include "search_common.h"
+
+namespace svtme {
+
+constexpr int HI_THREADS   = 64;
+constexpr int HI_WIN_BYTES = 14336; // LDS budget of one staged reference window
+constexpr int HI_XCHUNK    = 96; // search positions per staged column chunk (level 0 / pre-HME)
+constexpr int HI_WIN2_BYTES = 8192; // levels 1 and 2
+
+struct L0Shared {
+    u64      key;
+    uint32_t red;
+    int      zero; // always 0, but only known at run time
+    uint32_t src[8 * 4];
+};
+
+// get_hme_l0_search_area :1827-1894 when no reference's area depends on the first reference's vector
+__device__ void l0_area(const PicParams &p, int l, int r, int16_t &sa_w, int16_t &sa_h) {
+    const svtme_controls &k  = p.ctrl;
+    svtme_sa_minmax       sa = k.hme_l0_sa;
+    if (k.enable_me_sr_adjustment && k.distance_based_hme_resizing) {
+        sa.sa_min.width  = (uint16_t)(sa.sa_min.width / (1 + r));
+        sa.sa_min.height = (uint16_t)(sa.sa_min.height / (1 + r));
+        sa.sa_max.width  = (uint16_t)(sa.sa_max.width / (1 + r));
+        sa.sa_max.height = (uint16_t)(sa.sa_max.height / (1 + r));
+    }
+    const int factor = scaled_dist(p.dist[l][r]);
+    int16_t   w      = (int16_t)(sa.sa_min.width / k.num_hme_sa_w);
+    w = (int16_t)min(((w * factor) + 15) & ~0x0F, ((sa.sa_max.width / k.num_hme_sa_w) + 15) & ~0x0F);
+    int16_t h = (int16_t)(sa.sa_min.height / k.num_hme_sa_h);
+    h         = (int16_t)min(h * factor, sa.sa_max.height / k.num_hme_sa_h);
+    sa_w      = w;
+    sa_h      = h;
+}
+
+// What the callers of svt_sad_loop_kernel make of its outputs: SAD x2 (rows were subsampled), position + window
+// origin, times the level's scale (:938-944, :1040-1046, :1133-1137, :1710-1716).
+__device__ __forceinline__ void decode_key(u64 key, int sa_w, int org_x, int org_y, int scale, int16_t &mx, int16_t &my, uint32_t &sad) {
+    if (key == ~0ull) { // no position evaluated: svt_sad_loop_kernel leaves 0xffffff and does not touch x / y
+        sad = 0xffffffu * 2;
+        mx  = (int16_t)(org_x * scale);
+        my  = (int16_t)(org_y * scale);
+        return;
+    }
+    const int idx = (int)(uint32_t)key;
+    const int y = idx / sa_w, x = idx - y * sa_w;
+    sad = (uint32_t)(key >> 32) * 2;
+    mx  = (int16_t)((int16_t)(x + org_x) * scale);
+    my  = (int16_t)((int16_t)(y + org_y) * scale);
+}
+
+// One position straight from global memory: any block width (multiple of 2) and row count. Used for the blocks of a
+// picture's right edge, whose width is not the full 64 / 32 / 16 pixels.
+__device__ uint32_t slow_sad(const DevPlane &cur, const DevPlane &ref, int ox, int oy, int rx, int ry, int bw, int rows, int step) {
+    uint32_t sad = 0;
+    for (int j = 0; j < rows; ++j) {
+        const uint8_t *s = cur.pix + (ptrdiff_t)(oy + j * step) * cur.stride + ox;
+        const uint8_t *f = ref.pix + (ptrdiff_t)(ry + j * step) * ref.stride + rx;
+        int            i = 0;
+        for (; i + 4 <= bw; i += 4) {
+            uint32_t a, b;
+            __builtin_memcpy(&a, s + i, 4);
+            __builtin_memcpy(&b, f + i, 4);
+            sad = __builtin_amdgcn_sad_u8(a, b, sad);
+        }
+        for (; i < bw; ++i) sad += (uint32_t)abs((int)s[i] - (int)f[i]);
+    }
+    return sad;
+}
+
+// The T same-parity rows x 4 columns of every unit of a staged window band, for a 16-pixel-wide block of `rows`
+// sampled rows held in src (wave-uniform). Folds each lane's best (SAD, raster index) into `best`.
+template <int T>
+__device__ __forceinline__ void strip_units(const uint32_t *win, int pd, int n_xg, int brows, bool skip_even, const uint32_t (&src)[8][4],
+                                            int rows, int zero, int y_abs0, int x_abs0, int sa_w, u64 &best) {
+    const int lane   = threadIdx.x;
+    const int n_yg   = (brows + 2 * T - 1) / (2 * T);
+    const int n_unit = n_xg * n_yg * (skip_even ? 1 : 2);
+    for (int ub = 0; ub < n_unit; ub += HI_THREADS) {
+        const int  u     = ub + lane;
+        const bool valid = u < n_unit;
+        const int  rest  = valid ? u / n_xg : 0;
+        const int  xg    = valid ? u - rest * n_xg : 0;
+        const int  par   = skip_even ? 1 : (rest & 1);
+        const int  yg    = skip_even ? rest : rest >> 1;
+        const int  yfirst = yg * 2 * T + par;
+        const int  n_pos  = valid ? min(T, max(0, (brows - yfirst + 1) >> 1)) : 0;
+        // the four 8-byte operands of a step overlap by a dword; the odd pairs are read through a second pointer the
+        // compiler cannot prove equal to the first, so every pair comes from LDS in its own aligned register pair
+        const uint32_t *rr = win + yfirst * pd + xg;
+        const uint32_t *rq = rr + 1 + zero;
+        u64             acc[T];
+#pragma unroll
+        for (int t = 0; t < T; ++t) acc[t] = 0;
+        static_for<0, T + 7>([&](auto s_c) {
+            constexpr int s   = decltype(s_c)::value;
+            const u64     p01 = ((u64)rr[1] << 32) | rr[0], p12 = ((u64)rq[1] << 32) | rq[0];
+            const u64     p23 = ((u64)rr[3] << 32) | rr[2], p34 = ((u64)rq[3] << 32) | rq[2];
+            rr += 2 * pd;
+            rq += 2 * pd;
+            static_for<0, T>([&](auto t_c) {
+                constexpr int t = decltype(t_c)::value;
+                constexpr int m = s - t; // sampled source row of position t at this step
+                if constexpr (m >= 0 && m < 8) {
+                    if (m < rows) {
+                        acc[t] = __builtin_amdgcn_qsad_pk_u16_u8(p01, src[m][0], acc[t]);
+                        acc[t] = __builtin_amdgcn_qsad_pk_u16_u8(p12, src[m][1], acc[t]);
+                        acc[t] = __builtin_amdgcn_qsad_pk_u16_u8(p23, src[m][2], acc[t]);
+                        acc[t] = __builtin_amdgcn_qsad_pk_u16_u8(p34, src[m][3], acc[t]);
+                    }
+                }
+            });
+        });
+        // per column: min over rows of SAD << 4 | t (SAD <= 8 * 16 * 255: the packed sums never carried)
+        uint32_t col[4] = {~0u, ~0u, ~0u, ~0u};
+#pragma unroll
+        for (int t = 0; t < T; ++t) {
+            const uint32_t tk = t < n_pos ? (uint32_t)t : ~0u;
+            const uint32_t lo = (uint32_t)acc[t], hi = (uint32_t)(acc[t] >> 32);
+            col[0] = min(col[0], ((lo & 0xFFFFu) << 4) | tk);
+            col[1] = min(col[1], ((lo >> 16) << 4) | tk);
+            col[2] = min(col[2], ((hi & 0xFFFFu) << 4) | tk);
+            col[3] = min(col[3], ((hi >> 16) << 4) | tk);
+        }
+        // raster order: row first, then column
+        u64 ubest = ~0ull;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int x = x_abs0 + xg * 4 + i;
+            if (col[i] != ~0u && x < sa_w) {
+                const int y = y_abs0 + yfirst + 2 * (int)(col[i] & 15);
+                const u64 k = ((u64)(col[i] >> 4) << 32) | (uint32_t)(y * sa_w + x);
+                ubest       = k < ubest ? k : ubest;
+            }
+        }
+        best = ubest < best ? ubest : best;
+    }
+}
+
+// Exhaustive search of the (bw x rows sampled rows, 2 plane rows apart) block of `cur` at (ox, oy) over the sa_w x sa_h
+// window of `ref` whose first position is plane pixel (wx, wy). Returns min (SAD << 32 | y * sa_w + x), ~0 when no
+// position was evaluated (skip_even with a single row). Whole wave.
+__device__ u64 l0_search(L0Shared &S, uint32_t *win, const DevPlane &cur, const DevPlane &ref, int ox, int oy, int bw, int rows, int wx,
+                         int wy, int sa_w, int sa_h, bool skip_even) {
+    const int lane = threadIdx.x;
+    u64       best = ~0ull;
+    if (sa_w <= 0 || sa_h <= 0 || rows <= 0) return best;
+    if (bw != 16) {
+        for (int i = lane; i < sa_w * sa_h; i += HI_THREADS) {
+            const int y = i / sa_w, x = i - y * sa_w;
+            if (skip_even && (y & 1) == 0) continue;
+            const u64 k = ((u64)slow_sad(cur, ref, ox, oy, wx + x, wy + y, bw, rows, 2) << 32) | (uint32_t)i;
+            best        = k < best ? k : best;
+        }
+    } else {
+        if (lane < rows * 4)
+            S.src[lane] = *reinterpret_cast<const uint32_t *>(cur.pix + (ptrdiff_t)(oy + 2 * (lane >> 2)) * cur.stride + ox + 4 * (lane & 3));
+        if (lane == 0) S.zero = 0;
+        __syncthreads();
+        uint32_t src[8][4];
+#pragma unroll
+        for (int m = 0; m < 8; ++m)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) src[m][j] = (uint32_t)__builtin_amdgcn_readfirstlane((int)S.src[(m < rows ? m : 0) * 4 + j]);
+        const int zero = S.zero;
+        for (int x0 = 0; x0 < sa_w; x0 += HI_XCHUNK) {
+            const int n_xg = (min(HI_XCHUNK, sa_w - x0) + 3) >> 2;
+            const int pd   = n_xg + 4; // dwords per staged row: the positions + 15 more pixels, rounded up
+            // rows the LDS budget holds: a band's search rows + 14 rows under the last one + the staggered walk's
+            // overrun (rows that are addressed but never used)
+            const int cap  = HI_WIN_BYTES / (4 * pd);
+            int       band = cap - 14 - 16;
+            band           = band >= 16 ? band & ~15 : max(band, 1);
+            for (int y0 = 0; y0 < sa_h; y0 += band) {
+                const int brows = min(band, sa_h - y0);
+                __syncthreads();
+                {
+                    const int      nrow = brows + 14, n = nrow * pd;
+                    const uint8_t *g    = ref.pix + (ptrdiff_t)(wy + y0) * ref.stride + wx + x0;
+                    int            r = lane / pd, d = lane - r * pd;
+                    const int      dr = HI_THREADS / pd, dd = HI_THREADS - dr * pd;
+                    for (int i = lane; i < n; i += HI_THREADS) {
+                        uint32_t v;
+                        __builtin_memcpy(&v, g + (ptrdiff_t)r * ref.stride + 4 * d, 4);
+                        win[i] = v;
+                        r += dr;
+                        d += dd;
+                        if (d >= pd) {
+                            d -= pd;
+                            ++r;
+                        }
+                    }
+                }
+                __syncthreads();
+                if (brows > 8) strip_units<8>(win, pd, n_xg, brows, skip_even, src, rows, zero, y0, x0, sa_w, best);
+                else if (brows > 4) strip_units<4>(win, pd, n_xg, brows, skip_even, src, rows, zero, y0, x0, sa_w, best);
+                else strip_units<2>(win, pd, n_xg, brows, skip_even, src, rows, zero, y0, x0, sa_w, best);
+            }
+        }
+    }
+    if (lane == 0) S.key = ~0ull;
+    __syncthreads();
+    if (best != ~0ull) atomicMin(&S.key, best);
+    __syncthreads();
+    best = S.key;
+    __syncthreads();
+    return best;
+}
+
+__global__ void __launch_bounds__(HI_THREADS, 3) hme_l0_kernel(PicParams p) {
+    __shared__ L0Shared               S;
+    __shared__ __align__(16) uint32_t win[HI_WIN_BYTES / 4 + 64];
+    const svtme_controls &k   = p.ctrl;
+    const int             b64 = blockIdx.x;
+    const int             b64x = (b64 % p.b64_w) * 64, b64y = (b64 / p.b64_w) * 64;
+    const int             block_w = min(p.width - b64x, 64), block_h = min(p.height - b64y, 64);
+    int                   l = 0, r = blockIdx.y;
+    if (r >= p.n_ref[0]) {
+        r -= p.n_ref[0];
+        l = 1;
+    }
+    const int  sub      = blockIdx.z; // 0, 1: pre-HME shapes; 2..: level-0 regions in the reference's visiting order
+    const bool searched = ref_searched(p, l);
+    HmeRefOut *out      = &p.hme_out[(b64 * SVTME_MAX_LISTS + l) * SVTME_MAX_REFS + r];
+    const bool header   = sub == 2; // this item also writes the per-reference fields
+
+    // zero-MV SAD (init_zz_sad :2318-2333); stays ~0 (init_me_hme_data :2921) when not computed
+    uint32_t zz = ~0u;
+    if (k.me_early_exit_th && searched)
+        zz = wg_block_sad(p.cur.lvl[2], p.ref[l][r].lvl[2], b64x, b64y, 0, 0, block_w, block_h >> 1, 2, &S.red) << 1;
+    if (header && threadIdx.x == 0) {
+        if (k.me_early_exit_th && searched) count_ops(p, 0, (unsigned long long)(block_h >> 1) * block_w);
+        out->zz_sad = zz;
+        out->valid  = searched ? 1u : 0u;
+    }
+    if (!searched) return;
+
+    const DevPlane &cur = p.cur.lvl[0];
+    const DevPlane &ref = p.ref[l][r].lvl[0];
+    const int       ox = b64x >> 2, oy = b64y >> 2;
+    const int       bw = block_w >> 2, bh = block_h >> 2;
+    const int       rows = bh >> 1;
+    if (sub < 2) {
+        // pre-HME (prehme_b64 :1773-1823); check_prehme_early_exit :1746-1770 leaves a zero result
+        if (!k.prehme_enable || (k.me_early_exit_th && zz < k.me_early_exit_th)) return;
+        const svtme_sa_minmax &cfg    = k.prehme_sa_cfg[sub];
+        const int              factor = scaled_dist(p.dist[l][r]);
+        int16_t w = (int16_t)(uint16_t)min((uint32_t)cfg.sa_min.width * factor, (uint32_t)cfg.sa_max.width);
+        int16_t h = (int16_t)(uint16_t)min((uint32_t)cfg.sa_min.height * factor, (uint32_t)cfg.sa_max.height);
+        int16_t org_x = (int16_t)-(int16_t)(w >> 1), org_y = (int16_t)-(int16_t)(h >> 1);
+        clip_axis(ox, org_x, w, -(ref.pad - 1), ref.width);
+        clip_axis(oy, org_y, h, -(ref.pad - 1), ref.height);
+        // svt_sad_loop_kernel_c skips even rows only for 16-wide blocks of height <= 16
+        const bool skip = k.prehme_skip_search_line && bw == 16 && rows <= 16;
+        if (threadIdx.x == 0) count_ops(p, 1, (unsigned long long)max(skip ? h >> 1 : (int)h, 0) * max((int)w, 0) * rows * bw);
+        const u64 key = l0_search(S, win, cur, ref, ox, oy, bw, rows, ox + org_x, oy + org_y, w, h, skip);
+        if (threadIdx.x == 0) decode_key(key, w, org_x, org_y, 4, out->pre_x[sub], out->pre_y[sub], out->pre_sad[sub]);
+        return;
+    }
+    // level 0 (:1899-2004): a region per item; the early exit leaves zeros
+    const int q = sub - 2, nw = k.num_hme_sa_w, nh = k.num_hme_sa_h;
+    if (!k.enable_hme_flag || !k.enable_hme_level0_flag || q >= nw * nh) return;
+    if (k.me_early_exit_th && zz < (k.me_early_exit_th >> 2)) return;
+    const int sw = q % nw, sh = q / nw, i = sw * 2 + sh;
+    int16_t   sa_w = 0, sa_h = 0;
+    l0_area(p, l, r, sa_w, sa_h);
+    int16_t w = (int16_t)((sa_w + 7) & ~0x07), h = sa_h;
+    int16_t org_x = (int16_t)(-(int16_t)((w * nw) >> 1) + (int16_t)(w * sw));
+    int16_t org_y = (int16_t)(-(int16_t)((h * nh) >> 1) + (int16_t)(h * sh));
+    clip_axis(ox, org_x, w, -(ref.pad - 1), ref.width);
+    w = (int16_t)(w < 8 ? w : (w & ~0x07));
+    clip_axis(oy, org_y, h, -(ref.pad - 1), ref.height);
+    if (threadIdx.x == 0) count_ops(p, 2, (unsigned long long)max((int)h, 0) * max((int)w, 0) * rows * bw);
+    const u64 key = l0_search(S, win, cur, ref, ox, oy, bw, rows, ox + org_x, oy + org_y, w, h, false);
+    if (threadIdx.x == 0) decode_key(key, w, org_x, org_y, 4, out->raw_x[i], out->raw_y[i], out->raw_sad[i]);
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+struct L12Shared {
+    u64      key;
+    uint32_t src[32 * 16];
+};
+
+// Exhaustive search of a small window with a large block: position quads x block-row chunks over the lanes.
+// bw: block width in pixels (multiple of 4 at these levels), rows: sampled rows, 2 plane rows apart.
+__device__ u64 small_search(L12Shared &S, uint32_t *win, const DevPlane &cur, const DevPlane &ref, int ox, int oy, int bw, int rows, int wx,
+                            int wy, int sa_w, int sa_h) {
+    const int lane = threadIdx.x;
+    u64       best = ~0ull;
+    if (sa_w <= 0 || sa_h <= 0 || rows <= 0) return best;
+    const int bwd = bw >> 2;
+    __syncthreads();
+    for (int i = lane; i < rows * bwd; i += HI_THREADS) {
+        const int r = i / bwd, d = i - r * bwd;
+        S.src[r * 16 + d] = *reinterpret_cast<const uint32_t *>(cur.pix + (ptrdiff_t)(oy + 2 * r) * cur.stride + ox + 4 * d);
+    }
+    if (lane == 0) S.key = ~0ull;
+    const int n_xg = (sa_w + 3) >> 2, pd = n_xg + bwd, span = (rows - 1) * 2 + 1;
+    int       band = HI_WIN2_BYTES / (4 * pd) - (span - 1);
+    band           = max(band, 1);
+    const int chunk_log2 = rows >= 16 ? 3 : (rows >= 4 ? 2 : 0), chunks = 1 << chunk_log2;
+    const int rpc        = (rows + chunks - 1) >> chunk_log2; // sampled block rows per lane
+    for (int y0 = 0; y0 < sa_h; y0 += band) {
+        const int brows = min(band, sa_h - y0);
+        __syncthreads();
+        {
+            const int n = (brows + span - 1) * pd;
+            for (int i = lane; i < n; i += HI_THREADS) {
+                const int r = i / pd, d = i - r * pd;
+                uint32_t  v;
+                __builtin_memcpy(&v, ref.pix + (ptrdiff_t)(wy + y0 + r) * ref.stride + wx + 4 * d, 4);
+                win[i] = v;
+            }
+        }
+        __syncthreads();
+        const int total = (n_xg * brows) << chunk_log2;
+        for (int base = 0; base < total; base += HI_THREADS) {
+            const int  t     = base + lane;
+            const bool valid = t < total;
+            const int  chunk = t & (chunks - 1);
+            const int  q     = valid ? t >> chunk_log2 : 0;
+            const int  yl = q / n_xg, xg = q - yl * n_xg;
+            uint32_t   a32[4] = {0, 0, 0, 0};
+            if (valid) {
+                const int j0 = chunk * rpc, j1 = min(rows, j0 + rpc);
+                u64       a16 = 0;
+                int       px  = 0;
+                for (int j = j0; j < j1; ++j) {
+                    const uint32_t *rr = win + (yl + 2 * j) * pd + xg;
+                    const uint32_t *ss = &S.src[j * 16];
+                    if (px + bw > 256) { // keep the packed 16-bit sums below 65536
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) a32[i] += (uint32_t)(a16 >> (16 * i)) & 0xFFFFu;
+                        a16 = 0;
+                        px  = 0;
+                    }
+                    uint32_t r0 = rr[0];
+                    for (int d = 0; d < bwd; ++d) {
+                        const uint32_t r1 = rr[d + 1];
+                        a16 = __builtin_amdgcn_qsad_pk_u16_u8(((u64)r1 << 32) | r0, ss[d], a16);
+                        r0  = r1;
+                    }
+                    px += bw;
+                }
+#pragma unroll
+                for (int i = 0; i < 4; ++i) a32[i] += (uint32_t)(a16 >> (16 * i)) & 0xFFFFu;
+            }
+            for (int m = 1; m < chunks; m <<= 1) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) a32[i] += __shfl_xor(a32[i], m);
+            }
+            if (valid && chunk == 0) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int x = xg * 4 + i;
+                    if (x < sa_w) {
+                        const u64 kk = ((u64)a32[i] << 32) | (uint32_t)((y0 + yl) * sa_w + x);
+                        best         = kk < best ? kk : best;
+                    }
+                }
+            }
+        }
+    }
+    if (best != ~0ull) atomicMin(&S.key, best);
+    __syncthreads();
+    best = S.key;
+    __syncthreads();
+    return best;
+}
+
+__global__ void __launch_bounds__(HI_THREADS) hme_l12_kernel(PicParams p) {
+    __shared__ L12Shared              S;
+    __shared__ __align__(16) uint32_t win[HI_WIN2_BYTES / 4 + 64];
+    const svtme_controls &k   = p.ctrl;
+    const int             b64 = blockIdx.x;
+    const int             b64x = (b64 % p.b64_w) * 64, b64y = (b64 / p.b64_w) * 64;
+    const int             block_w = min(p.width - b64x, 64), block_h = min(p.height - b64y, 64);
+    int                   l = 0, r = blockIdx.y;
+    if (r >= p.n_ref[0]) {
+        r -= p.n_ref[0];
+        l = 1;
+    }
+    const int q = blockIdx.z, nw = k.num_hme_sa_w, nh = k.num_hme_sa_h;
+    if (!ref_searched(p, l) || !k.enable_hme_flag || q >= nw * nh) return;
+    const int  sw = q % nw, sh = q / nw, i = sw * 2 + sh;
+    HmeRefOut *out = &p.hme_out[(b64 * SVTME_MAX_LISTS + l) * SVTME_MAX_REFS + r];
+    const bool early = k.me_early_exit_th && out->zz_sad < (k.me_early_exit_th >> 2);
+
+    // level-0 result of this region: the worst region (strict '>', sr_h outer / sr_w inner) gives way to the better
+    // pre-HME result (:1967-1999)
+    int16_t  cx = 0, cy = 0; // vector of the previous level (zero when that level did not run)
+    uint32_t csad = 0;
+    if (k.enable_hme_level0_flag && !early) {
+        cx   = out->raw_x[i];
+        cy   = out->raw_y[i];
+        csad = out->raw_sad[i];
+        if (k.prehme_enable) {
+            uint32_t max_sad = 0;
+            int      mi      = 0;
+            for (int h_ = 0; h_ < nh; ++h_)
+                for (int w_ = 0; w_ < nw; ++w_)
+                    if (out->raw_sad[w_ * 2 + h_] > max_sad) {
+                        max_sad = out->raw_sad[w_ * 2 + h_];
+                        mi      = w_ * 2 + h_;
+                    }
+            const int s = out->pre_sad[0] <= out->pre_sad[1] ? 0 : 1;
+            if (mi == i && out->pre_sad[s] < csad) {
+                csad = out->pre_sad[s];
+                cx   = out->pre_x[s];
+                cy   = out->pre_y[s];
+            }
+        }
+        if (threadIdx.x == 0) {
+            out->lx[0][i]   = cx;
+            out->ly[0][i]   = cy;
+            out->lsad[0][i] = csad;
+        }
+    }
+    for (int level = 1; level <= 2; ++level) {
+        // a level that does not run, or level 1 on the early exit (:2032-2040; level 2 has none), leaves zeros
+        if ((level == 1 ? !k.enable_hme_level1_flag : !k.enable_hme_level2_flag) || (level == 1 && early)) {
+            cx = cy = 0;
+            continue;
+        }
+        const DevPlane &cur   = p.cur.lvl[level];
+        const DevPlane &ref   = p.ref[l][r].lvl[level];
+        const int       shift = 2 - level;
+        const int       ox = b64x >> shift, oy = b64y >> shift;
+        const int       bw = block_w >> shift, bh = block_h >> shift;
+        const int       rows = bh >> 1;
+        const int       pad  = level == 2 ? 63 : ref.pad - 1;
+        const svtme_sa &sa   = level == 1 ? k.hme_l1_sa : k.hme_l2_sa;
+        int16_t         w = (int16_t)(((int16_t)sa.width + 7) & ~0x07), h = (int16_t)sa.height;
+        if (level == 1) {
+            cx = (int16_t)(cx >> 1);
+            cy = (int16_t)(cy >> 1);
+        }
+        int16_t org_x = (int16_t)(-(w >> 1) + cx), org_y = (int16_t)(-(h >> 1) + cy);
+        clip_axis(ox, org_x, w, -pad, ref.width);
+        w = (int16_t)(w < 8 ? w : (w & ~0x07));
+        clip_axis(oy, org_y, h, -pad, ref.height);
+        if (threadIdx.x == 0) count_ops(p, 2 + level, (unsigned long long)max((int)h, 0) * max((int)w, 0) * rows * bw);
+        const u64 key = small_search(S, win, cur, ref, ox, oy, bw, rows, ox + org_x, oy + org_y, w, h);
+        uint32_t  sad;
+        decode_key(key, w, org_x, org_y, level == 1 ? 2 : 1, cx, cy, sad);
+        if (threadIdx.x == 0) {
+            out->lx[level][i]   = cx;
+            out->ly[level][i]   = cy;
+            out->lsad[level][i] = sad;
+        }
+    }
+}
+
+void launch_hme_items(const PicParams &p, hipStream_t s) {
+    const int n_refs = p.n_ref[0] + (p.n_list == 2 ? p.n_ref[1] : 0);
+    const int n_b64  = p.b64_w * p.b64_h;
+    const int n_reg  = p.ctrl.num_hme_sa_w * p.ctrl.num_hme_sa_h;
+    (void)hipMemsetAsync(p.hme_out, 0, (size_t)n_b64 * SVTME_MAX_LISTS * SVTME_MAX_REFS * sizeof(HmeRefOut), s);
+    hipLaunchKernelGGL(hme_l0_kernel, dim3(n_b64, n_refs, 2 + max(n_reg, 1)), dim3(HI_THREADS), 0, s, p);
+    if (p.ctrl.enable_hme_flag) hipLaunchKernelGGL(hme_l12_kernel, dim3(n_b64, n_refs, n_reg), dim3(HI_THREADS), 0, s, p);
+}
+
+} // namespace svtme

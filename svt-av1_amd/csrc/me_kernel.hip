@@ -24,8 +24,6 @@
 //                   Running minima carry the row number in the low key bits, so the reference's tie rule (first
 //                   strictly smaller SAD in raster order) is reproduced exactly: keys order by (SAD, y, x).
 //  me_finish_kernel keys -> p_sb_best_sad / p_sb_best_mv.
-#include <type_traits>
-
 #include "search_common.h"
 
 namespace svtme {
@@ -33,7 +31,7 @@ namespace svtme {
 constexpr int ME_THREADS   = 64;
 constexpr int ME_PD        = 32; // dwords per staged window row: 64 positions + 63 more pixels, rounded up
 constexpr int ME_TILE      = 64; // search positions per tile side
-constexpr int ME_WIN_ROWS  = ME_TILE + 70; // 62 rows under the last position + the staggered walk's overrun
+constexpr int ME_WIN_ROWS  = 8 + 70; // a work item's 8 search rows, 62 rows under the last one + the staggered walk's overrun
 constexpr int ME_WIN_BYTES = ME_WIN_ROWS * ME_PD * 4;
 
 struct MeShared {
@@ -50,16 +48,6 @@ struct MeShared {
 
 // z-order index of the 16x16 block in raster (row, col): svt_ext_all_sad_calculation_8x8_16x16_c's `offsets` (:366)
 __device__ __forceinline__ int z16(int row, int col) { return ((row >> 1) << 3) | ((col >> 1) << 2) | ((row & 1) << 1) | (col & 1); }
-
-// compile-time loop: f(std::integral_constant<int, I>) for I in [B, E); indices stay constant expressions, so the
-// per-position register arrays below never become runtime-indexed
-template <int B, int E, class F>
-__device__ __forceinline__ void static_for(F &&f) {
-    if constexpr (B < E) {
-        f(std::integral_constant<int, B>{});
-        static_for<B + 1, E>(f);
-    }
-}
 
 // lane ^ 1 and lane ^ 2 within a quad, as DPP quad_perm moves (no LDS traffic)
 __device__ __forceinline__ uint32_t quad_xor1(uint32_t v) { return (uint32_t)__builtin_amdgcn_mov_dpp((int)v, 0xB1, 0xF, 0xF, true); }
@@ -86,20 +74,8 @@ __device__ __forceinline__ void min4(const uint32_t (&k)[4], uint32_t &best, uin
         }
 }
 
-// Runs (4 adjacent positions x 8 rows) per work item in a column chunk of n_xg position quads: at most 16 (one per
-// quad of lanes), and few enough that an item never spans more than 8 row groups = the 64 search rows LDS holds.
-__device__ __forceinline__ int me_runs_per_item(int n_xg) { return min(16, 7 * n_xg); }
-
-// Work items of a w x h window: per 64-position column chunk, ceil(runs / runs per item).
-__device__ __forceinline__ int me_item_count(int w, int h) {
-    const int n_yg = (h + 7) >> 3;
-    int       n    = 0;
-    for (int tx0 = 0; tx0 < w; tx0 += ME_TILE) {
-        const int n_xg = (min(ME_TILE, w - tx0) + 3) >> 2, cap = me_runs_per_item(n_xg);
-        n += (n_xg * n_yg + cap - 1) / cap;
-    }
-    return n;
-}
+// Work items of a w x h window: one per (64-position column chunk, group of 8 rows).
+__device__ __forceinline__ int me_item_count(int w, int h) { return ((w + ME_TILE - 1) / ME_TILE) * ((h + 7) >> 3); }
 
 __global__ void __launch_bounds__(ME_THREADS) me_plan_kernel(PicParams p) {
     __shared__ MeShared S;
@@ -267,7 +243,7 @@ __global__ void __launch_bounds__(ME_THREADS) me_plan_kernel(PicParams p) {
     }
 }
 
-__global__ void __launch_bounds__(ME_THREADS, 2) me_search_kernel(PicParams p) {
+__global__ void __launch_bounds__(ME_THREADS, 3) me_search_kernel(PicParams p) {
     __shared__ MeShared               S;
     __shared__ __align__(16) uint32_t win[ME_WIN_BYTES / 4];
     const int tid = threadIdx.x;
@@ -282,27 +258,13 @@ __global__ void __launch_bounds__(ME_THREADS, 2) me_search_kernel(PicParams p) {
     const MeJob job = p.me_jobs[b64 * 8 + my];
     const int   w = job.w, h = job.h, org_x = job.org_x, org_y = job.org_y;
     if (w <= 0) return;
-    // ---- which runs are this item's: column chunks of 64 positions, each cut into items of <= 16 runs
+    // ---- this item: one group of 8 search rows of one 64-position column chunk = up to 16 runs (4 positions x 8 rows)
     const int n_yg = (h + 7) >> 3;
-    int       item = blockIdx.z, tx0 = 0, n_xg = 0, r0 = 0, r1 = 0;
-    bool      found = false;
-    for (; tx0 < w; tx0 += ME_TILE) {
-        n_xg               = (min(ME_TILE, w - tx0) + 3) >> 2;
-        const int n_run    = n_xg * n_yg;
-        const int cap      = me_runs_per_item(n_xg);
-        const int n_item   = (n_run + cap - 1) / cap;
-        if (item < n_item) {
-            const int per = (n_run + n_item - 1) / n_item;
-            r0            = item * per;
-            r1            = min(n_run, r0 + per);
-            found         = r0 < r1;
-            break;
-        }
-        item -= n_item;
-    }
-    if (!found) return;
-    const int yg0 = r0 / n_xg, yg1 = (r1 - 1) / n_xg;
-    const int ty0 = yg0 * 8, rows = min(h, yg1 * 8 + 8) - ty0; // search rows staged for this item
+    if ((int)blockIdx.z >= me_item_count(w, h)) return;
+    const int chunk = blockIdx.z / n_yg, yg0 = blockIdx.z - chunk * n_yg;
+    const int tx0 = chunk * ME_TILE, n_xg = (min(ME_TILE, w - tx0) + 3) >> 2;
+    const int ty0 = yg0 * 8, rows = min(h - ty0, 8); // search rows staged for this item
+    const int r0 = 0, r1 = n_xg;
 
     const DevPlane &cur = p.cur.lvl[2];
     const DevPlane &ref = p.ref[my_l][my_r].lvl[2];
@@ -321,18 +283,18 @@ __global__ void __launch_bounds__(ME_THREADS, 2) me_search_kernel(PicParams p) {
         {
             __syncthreads();
             {
-                // stage the window: 2 rows per trip, lane = dword within the row (unaligned 4-byte loads)
-                const int      ndw = n_xg + 16, nrow = rows + 62, d = tid & 31;
-                const uint8_t *g = ref.pix + (ptrdiff_t)(b64y + org_y + ty0 + (tid >> 5)) * ref.stride + (b64x + org_x + tx0 + 4 * d);
-                uint32_t      *dst = win + (tid >> 5) * ME_PD + d;
-                if (d < ndw) {
-#pragma unroll 4
-                    for (int r = tid >> 5; r < nrow; r += 2) {
-                        uint32_t v;
-                        __builtin_memcpy(&v, g, 4);
+                // stage the window: 8 rows per trip, lane = 16 bytes of a row (unaligned 16-byte loads)
+                const int      nq = (n_xg + 16 + 3) >> 2, nrow = rows + 62, d = tid & 7;
+                const uint8_t *g = ref.pix + (ptrdiff_t)(b64y + org_y + ty0 + (tid >> 3)) * ref.stride + (b64x + org_x + tx0 + 16 * d);
+                uint4         *dst = reinterpret_cast<uint4 *>(win) + (tid >> 3) * (ME_PD / 4) + d;
+                if (d < nq) {
+#pragma unroll 2
+                    for (int r = tid >> 3; r < nrow; r += 8) {
+                        uint4 v;
+                        __builtin_memcpy(&v, g, 16);
                         *dst = v;
-                        g += 2 * (ptrdiff_t)ref.stride;
-                        dst += 2 * ME_PD;
+                        g += 8 * (ptrdiff_t)ref.stride;
+                        dst += 8 * (ME_PD / 4);
                     }
                 }
             }
@@ -347,9 +309,8 @@ __global__ void __launch_bounds__(ME_THREADS, 2) me_search_kernel(PicParams p) {
                 const bool valid = u < n_unit;
                 const int  run   = r0 + (valid ? (split ? u >> 1 : u) : 0);
                 const int  par0  = split ? (u & 1) : 0;
-                const int  yg    = run / n_xg;
-                const int  xg    = run - yg * n_xg;
-                const int  ya    = yg * 8 - ty0, yb = min(rows, ya + 8);
+                const int  xg    = run;
+                const int  ya = 0, yb = rows;
                 // running minima of this lane. 8x8: packed 16-bit keys SAD * 8 + row-in-run, two positions per dword;
                 // 16x16: SAD << 16 | row; larger: SAD << 3 | row. A position that does not exist carries an all-ones row
                 // mask, which makes its keys all ones.

@@ -1,10 +1,22 @@
 // search_common.h - device helpers shared by the HME and integer-search kernels.
 #pragma once
+#include <type_traits>
+
 #include "svtme_device.h"
 
 namespace svtme {
 
 typedef unsigned long long u64;
+
+// compile-time loop: f(std::integral_constant<int, I>) for I in [B, E); indices stay constant expressions, so
+// register arrays indexed by them never become runtime-indexed
+template <int B, int E, class F>
+__device__ __forceinline__ void static_for(F &&f) {
+    if constexpr (B < E) {
+        f(std::integral_constant<int, B>{});
+        static_for<B + 1, E>(f);
+    }
+}
 
 // get_scaled_picture_distance, Source/Lib/Encoder/Codec/EbMotionEstimation.c:1276-1280
 __device__ __forceinline__ int scaled_dist(int dist) { return (uint16_t)(((dist * 5) / 8) + ((dist % 8) ? 1 : 0)); }

@@ -34,6 +34,10 @@ struct HmeRefOut {
     uint32_t pre_sad[2];
     uint32_t zz_sad;
     uint32_t valid; // bit0: HME ran for this reference (not a base-layer list-1 reference)
+    // level-0 results before the worst region gives way to a better pre-HME result
+    int16_t  raw_x[4];
+    int16_t  raw_y[4];
+    uint32_t raw_sad[4];
 };
 
 // Integer-search window of one (b64, list, ref), window origin relative to the b64 origin; w == 0: not searched.
@@ -77,7 +81,8 @@ constexpr int SVTME_OPS_BYTES = SVTME_OPS_SLOTS * 8 * 8;
 // store kernels (store_kernels.hip)
 void launch_store_build(const uint8_t *luma, int luma_stride, const DevPicture &pic, int hme_level1, hipStream_t s);
 // search kernels
-void launch_hme(const PicParams &p, hipStream_t s);
+void launch_hme(const PicParams &p, hipStream_t s); // picks the serial or the itemised kernels
+void launch_hme_items(const PicParams &p, hipStream_t s);
 void launch_me(const PicParams &p, hipStream_t s);
 
 } // namespace svtme
