@@ -57,6 +57,15 @@ struct Flight {
     // pinned host mirror of d_res
     uint8_t             *h_res = nullptr;
     size_t               off_mv = 0, off_sr = 0, off_zz = 0, off_div = 0, off_ops = 0, res_bytes = 0;
+    // result arrays of n (b64, list, ref) entries, packed back to back so that one copy brings them all to the host
+    void layout(size_t n) {
+        off_mv    = n * SVTME_PU_COUNT * 4;
+        off_sr    = off_mv * 2;
+        off_zz    = off_sr + n * sizeof(svtme_search_result);
+        off_div   = off_zz + n * 4;
+        off_ops   = (off_div + n * 4 + 63) / 64 * 64;
+        res_bytes = off_ops + SVTME_OPS_BYTES;
+    }
     hipEvent_t           ev[4] = {nullptr, nullptr, nullptr, nullptr}; // start, after HME, after ME, after D2H
 };
 
@@ -65,7 +74,7 @@ struct Flight {
 struct svtme_engine {
     svtme_config        cfg{};
     std::mutex          mu;
-    hipStream_t         s_store = nullptr, s_me = nullptr;
+    hipStream_t         s_store = nullptr, s_me = nullptr, s_copy = nullptr;
     std::vector<Slot>   slots;
     std::vector<Flight> flights;
     svtme_ticket        next_ticket = 1;
@@ -135,7 +144,8 @@ extern "C" int svtme_create(const svtme_config *cfg, svtme_engine **out) {
         return code;
     };
     if (hipStreamCreateWithFlags(&e->s_store, hipStreamNonBlocking) != hipSuccess ||
-        hipStreamCreateWithFlags(&e->s_me, hipStreamNonBlocking) != hipSuccess)
+        hipStreamCreateWithFlags(&e->s_me, hipStreamNonBlocking) != hipSuccess ||
+        hipStreamCreateWithFlags(&e->s_copy, hipStreamNonBlocking) != hipSuccess)
         return fail(SVTME_ERR_DEVICE);
     DevPicture tmp;
     layout_planes(nullptr, cfg->max_width, cfg->max_height, &tmp, &e->slot_bytes);
@@ -151,12 +161,7 @@ extern "C" int svtme_create(const svtme_config *cfg, svtme_engine **out) {
     e->flights.resize(cfg->max_in_flight);
     for (auto &f : e->flights) {
         const size_t n = e->max_b64 * SVTME_MAX_LISTS * SVTME_MAX_REFS;
-        f.off_mv  = n * SVTME_PU_COUNT * 4;
-        f.off_sr  = f.off_mv * 2;
-        f.off_zz  = f.off_sr + n * sizeof(svtme_search_result);
-        f.off_div = f.off_zz + n * 4;
-        f.off_ops = (f.off_div + n * 4 + 63) / 64 * 64;
-        f.res_bytes = f.off_ops + SVTME_OPS_BYTES;
+        f.layout(n);
         if (hipMalloc((void **)&f.d_hme, n * sizeof(HmeRefOut)) != hipSuccess || hipMalloc((void **)&f.d_res, f.res_bytes) != hipSuccess ||
             hipMalloc((void **)&f.d_jobs, n * sizeof(MeJob)) != hipSuccess ||
             hipMalloc((void **)&f.d_keys, n * SVTME_PU_COUNT * sizeof(unsigned long long)) != hipSuccess ||
@@ -173,6 +178,7 @@ extern "C" void svtme_destroy(svtme_engine *e) {
     if (!e) return;
     (void)hipSetDevice(e->cfg.device);
     if (e->s_me) (void)hipStreamSynchronize(e->s_me);
+    if (e->s_copy) (void)hipStreamSynchronize(e->s_copy);
     if (e->s_store) (void)hipStreamSynchronize(e->s_store);
     for (auto &s : e->slots) {
         if (s.mem) (void)hipFree(s.mem);
@@ -183,6 +189,7 @@ extern "C" void svtme_destroy(svtme_engine *e) {
     for (auto &f : e->flights) free_flight(f);
     if (e->s_me) (void)hipStreamDestroy(e->s_me);
     if (e->s_store) (void)hipStreamDestroy(e->s_store);
+    if (e->s_copy) (void)hipStreamDestroy(e->s_copy);
     delete e;
 }
 
@@ -309,6 +316,7 @@ extern "C" int svtme_picture_submit(svtme_engine *e, const svtme_picture *pic, s
         (k.enable_me_sr_adjustment && k.distance_based_hme_resizing && k.reduce_hme_l0_sr_th_min && k.reduce_hme_l0_sr_th_max);
     const size_t n_b64 = (size_t)p.b64_w * p.b64_h;
     if (n_b64 > e->max_b64) return SVTME_ERR_BAD_ARG;
+    f->layout(n_b64 * SVTME_MAX_LISTS * SVTME_MAX_REFS); // never larger than the allocation (n_b64 <= max_b64)
     p.hme_out        = f->d_hme;
     p.me_jobs        = f->d_jobs;
     p.me_keys        = f->d_keys;
@@ -339,15 +347,10 @@ extern "C" int svtme_picture_submit(svtme_engine *e, const svtme_picture *pic, s
         e->slots[si].read_recorded = true;
         e->slots[si].readers++;
     }
-    // results back to pinned host memory (compacted to this picture's n_b64)
-    const size_t n = n_b64 * SVTME_MAX_LISTS * SVTME_MAX_REFS;
-    HIP_TRY(hipMemcpyAsync(f->h_res, f->d_res, n * SVTME_PU_COUNT * 4, hipMemcpyDeviceToHost, e->s_me));
-    HIP_TRY(hipMemcpyAsync(f->h_res + f->off_mv, f->d_res + f->off_mv, n * SVTME_PU_COUNT * 4, hipMemcpyDeviceToHost, e->s_me));
-    HIP_TRY(hipMemcpyAsync(f->h_res + f->off_sr, f->d_res + f->off_sr, n * sizeof(svtme_search_result), hipMemcpyDeviceToHost, e->s_me));
-    HIP_TRY(hipMemcpyAsync(f->h_res + f->off_zz, f->d_res + f->off_zz, n * 4, hipMemcpyDeviceToHost, e->s_me));
-    HIP_TRY(hipMemcpyAsync(f->h_res + f->off_div, f->d_res + f->off_div, n * 4, hipMemcpyDeviceToHost, e->s_me));
-    HIP_TRY(hipMemcpyAsync(f->h_res + f->off_ops, f->d_res + f->off_ops, SVTME_OPS_BYTES, hipMemcpyDeviceToHost, e->s_me));
-    HIP_TRY(hipEventRecord(f->ev[3], e->s_me));
+    // results back to pinned host memory on the copy stream, so that the next picture's kernels do not wait for PCIe
+    HIP_TRY(hipStreamWaitEvent(e->s_copy, f->ev[2], 0));
+    HIP_TRY(hipMemcpyAsync(f->h_res, f->d_res, f->res_bytes, hipMemcpyDeviceToHost, e->s_copy));
+    HIP_TRY(hipEventRecord(f->ev[3], e->s_copy));
     f->busy   = true;
     f->waited = false;
     f->n_b64  = (uint32_t)n_b64;

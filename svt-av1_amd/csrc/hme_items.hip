@@ -193,23 +193,7 @@ __device__ u64 l0_search(L0Shared &S, uint32_t *win, const DevPlane &cur, const 
             for (int y0 = 0; y0 < sa_h; y0 += band) {
                 const int brows = min(band, sa_h - y0);
                 __syncthreads();
-                {
-                    const int      nrow = brows + 14, n = nrow * pd;
-                    const uint8_t *g    = ref.pix + (ptrdiff_t)(wy + y0) * ref.stride + wx + x0;
-                    int            r = lane / pd, d = lane - r * pd;
-                    const int      dr = HI_THREADS / pd, dd = HI_THREADS - dr * pd;
-                    for (int i = lane; i < n; i += HI_THREADS) {
-                        uint32_t v;
-                        __builtin_memcpy(&v, g + (ptrdiff_t)r * ref.stride + 4 * d, 4);
-                        win[i] = v;
-                        r += dr;
-                        d += dd;
-                        if (d >= pd) {
-                            d -= pd;
-                            ++r;
-                        }
-                    }
-                }
+                stage_window(win, ref.pix + (ptrdiff_t)(wy + y0) * ref.stride + wx + x0, ref.stride, pd, brows + 14);
                 __syncthreads();
                 if (brows > 8) strip_units<8>(win, pd, n_xg, brows, skip_even, src, rows, zero, y0, x0, sa_w, best);
                 else if (brows > 4) strip_units<4>(win, pd, n_xg, brows, skip_even, src, rows, zero, y0, x0, sa_w, best);
@@ -322,15 +306,7 @@ __device__ u64 small_search(L12Shared &S, uint32_t *win, const DevPlane &cur, co
     for (int y0 = 0; y0 < sa_h; y0 += band) {
         const int brows = min(band, sa_h - y0);
         __syncthreads();
-        {
-            const int n = (brows + span - 1) * pd;
-            for (int i = lane; i < n; i += HI_THREADS) {
-                const int r = i / pd, d = i - r * pd;
-                uint32_t  v;
-                __builtin_memcpy(&v, ref.pix + (ptrdiff_t)(wy + y0 + r) * ref.stride + wx + 4 * d, 4);
-                win[i] = v;
-            }
-        }
+        stage_window(win, ref.pix + (ptrdiff_t)(wy + y0) * ref.stride + wx, ref.stride, pd, brows + span - 1);
         __syncthreads();
         const int total = (n_xg * brows) << chunk_log2;
         for (int base = 0; base < total; base += HI_THREADS) {

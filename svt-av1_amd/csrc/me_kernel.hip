@@ -271,10 +271,15 @@ __global__ void __launch_bounds__(ME_THREADS, 3) me_search_kernel(PicParams p) {
     if (tid == 0) S.zero = 0;
     // ---- open_loop_me_fullpel_search_sblock
     for (int i = tid; i < SVTME_PU_COUNT; i += ME_THREADS) S.best[i] = ~0ull;
+    {
+        uint4 v[2];
 #pragma unroll
-    for (int i = tid; i < 32 * 16; i += ME_THREADS) {
-        const int r = i >> 4, d = i & 15;
-        S.src[i] = *reinterpret_cast<const uint32_t *>(cur.pix + (ptrdiff_t)(b64y + 2 * r) * cur.stride + b64x + 4 * d);
+        for (int t = 0; t < 2; ++t) {
+            const int i = tid + ME_THREADS * t; // 16-byte piece: row i / 4, piece i % 4
+            __builtin_memcpy(&v[t], cur.pix + (ptrdiff_t)(b64y + 2 * (i >> 2)) * cur.stride + b64x + 16 * (i & 3), 16);
+        }
+#pragma unroll
+        for (int t = 0; t < 2; ++t) reinterpret_cast<uint4 *>(S.src)[tid + ME_THREADS * t] = v[t];
     }
     const int       quad = tid >> 2, col = tid & 3;
     const uint32_t *sbase = &S.src[col * 4];
@@ -288,14 +293,14 @@ __global__ void __launch_bounds__(ME_THREADS, 3) me_search_kernel(PicParams p) {
                 const uint8_t *g = ref.pix + (ptrdiff_t)(b64y + org_y + ty0 + (tid >> 3)) * ref.stride + (b64x + org_x + tx0 + 16 * d);
                 uint4         *dst = reinterpret_cast<uint4 *>(win) + (tid >> 3) * (ME_PD / 4) + d;
                 if (d < nq) {
-#pragma unroll 2
-                    for (int r = tid >> 3; r < nrow; r += 8) {
-                        uint4 v;
-                        __builtin_memcpy(&v, g, 16);
-                        *dst = v;
-                        g += 8 * (ptrdiff_t)ref.stride;
-                        dst += 8 * (ME_PD / 4);
-                    }
+                    // nrow <= 70: at most 9 trips, all loads issued before the first store
+                    uint4 v[9];
+#pragma unroll
+                    for (int t = 0; t < 9; ++t)
+                        if ((tid >> 3) + 8 * t < nrow) __builtin_memcpy(&v[t], g + (ptrdiff_t)(8 * t) * ref.stride, 16);
+#pragma unroll
+                    for (int t = 0; t < 9; ++t)
+                        if ((tid >> 3) + 8 * t < nrow) dst[8 * t * (ME_PD / 4)] = v[t];
                 }
             }
             __syncthreads();

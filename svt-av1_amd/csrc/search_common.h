@@ -51,6 +51,30 @@ __device__ __forceinline__ uint32_t load_u32_any(const uint8_t *p) {
     return __builtin_amdgcn_alignbyte(hi, lo, (uint32_t)(a & 3));
 }
 
+// Copies an (n_row x pd dwords) window from a plane (any byte alignment) into LDS rows of pd dwords, whole 64-lane wave.
+// Eight loads are in flight per lane before the first is stored, so a window costs a few memory round trips, not one
+// per 64 dwords.
+__device__ __forceinline__ void stage_window(uint32_t *win, const uint8_t *g, int stride, int pd, int n_row) {
+    const int n    = n_row * pd;
+    const int lane = threadIdx.x & 63;
+    for (int base = 0; base < n; base += 64 * 8) {
+        uint32_t v[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const int i = base + k * 64 + lane;
+            if (i < n) {
+                const int r = i / pd, d = i - r * pd;
+                __builtin_memcpy(&v[k], g + (ptrdiff_t)r * stride + 4 * d, 4);
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const int i = base + k * 64 + lane;
+            if (i < n) win[i] = v[k];
+        }
+    }
+}
+
 __device__ __forceinline__ uint32_t wave_sum(uint32_t v) {
 #pragma unroll
     for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m);
