@@ -197,9 +197,11 @@ int svtme_picture_wait(svtme_engine *e, svtme_ticket ticket, svtme_results *out)
 /* Returns the result buffers of a waited picture to the engine. */
 int svtme_picture_done(svtme_engine *e, svtme_ticket ticket);
 
-/* Device time of the last waited picture's kernels in milliseconds (HIP events on the engine stream):
- * [0] = HME kernel, [1] = integer-search kernel, [2] = whole picture incl. D2H. Diagnostic only. */
-int svtme_picture_timing(svtme_engine *e, svtme_ticket ticket, float ms[3]);
+/* Device time of a waited picture's kernels in milliseconds (HIP events on the stream the kernels run on):
+ * [0] HME pre-HME + level-0 kernel (or the serial HME kernel), [1] HME level-1/2 kernel, [2] integer-search plan,
+ * [3] integer-search kernel, [4] integer-search finish, [5] first kernel start to last kernel end,
+ * [6] the same up to the end of the result copy, [7] 0. Diagnostic only. */
+int svtme_picture_timing(svtme_engine *e, svtme_ticket ticket, float ms[8]);
 
 /* Number of abs-diff-accumulate operations the waited picture's searches performed (after clipping, early exits
  * and pruning): [0] zero-MV / search-centre SADs, [1] pre-HME, [2] HME L0, [3] L1, [4] L2, [5] integer search.

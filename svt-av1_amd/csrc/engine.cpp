@@ -66,7 +66,8 @@ struct Flight {
         off_ops   = (off_div + n * 4 + 63) / 64 * 64;
         res_bytes = off_ops + SVTME_OPS_BYTES;
     }
-    hipEvent_t           ev[4] = {nullptr, nullptr, nullptr, nullptr}; // start, after HME, after ME, after D2H
+    // start, after each of the 2 HME and 3 ME kernels, after D2H
+    hipEvent_t           ev[7] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
 };
 
 } // namespace
@@ -337,20 +338,18 @@ extern "C" int svtme_picture_submit(svtme_engine *e, const svtme_picture *pic, s
     for (int si : used) HIP_TRY(hipStreamWaitEvent(e->s_me, e->slots[si].ready, 0));
     HIP_TRY(hipEventRecord(f->ev[0], e->s_me));
     HIP_TRY(hipMemsetAsync(f->d_res + f->off_ops, 0, SVTME_OPS_BYTES, e->s_me));
-    launch_hme(p, e->s_me);
-    HIP_TRY(hipEventRecord(f->ev[1], e->s_me));
-    launch_me(p, e->s_me);
+    launch_hme(p, e->s_me, &f->ev[1]);
+    launch_me(p, e->s_me, &f->ev[3]);
     HIP_TRY(hipGetLastError());
-    HIP_TRY(hipEventRecord(f->ev[2], e->s_me));
     for (int si : used) {
         HIP_TRY(hipEventRecord(e->slots[si].last_read, e->s_me));
         e->slots[si].read_recorded = true;
         e->slots[si].readers++;
     }
     // results back to pinned host memory on the copy stream, so that the next picture's kernels do not wait for PCIe
-    HIP_TRY(hipStreamWaitEvent(e->s_copy, f->ev[2], 0));
+    HIP_TRY(hipStreamWaitEvent(e->s_copy, f->ev[5], 0));
     HIP_TRY(hipMemcpyAsync(f->h_res, f->d_res, f->res_bytes, hipMemcpyDeviceToHost, e->s_copy));
-    HIP_TRY(hipEventRecord(f->ev[3], e->s_copy));
+    HIP_TRY(hipEventRecord(f->ev[6], e->s_copy));
     f->busy   = true;
     f->waited = false;
     f->n_b64  = (uint32_t)n_b64;
@@ -375,7 +374,7 @@ extern "C" int svtme_picture_wait(svtme_engine *e, svtme_ticket ticket, svtme_re
         if (!f) return SVTME_ERR_NOT_FOUND;
     }
     HIP_TRY(hipSetDevice(e->cfg.device));
-    HIP_TRY(hipEventSynchronize(f->ev[3]));
+    HIP_TRY(hipEventSynchronize(f->ev[6]));
     std::lock_guard<std::mutex> lock(e->mu);
     if (!f->waited) {
         f->waited = true;
@@ -412,14 +411,15 @@ extern "C" int svtme_picture_done(svtme_engine *e, svtme_ticket ticket) {
     return SVTME_OK;
 }
 
-extern "C" int svtme_picture_timing(svtme_engine *e, svtme_ticket ticket, float ms[3]) {
+extern "C" int svtme_picture_timing(svtme_engine *e, svtme_ticket ticket, float ms[8]) {
     if (!e || !ms) return SVTME_ERR_BAD_ARG;
     std::lock_guard<std::mutex> lock(e->mu);
     Flight *f = find_flight(e, ticket);
     if (!f || !f->waited) return SVTME_ERR_NOT_FOUND;
-    HIP_TRY(hipEventElapsedTime(&ms[0], f->ev[0], f->ev[1]));
-    HIP_TRY(hipEventElapsedTime(&ms[1], f->ev[1], f->ev[2]));
-    HIP_TRY(hipEventElapsedTime(&ms[2], f->ev[0], f->ev[3]));
+    for (int i = 0; i < 5; ++i) HIP_TRY(hipEventElapsedTime(&ms[i], f->ev[i], f->ev[i + 1]));
+    HIP_TRY(hipEventElapsedTime(&ms[5], f->ev[0], f->ev[5]));
+    HIP_TRY(hipEventElapsedTime(&ms[6], f->ev[0], f->ev[6]));
+    ms[7] = 0.f;
     return SVTME_OK;
 }
 
@@ -445,5 +445,13 @@ extern "C" int svtme_unpack_b64(const svtme_results *res, uint32_t b64_index, ui
     if (search_results) memcpy(search_results, res->search_results + (size_t)b64_index * n, n * sizeof(svtme_search_result));
     if (zz_sad) memcpy(zz_sad, res->zz_sad + (size_t)b64_index * n, n * 4);
     if (reduce_me_sr_divisor) memcpy(reduce_me_sr_divisor, res->reduce_me_sr_divisor + (size_t)b64_index * n, n * 4);
+    return SVTME_OK;
+}
+
+// Diagnostic, not part of the public header: resident workgroups per CU of {hme_l0, hme_l12, me_search}.
+extern "C" int svtme_debug_occupancy(int device, int out[3]) {
+    HIP_TRY(hipSetDevice(device));
+    occupancy_hme_items(out);
+    out[2] = occupancy_me_search();
     return SVTME_OK;
 }

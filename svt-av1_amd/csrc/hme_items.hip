@@ -184,7 +184,7 @@ __device__ u64 l0_search(L0Shared &S, uint32_t *win, const DevPlane &cur, const 
         const int zero = S.zero;
         for (int x0 = 0; x0 < sa_w; x0 += HI_XCHUNK) {
             const int n_xg = (min(HI_XCHUNK, sa_w - x0) + 3) >> 2;
-            const int pd   = n_xg + 4; // dwords per staged row: the positions + 15 more pixels, rounded up
+            const int pd   = (n_xg + 4 + 3) & ~3; // dwords per staged row: the positions + 15 more pixels, in 16-byte pieces
             // rows the LDS budget holds: a band's search rows + 14 rows under the last one + the staggered walk's
             // overrun (rows that are addressed but never used)
             const int cap  = HI_WIN_BYTES / (4 * pd);
@@ -195,8 +195,10 @@ __device__ u64 l0_search(L0Shared &S, uint32_t *win, const DevPlane &cur, const 
                 __syncthreads();
                 stage_window(win, ref.pix + (ptrdiff_t)(wy + y0) * ref.stride + wx + x0, ref.stride, pd, brows + 14);
                 __syncthreads();
-                if (brows > 8) strip_units<8>(win, pd, n_xg, brows, skip_even, src, rows, zero, y0, x0, sa_w, best);
-                else if (brows > 4) strip_units<4>(win, pd, n_xg, brows, skip_even, src, rows, zero, y0, x0, sa_w, best);
+                // rows per unit: as many as still give every lane a unit
+                const int cells = n_xg * ((brows + 1) >> 1); // position quads x row pairs
+                if (brows > 8 && cells >= 8 * HI_THREADS) strip_units<8>(win, pd, n_xg, brows, skip_even, src, rows, zero, y0, x0, sa_w, best);
+                else if (brows > 4 && cells >= 4 * HI_THREADS) strip_units<4>(win, pd, n_xg, brows, skip_even, src, rows, zero, y0, x0, sa_w, best);
                 else strip_units<2>(win, pd, n_xg, brows, skip_even, src, rows, zero, y0, x0, sa_w, best);
             }
         }
@@ -217,12 +219,14 @@ __global__ void __launch_bounds__(HI_THREADS, 3) hme_l0_kernel(PicParams p) {
     const int             b64 = blockIdx.x;
     const int             b64x = (b64 % p.b64_w) * 64, b64y = (b64 / p.b64_w) * 64;
     const int             block_w = min(p.width - b64x, 64), block_h = min(p.height - b64y, 64);
-    int                   l = 0, r = blockIdx.y;
+    // references in reverse order: the closest references (smallest areas, cheapest items) are dispatched last and keep
+    // the kernel's tail short
+    int                   l = 0, r = (int)(gridDim.z - 1 - blockIdx.z);
     if (r >= p.n_ref[0]) {
         r -= p.n_ref[0];
         l = 1;
     }
-    const int  sub      = blockIdx.z; // 0, 1: pre-HME shapes; 2..: level-0 regions in the reference's visiting order
+    const int  sub      = blockIdx.y; // 0, 1: pre-HME shapes; 2..: level-0 regions in the reference's visiting order
     const bool searched = ref_searched(p, l);
     HmeRefOut *out      = &p.hme_out[(b64 * SVTME_MAX_LISTS + l) * SVTME_MAX_REFS + r];
     const bool header   = sub == 2; // this item also writes the per-reference fields
@@ -298,59 +302,62 @@ __device__ u64 small_search(L12Shared &S, uint32_t *win, const DevPlane &cur, co
         S.src[r * 16 + d] = *reinterpret_cast<const uint32_t *>(cur.pix + (ptrdiff_t)(oy + 2 * r) * cur.stride + ox + 4 * d);
     }
     if (lane == 0) S.key = ~0ull;
-    const int n_xg = (sa_w + 3) >> 2, pd = n_xg + bwd, span = (rows - 1) * 2 + 1;
-    int       band = HI_WIN2_BYTES / (4 * pd) - (span - 1);
-    band           = max(band, 1);
+    const int span       = (rows - 1) * 2 + 1;
     const int chunk_log2 = rows >= 16 ? 3 : (rows >= 4 ? 2 : 0), chunks = 1 << chunk_log2;
     const int rpc        = (rows + chunks - 1) >> chunk_log2; // sampled block rows per lane
-    for (int y0 = 0; y0 < sa_h; y0 += band) {
-        const int brows = min(band, sa_h - y0);
-        __syncthreads();
-        stage_window(win, ref.pix + (ptrdiff_t)(wy + y0) * ref.stride + wx, ref.stride, pd, brows + span - 1);
-        __syncthreads();
-        const int total = (n_xg * brows) << chunk_log2;
-        for (int base = 0; base < total; base += HI_THREADS) {
-            const int  t     = base + lane;
-            const bool valid = t < total;
-            const int  chunk = t & (chunks - 1);
-            const int  q     = valid ? t >> chunk_log2 : 0;
-            const int  yl = q / n_xg, xg = q - yl * n_xg;
-            uint32_t   a32[4] = {0, 0, 0, 0};
-            if (valid) {
-                const int j0 = chunk * rpc, j1 = min(rows, j0 + rpc);
-                u64       a16 = 0;
-                int       px  = 0;
-                for (int j = j0; j < j1; ++j) {
-                    const uint32_t *rr = win + (yl + 2 * j) * pd + xg;
-                    const uint32_t *ss = &S.src[j * 16];
-                    if (px + bw > 256) { // keep the packed 16-bit sums below 65536
+    const int xc         = (32 - bwd) * 4; // positions per staged column chunk: a staged row is at most 32 dwords
+    for (int x0 = 0; x0 < sa_w; x0 += xc) {
+        const int n_xg = (min(xc, sa_w - x0) + 3) >> 2, pd = (n_xg + bwd + 3) & ~3;
+        const int band = max(HI_WIN2_BYTES / (4 * pd) - (span - 1), 1);
+        for (int y0 = 0; y0 < sa_h; y0 += band) {
+            const int brows = min(band, sa_h - y0);
+            __syncthreads();
+            stage_window(win, ref.pix + (ptrdiff_t)(wy + y0) * ref.stride + wx + x0, ref.stride, pd, brows + span - 1);
+            __syncthreads();
+            const int total = (n_xg * brows) << chunk_log2;
+            for (int base = 0; base < total; base += HI_THREADS) {
+                const int  t     = base + lane;
+                const bool valid = t < total;
+                const int  chunk = t & (chunks - 1);
+                const int  q     = valid ? t >> chunk_log2 : 0;
+                const int  yl = q / n_xg, xg = q - yl * n_xg;
+                uint32_t   a32[4] = {0, 0, 0, 0};
+                if (valid) {
+                    const int j0 = chunk * rpc, j1 = min(rows, j0 + rpc);
+                    u64       a16 = 0;
+                    int       px  = 0;
+                    for (int j = j0; j < j1; ++j) {
+                        const uint32_t *rr = win + (yl + 2 * j) * pd + xg;
+                        const uint32_t *ss = &S.src[j * 16];
+                        if (px + bw > 256) { // keep the packed 16-bit sums below 65536
 #pragma unroll
-                        for (int i = 0; i < 4; ++i) a32[i] += (uint32_t)(a16 >> (16 * i)) & 0xFFFFu;
-                        a16 = 0;
-                        px  = 0;
+                            for (int i = 0; i < 4; ++i) a32[i] += (uint32_t)(a16 >> (16 * i)) & 0xFFFFu;
+                            a16 = 0;
+                            px  = 0;
+                        }
+                        uint32_t r0 = rr[0];
+                        for (int d = 0; d < bwd; ++d) {
+                            const uint32_t r1 = rr[d + 1];
+                            a16 = __builtin_amdgcn_qsad_pk_u16_u8(((u64)r1 << 32) | r0, ss[d], a16);
+                            r0  = r1;
+                        }
+                        px += bw;
                     }
-                    uint32_t r0 = rr[0];
-                    for (int d = 0; d < bwd; ++d) {
-                        const uint32_t r1 = rr[d + 1];
-                        a16 = __builtin_amdgcn_qsad_pk_u16_u8(((u64)r1 << 32) | r0, ss[d], a16);
-                        r0  = r1;
-                    }
-                    px += bw;
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) a32[i] += (uint32_t)(a16 >> (16 * i)) & 0xFFFFu;
                 }
+                for (int m = 1; m < chunks; m <<= 1) {
 #pragma unroll
-                for (int i = 0; i < 4; ++i) a32[i] += (uint32_t)(a16 >> (16 * i)) & 0xFFFFu;
-            }
-            for (int m = 1; m < chunks; m <<= 1) {
+                    for (int i = 0; i < 4; ++i) a32[i] += __shfl_xor(a32[i], m);
+                }
+                if (valid && chunk == 0) {
 #pragma unroll
-                for (int i = 0; i < 4; ++i) a32[i] += __shfl_xor(a32[i], m);
-            }
-            if (valid && chunk == 0) {
-#pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    const int x = xg * 4 + i;
-                    if (x < sa_w) {
-                        const u64 kk = ((u64)a32[i] << 32) | (uint32_t)((y0 + yl) * sa_w + x);
-                        best         = kk < best ? kk : best;
+                    for (int i = 0; i < 4; ++i) {
+                        const int x = x0 + xg * 4 + i;
+                        if (x < sa_w) {
+                            const u64 kk = ((u64)a32[i] << 32) | (uint32_t)((y0 + yl) * sa_w + x);
+                            best         = kk < best ? kk : best;
+                        }
                     }
                 }
             }
@@ -446,13 +453,21 @@ __global__ void __launch_bounds__(HI_THREADS) hme_l12_kernel(PicParams p) {
     }
 }
 
-void launch_hme_items(const PicParams &p, hipStream_t s) {
+void launch_hme_items(const PicParams &p, hipStream_t s, hipEvent_t marks[2]) {
     const int n_refs = p.n_ref[0] + (p.n_list == 2 ? p.n_ref[1] : 0);
     const int n_b64  = p.b64_w * p.b64_h;
     const int n_reg  = p.ctrl.num_hme_sa_w * p.ctrl.num_hme_sa_h;
     (void)hipMemsetAsync(p.hme_out, 0, (size_t)n_b64 * SVTME_MAX_LISTS * SVTME_MAX_REFS * sizeof(HmeRefOut), s);
-    hipLaunchKernelGGL(hme_l0_kernel, dim3(n_b64, n_refs, 2 + max(n_reg, 1)), dim3(HI_THREADS), 0, s, p);
+    hipLaunchKernelGGL(hme_l0_kernel, dim3(n_b64, 2 + max(n_reg, 1), n_refs), dim3(HI_THREADS), 0, s, p);
+    (void)hipEventRecord(marks[0], s);
     if (p.ctrl.enable_hme_flag) hipLaunchKernelGGL(hme_l12_kernel, dim3(n_b64, n_refs, n_reg), dim3(HI_THREADS), 0, s, p);
+    (void)hipEventRecord(marks[1], s);
+}
+
+// resident workgroups per CU the runtime expects for the two kernels (diagnostic)
+void occupancy_hme_items(int out[2]) {
+    (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&out[0], hme_l0_kernel, HI_THREADS, 0);
+    (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&out[1], hme_l12_kernel, HI_THREADS, 0);
 }
 
 } // namespace svtme

@@ -482,17 +482,19 @@ __global__ void __launch_bounds__(HME_THREADS) hme_kernel(PicParams p) {
     }
 }
 
-void launch_hme(const PicParams &p, hipStream_t s) {
+void launch_hme(const PicParams &p, hipStream_t s, hipEvent_t marks[2]) {
     // Every search of the picture at once, unless a reference depends on an earlier one's result (or the full-SAD
     // HME of temporal filtering is asked for): then one workgroup per b64 walks the references in order.
     if (!p.serial_refs && p.ctrl.hme_search_method == 0) {
-        launch_hme_items(p, s);
+        launch_hme_items(p, s, marks);
         return;
     }
     const int n_refs = p.n_ref[0] + (p.n_list == 2 ? p.n_ref[1] : 0);
     dim3      grid(p.b64_w * p.b64_h, p.serial_refs ? 1 : n_refs);
     (void)hipMemsetAsync(p.hme_out, 0, (size_t)grid.x * SVTME_MAX_LISTS * SVTME_MAX_REFS * sizeof(HmeRefOut), s);
     hipLaunchKernelGGL(hme_kernel, grid, dim3(HME_THREADS), HME_WIN_BYTES + 64, s, p);
+    (void)hipEventRecord(marks[0], s);
+    (void)hipEventRecord(marks[1], s);
 }
 
 } // namespace svtme

@@ -249,7 +249,9 @@ __global__ void __launch_bounds__(ME_THREADS, 3) me_search_kernel(PicParams p) {
     const int tid = threadIdx.x;
     const int b64 = blockIdx.x;
     const int b64x = (b64 % p.b64_w) * 64, b64y = (b64 / p.b64_w) * 64;
-    int       my_l = 0, my_r = blockIdx.y;
+    // references in reverse order: the closest references (smallest windows, cheapest items) are dispatched last and
+    // keep the kernel's tail short
+    int       my_l = 0, my_r = (int)(gridDim.z - 1 - blockIdx.z);
     if (my_r >= p.n_ref[0]) {
         my_r -= p.n_ref[0];
         my_l = 1;
@@ -260,8 +262,8 @@ __global__ void __launch_bounds__(ME_THREADS, 3) me_search_kernel(PicParams p) {
     if (w <= 0) return;
     // ---- this item: one group of 8 search rows of one 64-position column chunk = up to 16 runs (4 positions x 8 rows)
     const int n_yg = (h + 7) >> 3;
-    if ((int)blockIdx.z >= me_item_count(w, h)) return;
-    const int chunk = blockIdx.z / n_yg, yg0 = blockIdx.z - chunk * n_yg;
+    if ((int)blockIdx.y >= me_item_count(w, h)) return;
+    const int chunk = blockIdx.y / n_yg, yg0 = blockIdx.y - chunk * n_yg;
     const int tx0 = chunk * ME_TILE, n_xg = (min(ME_TILE, w - tx0) + 3) >> 2;
     const int ty0 = yg0 * 8, rows = min(h - ty0, 8); // search rows staged for this item
     const int r0 = 0, r1 = n_xg;
@@ -512,12 +514,22 @@ __global__ void __launch_bounds__(256) me_finish_kernel(PicParams p) {
     p.best_mv[i]  = mv;
 }
 
-void launch_me(const PicParams &p, hipStream_t s) {
+void launch_me(const PicParams &p, hipStream_t s, hipEvent_t marks[3]) {
     const int n_refs = p.n_ref[0] + (p.n_list == 2 ? p.n_ref[1] : 0);
     const int n_b64  = p.b64_w * p.b64_h;
     hipLaunchKernelGGL(me_plan_kernel, dim3(n_b64, n_refs), dim3(ME_THREADS), 0, s, p);
-    hipLaunchKernelGGL(me_search_kernel, dim3(n_b64, n_refs, p.me_max_items), dim3(ME_THREADS), 0, s, p);
+    (void)hipEventRecord(marks[0], s);
+    hipLaunchKernelGGL(me_search_kernel, dim3(n_b64, p.me_max_items, n_refs), dim3(ME_THREADS), 0, s, p);
+    (void)hipEventRecord(marks[1], s);
     hipLaunchKernelGGL(me_finish_kernel, dim3((n_b64 * 8 * SVTME_PU_COUNT + 255) / 256), dim3(256), 0, s, p);
+    (void)hipEventRecord(marks[2], s);
+}
+
+// resident workgroups per CU the runtime expects for the search kernel (diagnostic)
+int occupancy_me_search() {
+    int n = 0;
+    (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, me_search_kernel, ME_THREADS, 0);
+    return n;
 }
 
 } // namespace svtme

@@ -51,27 +51,24 @@ __device__ __forceinline__ uint32_t load_u32_any(const uint8_t *p) {
     return __builtin_amdgcn_alignbyte(hi, lo, (uint32_t)(a & 3));
 }
 
-// Copies an (n_row x pd dwords) window from a plane (any byte alignment) into LDS rows of pd dwords, whole 64-lane wave.
-// Eight loads are in flight per lane before the first is stored, so a window costs a few memory round trips, not one
-// per 64 dwords.
+// Copies an (n_row x pd dwords) window from a plane (any byte alignment) into LDS rows of pd dwords, whole 64-lane wave;
+// pd <= 32. A lane moves dword (lane % 32) of rows lane / 32, + 2, ... with unaligned 4-byte loads; eight rows' loads
+// are in flight per lane before the first is stored, so a window costs a few memory round trips.
 __device__ __forceinline__ void stage_window(uint32_t *win, const uint8_t *g, int stride, int pd, int n_row) {
-    const int n    = n_row * pd;
-    const int lane = threadIdx.x & 63;
-    for (int base = 0; base < n; base += 64 * 8) {
+    const int lane = threadIdx.x & 63, d = lane & 31;
+    if (d >= pd) return;
+    const uint8_t *src = g + (ptrdiff_t)(lane >> 5) * stride + 4 * d;
+    uint32_t      *dst = win + (lane >> 5) * pd + d;
+    for (int r = lane >> 5; r < n_row; r += 16) {
         uint32_t v[8];
 #pragma unroll
-        for (int k = 0; k < 8; ++k) {
-            const int i = base + k * 64 + lane;
-            if (i < n) {
-                const int r = i / pd, d = i - r * pd;
-                __builtin_memcpy(&v[k], g + (ptrdiff_t)r * stride + 4 * d, 4);
-            }
-        }
+        for (int k = 0; k < 8; ++k)
+            if (r + 2 * k < n_row) __builtin_memcpy(&v[k], src + (ptrdiff_t)(2 * k) * stride, 4);
 #pragma unroll
-        for (int k = 0; k < 8; ++k) {
-            const int i = base + k * 64 + lane;
-            if (i < n) win[i] = v[k];
-        }
+        for (int k = 0; k < 8; ++k)
+            if (r + 2 * k < n_row) dst[2 * k * pd] = v[k];
+        src += (ptrdiff_t)16 * stride;
+        dst += 16 * pd;
     }
 }
 

@@ -81,8 +81,12 @@ constexpr int SVTME_OPS_BYTES = SVTME_OPS_SLOTS * 8 * 8;
 // store kernels (store_kernels.hip)
 void launch_store_build(const uint8_t *luma, int luma_stride, const DevPicture &pic, int hme_level1, hipStream_t s);
 // search kernels
-void launch_hme(const PicParams &p, hipStream_t s); // picks the serial or the itemised kernels
-void launch_hme_items(const PicParams &p, hipStream_t s);
-void launch_me(const PicParams &p, hipStream_t s);
+// Each launcher records marks[i] on the stream after its i-th kernel (timing only).
+void launch_hme(const PicParams &p, hipStream_t s, hipEvent_t marks[2]); // picks the serial or the itemised kernels
+void launch_hme_items(const PicParams &p, hipStream_t s, hipEvent_t marks[2]);
+void launch_me(const PicParams &p, hipStream_t s, hipEvent_t marks[3]);
+
+int  occupancy_me_search();
+void occupancy_hme_items(int out[2]);
 
 } // namespace svtme

@@ -116,7 +116,7 @@ def load_library():
     lib.svtme_picture_submit.argtypes = [C.c_void_p, C.POINTER(Picture), C.POINTER(C.c_uint64)]
     lib.svtme_picture_wait.argtypes = [C.c_void_p, C.c_uint64, C.POINTER(Results)]
     lib.svtme_picture_done.argtypes = [C.c_void_p, C.c_uint64]
-    lib.svtme_picture_timing.argtypes = [C.c_void_p, C.c_uint64, C.POINTER(C.c_float * 3)]
+    lib.svtme_picture_timing.argtypes = [C.c_void_p, C.c_uint64, C.POINTER(C.c_float * 8)]
     lib.svtme_picture_ops.argtypes = [C.c_void_p, C.c_uint64, C.POINTER(C.c_uint64 * 6)]
     lib.svtme_unpack_b64.argtypes = [C.POINTER(Results), C.c_uint32] + [C.c_void_p] * 5
     _lib = lib
@@ -225,7 +225,7 @@ class Engine:
         return out
 
     def timing(self, ticket):
-        ms = (C.c_float * 3)()
+        ms = (C.c_float * 8)()
         rc = self.lib.svtme_picture_timing(self.h, ticket, C.byref(ms))
         if rc:
             raise SvtmeError(rc, "svtme_picture_timing")
