@@ -120,6 +120,8 @@ typedef struct svtme_config {
     uint32_t max_height;
     uint32_t store_slots; /* capacity of the device picture store (>= references + pictures in flight) */
     uint32_t max_in_flight; /* pictures submitted but not yet waited for */
+    uint32_t search_streams; /* 0 = default (2): pictures alternate between this many HIP streams, so that one
+                                picture's kernel tails overlap another's kernels; 1 runs pictures back to back */
 } svtme_config;
 
 /* Replaces nothing in the reference (the reference has no device): engine life cycle. */

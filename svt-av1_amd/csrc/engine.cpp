@@ -1,7 +1,8 @@
 // engine.cpp - host side of the engine: device picture store, picture queue, C ABI (include/svtme.h).
 //
-// Two HIP streams: `s_store` carries the uploads and the store-building kernels, `s_me` the search kernels and
-// the result copies. A picture waits (on the device, through events) for the store slots it reads; a slot that is
+// HIP streams: `s_store` carries the uploads and the store-building kernels, the `s_me` pair the search kernels
+// (pictures alternate between the two, so one picture's kernel tails overlap the other's kernels), `s_copy` the
+// result copies. A picture waits (on the device, through events) for the store slots it reads; a slot that is
 // rewritten waits for the last picture that read it. Nothing here blocks the host except svtme_picture_wait.
 #include <hip/hip_runtime.h>
 
@@ -40,8 +41,8 @@ struct Slot {
     uint8_t   *mem = nullptr; // device
     uint8_t   *host_stage = nullptr; // pinned
     hipEvent_t ready = nullptr; // planes built (recorded on s_store)
-    hipEvent_t last_read = nullptr; // last search kernel that read the planes (recorded on s_me)
-    bool       read_recorded = false;
+    hipEvent_t last_read[2] = {nullptr, nullptr}; // last search kernels that read the planes, per search stream
+    bool       read_recorded[2] = {false, false};
 };
 
 struct Flight {
@@ -75,7 +76,8 @@ struct Flight {
 struct svtme_engine {
     svtme_config        cfg{};
     std::mutex          mu;
-    hipStream_t         s_store = nullptr, s_me = nullptr, s_copy = nullptr;
+    hipStream_t         s_store = nullptr, s_me[2] = {nullptr, nullptr}, s_copy = nullptr;
+    unsigned            next_me = 0;
     std::vector<Slot>   slots;
     std::vector<Flight> flights;
     svtme_ticket        next_ticket = 1;
@@ -129,7 +131,7 @@ extern "C" const char *svtme_version(void) { return "svtme 0.1 (gfx950)"; }
 
 extern "C" int svtme_create(const svtme_config *cfg, svtme_engine **out) {
     if (!cfg || !out || cfg->max_width < 64 || cfg->max_height < 64 || cfg->max_width % 8 || cfg->max_height % 8 ||
-        cfg->max_width > 16384 || cfg->max_height > 16384 || cfg->store_slots < 2 || cfg->max_in_flight < 1)
+        cfg->max_width > 16384 || cfg->max_height > 16384 || cfg->store_slots < 2 || cfg->max_in_flight < 1 || cfg->search_streams > 2)
         return SVTME_ERR_BAD_ARG;
     int n_dev = 0;
     if (hipGetDeviceCount(&n_dev) != hipSuccess || cfg->device < 0 || cfg->device >= n_dev) {
@@ -145,7 +147,8 @@ extern "C" int svtme_create(const svtme_config *cfg, svtme_engine **out) {
         return code;
     };
     if (hipStreamCreateWithFlags(&e->s_store, hipStreamNonBlocking) != hipSuccess ||
-        hipStreamCreateWithFlags(&e->s_me, hipStreamNonBlocking) != hipSuccess ||
+        hipStreamCreateWithFlags(&e->s_me[0], hipStreamNonBlocking) != hipSuccess ||
+        hipStreamCreateWithFlags(&e->s_me[1], hipStreamNonBlocking) != hipSuccess ||
         hipStreamCreateWithFlags(&e->s_copy, hipStreamNonBlocking) != hipSuccess)
         return fail(SVTME_ERR_DEVICE);
     DevPicture tmp;
@@ -156,7 +159,8 @@ extern "C" int svtme_create(const svtme_config *cfg, svtme_engine **out) {
         if (hipMalloc((void **)&s.mem, e->slot_bytes) != hipSuccess ||
             hipHostMalloc((void **)&s.host_stage, (size_t)cfg->max_width * cfg->max_height, hipHostMallocDefault) != hipSuccess ||
             hipEventCreateWithFlags(&s.ready, hipEventDisableTiming) != hipSuccess ||
-            hipEventCreateWithFlags(&s.last_read, hipEventDisableTiming) != hipSuccess)
+            hipEventCreateWithFlags(&s.last_read[0], hipEventDisableTiming) != hipSuccess ||
+            hipEventCreateWithFlags(&s.last_read[1], hipEventDisableTiming) != hipSuccess)
             return fail(SVTME_ERR_NO_RESOURCES);
     }
     e->flights.resize(cfg->max_in_flight);
@@ -178,17 +182,20 @@ extern "C" int svtme_create(const svtme_config *cfg, svtme_engine **out) {
 extern "C" void svtme_destroy(svtme_engine *e) {
     if (!e) return;
     (void)hipSetDevice(e->cfg.device);
-    if (e->s_me) (void)hipStreamSynchronize(e->s_me);
+    for (auto sm : e->s_me)
+        if (sm) (void)hipStreamSynchronize(sm);
     if (e->s_copy) (void)hipStreamSynchronize(e->s_copy);
     if (e->s_store) (void)hipStreamSynchronize(e->s_store);
     for (auto &s : e->slots) {
         if (s.mem) (void)hipFree(s.mem);
         if (s.host_stage) (void)hipHostFree(s.host_stage);
         if (s.ready) (void)hipEventDestroy(s.ready);
-        if (s.last_read) (void)hipEventDestroy(s.last_read);
+        for (auto ev : s.last_read)
+            if (ev) (void)hipEventDestroy(ev);
     }
     for (auto &f : e->flights) free_flight(f);
-    if (e->s_me) (void)hipStreamDestroy(e->s_me);
+    for (auto sm : e->s_me)
+        if (sm) (void)hipStreamDestroy(sm);
     if (e->s_store) (void)hipStreamDestroy(e->s_store);
     if (e->s_copy) (void)hipStreamDestroy(e->s_copy);
     delete e;
@@ -211,7 +218,8 @@ extern "C" int svtme_store_put(svtme_engine *e, uint64_t key, uint64_t picture_n
         if (si < 0) return SVTME_ERR_NO_RESOURCES;
     }
     Slot &s = e->slots[si];
-    if (s.used && s.read_recorded) HIP_TRY(hipStreamWaitEvent(e->s_store, s.last_read, 0)); // rewrite after the readers
+    for (int m = 0; m < 2; ++m) // rewrite after the readers
+        if (s.used && s.read_recorded[m]) HIP_TRY(hipStreamWaitEvent(e->s_store, s.last_read[m], 0));
     if (s.used) HIP_TRY(hipEventSynchronize(s.ready)); // the pinned staging buffer of this slot is free again
     s.used = true;
     s.release_pending = false;
@@ -335,15 +343,17 @@ extern "C" int svtme_picture_submit(svtme_engine *e, const svtme_picture *pic, s
     p.sr_divisor     = reinterpret_cast<uint32_t *>(f->d_res + f->off_div);
     p.ops            = reinterpret_cast<unsigned long long *>(f->d_res + f->off_ops);
 
-    for (int si : used) HIP_TRY(hipStreamWaitEvent(e->s_me, e->slots[si].ready, 0));
-    HIP_TRY(hipEventRecord(f->ev[0], e->s_me));
-    HIP_TRY(hipMemsetAsync(f->d_res + f->off_ops, 0, SVTME_OPS_BYTES, e->s_me));
-    launch_hme(p, e->s_me, &f->ev[1]);
-    launch_me(p, e->s_me, &f->ev[3]);
+    const unsigned    mi = e->cfg.search_streams == 1 ? 0 : (e->next_me++ & 1);
+    const hipStream_t sm = e->s_me[mi];
+    for (int si : used) HIP_TRY(hipStreamWaitEvent(sm, e->slots[si].ready, 0));
+    HIP_TRY(hipEventRecord(f->ev[0], sm));
+    HIP_TRY(hipMemsetAsync(f->d_res + f->off_ops, 0, SVTME_OPS_BYTES, sm));
+    launch_hme(p, sm, &f->ev[1]);
+    launch_me(p, sm, &f->ev[3]);
     HIP_TRY(hipGetLastError());
     for (int si : used) {
-        HIP_TRY(hipEventRecord(e->slots[si].last_read, e->s_me));
-        e->slots[si].read_recorded = true;
+        HIP_TRY(hipEventRecord(e->slots[si].last_read[mi], sm));
+        e->slots[si].read_recorded[mi] = true;
         e->slots[si].readers++;
     }
     // results back to pinned host memory on the copy stream, so that the next picture's kernels do not wait for PCIe

@@ -184,7 +184,7 @@ __device__ u64 l0_search(L0Shared &S, uint32_t *win, const DevPlane &cur, const 
         const int zero = S.zero;
         for (int x0 = 0; x0 < sa_w; x0 += HI_XCHUNK) {
             const int n_xg = (min(HI_XCHUNK, sa_w - x0) + 3) >> 2;
-            const int pd   = (n_xg + 4 + 3) & ~3; // dwords per staged row: the positions + 15 more pixels, in 16-byte pieces
+            const int pd   = n_xg + 4; // dwords per staged row: the positions + 15 more pixels, rounded up
             // rows the LDS budget holds: a band's search rows + 14 rows under the last one + the staggered walk's
             // overrun (rows that are addressed but never used)
             const int cap  = HI_WIN_BYTES / (4 * pd);
@@ -193,7 +193,7 @@ __device__ u64 l0_search(L0Shared &S, uint32_t *win, const DevPlane &cur, const 
             for (int y0 = 0; y0 < sa_h; y0 += band) {
                 const int brows = min(band, sa_h - y0);
                 __syncthreads();
-                stage_window(win, ref.pix + (ptrdiff_t)(wy + y0) * ref.stride + wx + x0, ref.stride, pd, brows + 14);
+                stage_window<16>(win, ref.pix + (ptrdiff_t)(wy + y0) * ref.stride + wx + x0, ref.stride, pd, brows + 14);
                 __syncthreads();
                 // rows per unit: as many as still give every lane a unit
                 const int cells = n_xg * ((brows + 1) >> 1); // position quads x row pairs
@@ -285,34 +285,50 @@ __global__ void __launch_bounds__(HI_THREADS, 3) hme_l0_kernel(PicParams p) {
 // ---------------------------------------------------------------------------------------------------------------------
 struct L12Shared {
     u64      key;
-    uint32_t src[32 * 16];
+    uint32_t src1[16 * 16]; // sampled rows of the quarter-resolution 32x32 block, 16 dwords apart
+    uint32_t src2[32 * 16]; // sampled rows of the full-resolution 64x64 block
 };
 
-// Exhaustive search of a small window with a large block: position quads x block-row chunks over the lanes.
-// bw: block width in pixels (multiple of 4 at these levels), rows: sampled rows, 2 plane rows apart.
-__device__ u64 small_search(L12Shared &S, uint32_t *win, const DevPlane &cur, const DevPlane &ref, int ox, int oy, int bw, int rows, int wx,
-                            int wy, int sa_w, int sa_h) {
+// Exhaustive search of a small window with a large block whose sampled rows are staged at `src` (16 dwords per row):
+// position quads x block-row chunks over the lanes. bw: block width in pixels (multiple of 4 at these levels),
+// rows: sampled rows, 2 plane rows apart.
+// Sampled rows (2 plane rows apart) of the bw x rows block at (ox, oy) -> dst, 16 dwords per row. Issues its loads and
+// stores without waiting: the caller's next barrier orders them.
+__device__ __forceinline__ void stage_block(uint32_t *dst, const DevPlane &cur, int ox, int oy, int bw, int rows) {
+    const int bwd = bw >> 2, lane = threadIdx.x & 63, d = lane & 15;
+    if (d >= bwd) return;
+    uint32_t v[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        const int r = (lane >> 4) + 4 * k;
+        if (r < rows) v[k] = *reinterpret_cast<const uint32_t *>(cur.pix + (ptrdiff_t)(oy + 2 * r) * cur.stride + ox + 4 * d);
+    }
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        const int r = (lane >> 4) + 4 * k;
+        if (r < rows) dst[r * 16 + d] = v[k];
+    }
+}
+
+__device__ u64 small_search(L12Shared &S, const uint32_t *src, uint32_t *win, const DevPlane &ref, int bw, int rows, int wx, int wy,
+                            int sa_w, int sa_h) {
     const int lane = threadIdx.x;
     u64       best = ~0ull;
     if (sa_w <= 0 || sa_h <= 0 || rows <= 0) return best;
     const int bwd = bw >> 2;
     __syncthreads();
-    for (int i = lane; i < rows * bwd; i += HI_THREADS) {
-        const int r = i / bwd, d = i - r * bwd;
-        S.src[r * 16 + d] = *reinterpret_cast<const uint32_t *>(cur.pix + (ptrdiff_t)(oy + 2 * r) * cur.stride + ox + 4 * d);
-    }
     if (lane == 0) S.key = ~0ull;
     const int span       = (rows - 1) * 2 + 1;
     const int chunk_log2 = rows >= 16 ? 3 : (rows >= 4 ? 2 : 0), chunks = 1 << chunk_log2;
     const int rpc        = (rows + chunks - 1) >> chunk_log2; // sampled block rows per lane
-    const int xc         = (32 - bwd) * 4; // positions per staged column chunk: a staged row is at most 32 dwords
+    const int xc         = 64; // positions per staged column chunk
     for (int x0 = 0; x0 < sa_w; x0 += xc) {
-        const int n_xg = (min(xc, sa_w - x0) + 3) >> 2, pd = (n_xg + bwd + 3) & ~3;
+        const int n_xg = (min(xc, sa_w - x0) + 3) >> 2, pd = n_xg + bwd;
         const int band = max(HI_WIN2_BYTES / (4 * pd) - (span - 1), 1);
         for (int y0 = 0; y0 < sa_h; y0 += band) {
             const int brows = min(band, sa_h - y0);
             __syncthreads();
-            stage_window(win, ref.pix + (ptrdiff_t)(wy + y0) * ref.stride + wx + x0, ref.stride, pd, brows + span - 1);
+            stage_window<24>(win, ref.pix + (ptrdiff_t)(wy + y0) * ref.stride + wx + x0, ref.stride, pd, brows + span - 1);
             __syncthreads();
             const int total = (n_xg * brows) << chunk_log2;
             for (int base = 0; base < total; base += HI_THREADS) {
@@ -328,7 +344,7 @@ __device__ u64 small_search(L12Shared &S, uint32_t *win, const DevPlane &cur, co
                     int       px  = 0;
                     for (int j = j0; j < j1; ++j) {
                         const uint32_t *rr = win + (yl + 2 * j) * pd + xg;
-                        const uint32_t *ss = &S.src[j * 16];
+                        const uint32_t *ss = &src[j * 16];
                         if (px + bw > 256) { // keep the packed 16-bit sums below 65536
 #pragma unroll
                             for (int i = 0; i < 4; ++i) a32[i] += (uint32_t)(a16 >> (16 * i)) & 0xFFFFu;
@@ -384,6 +400,9 @@ __global__ void __launch_bounds__(HI_THREADS) hme_l12_kernel(PicParams p) {
     }
     const int q = blockIdx.z, nw = k.num_hme_sa_w, nh = k.num_hme_sa_h;
     if (!ref_searched(p, l) || !k.enable_hme_flag || q >= nw * nh) return;
+    // both levels' source blocks are fetched while the level-0 results arrive
+    if (k.enable_hme_level1_flag) stage_block(S.src1, p.cur.lvl[1], b64x >> 1, b64y >> 1, block_w >> 1, block_h >> 2);
+    if (k.enable_hme_level2_flag) stage_block(S.src2, p.cur.lvl[2], b64x, b64y, block_w, block_h >> 1);
     const int  sw = q % nw, sh = q / nw, i = sw * 2 + sh;
     HmeRefOut *out = &p.hme_out[(b64 * SVTME_MAX_LISTS + l) * SVTME_MAX_REFS + r];
     const bool early = k.me_early_exit_th && out->zz_sad < (k.me_early_exit_th >> 2);
@@ -424,7 +443,6 @@ __global__ void __launch_bounds__(HI_THREADS) hme_l12_kernel(PicParams p) {
             cx = cy = 0;
             continue;
         }
-        const DevPlane &cur   = p.cur.lvl[level];
         const DevPlane &ref   = p.ref[l][r].lvl[level];
         const int       shift = 2 - level;
         const int       ox = b64x >> shift, oy = b64y >> shift;
@@ -442,7 +460,7 @@ __global__ void __launch_bounds__(HI_THREADS) hme_l12_kernel(PicParams p) {
         w = (int16_t)(w < 8 ? w : (w & ~0x07));
         clip_axis(oy, org_y, h, -pad, ref.height);
         if (threadIdx.x == 0) count_ops(p, 2 + level, (unsigned long long)max((int)h, 0) * max((int)w, 0) * rows * bw);
-        const u64 key = small_search(S, win, cur, ref, ox, oy, bw, rows, ox + org_x, oy + org_y, w, h);
+        const u64 key = small_search(S, level == 1 ? S.src1 : S.src2, win, ref, bw, rows, ox + org_x, oy + org_y, w, h);
         uint32_t  sad;
         decode_key(key, w, org_x, org_y, level == 1 ? 2 : 1, cx, cy, sad);
         if (threadIdx.x == 0) {

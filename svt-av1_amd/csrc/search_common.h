@@ -51,24 +51,30 @@ __device__ __forceinline__ uint32_t load_u32_any(const uint8_t *p) {
     return __builtin_amdgcn_alignbyte(hi, lo, (uint32_t)(a & 3));
 }
 
-// Copies an (n_row x pd dwords) window from a plane (any byte alignment) into LDS rows of pd dwords, whole 64-lane wave;
-// pd <= 32. A lane moves dword (lane % 32) of rows lane / 32, + 2, ... with unaligned 4-byte loads; eight rows' loads
-// are in flight per lane before the first is stored, so a window costs a few memory round trips.
+// Copies an (n_row x pd dwords) window from a plane (any byte alignment) into LDS rows of pd dwords, whole 64-lane wave,
+// with unaligned 4-byte loads. Element i = lane + 64 k goes to win[i]; NB loads are in flight per lane before the first
+// is stored, so a window of up to 64 NB dwords costs one memory round trip.
+template <int NB>
 __device__ __forceinline__ void stage_window(uint32_t *win, const uint8_t *g, int stride, int pd, int n_row) {
-    const int lane = threadIdx.x & 63, d = lane & 31;
-    if (d >= pd) return;
-    const uint8_t *src = g + (ptrdiff_t)(lane >> 5) * stride + 4 * d;
-    uint32_t      *dst = win + (lane >> 5) * pd + d;
-    for (int r = lane >> 5; r < n_row; r += 16) {
-        uint32_t v[8];
+    const int n    = n_row * pd;
+    const int lane = threadIdx.x & 63;
+    const int dr = 64 / pd, dd = 64 - dr * pd; // row / dword advance of 64 elements
+    int       r = lane / pd, d = lane - r * pd;
+    for (int base = lane; base < n; base += 64 * NB) {
+        uint32_t v[NB];
 #pragma unroll
-        for (int k = 0; k < 8; ++k)
-            if (r + 2 * k < n_row) __builtin_memcpy(&v[k], src + (ptrdiff_t)(2 * k) * stride, 4);
+        for (int k = 0; k < NB; ++k) {
+            if (base + 64 * k < n) __builtin_memcpy(&v[k], g + (ptrdiff_t)r * stride + 4 * d, 4);
+            r += dr;
+            d += dd;
+            if (d >= pd) {
+                d -= pd;
+                ++r;
+            }
+        }
 #pragma unroll
-        for (int k = 0; k < 8; ++k)
-            if (r + 2 * k < n_row) dst[2 * k * pd] = v[k];
-        src += (ptrdiff_t)16 * stride;
-        dst += 16 * pd;
+        for (int k = 0; k < NB; ++k)
+            if (base + 64 * k < n) win[base + 64 * k] = v[k];
     }
 }
 
