@@ -123,3 +123,49 @@ def canonical(bd, pic, pruning_enabled):
     out["best_sad"] = np.where(m, bd["best_sad"], 0).astype(np.uint32)
     out["best_mv"] = np.where(m, bd["best_mv"], 0).astype(np.uint32)
     return out
+
+
+class OracleEngine:
+    """Stand-in with svtme.Engine's interface whose searches run on the CPU oracle: lets the host-side scheduling
+    logic (sharding, store residency, in-flight queue) run in tests without a GPU. Raises if a picture is submitted
+    while one of its sources is not resident, exactly what the device store would report as NOT_FOUND."""
+
+    def __init__(self, enc_mode, ref_counts, store_slots=64):
+        self.enc_mode, self.ref_counts, self.store_slots = enc_mode, ref_counts, store_slots
+        self.store, self.pending, self.next_ticket = {}, {}, 1
+        self.puts = self.releases = self.max_resident = 0
+
+    def store_put(self, key, picture_number, luma):
+        if key not in self.store and len(self.store) >= self.store_slots:
+            raise RuntimeError("store full")
+        self.store[key] = np.array(luma, np.uint8)
+        self.puts += 1
+        self.max_resident = max(self.max_resident, len(self.store))
+
+    def store_release(self, key):
+        del self.store[key]
+        self.releases += 1
+
+    def make_picture(self, width, height, poc, temporal_layer, is_ref, refs, ctrl):
+        return gop.Picture(poc=poc, temporal_layer=temporal_layer, is_ref=is_ref, refs=[list(refs[0]), list(refs[1])])
+
+    def submit(self, pic):
+        need = [pic.poc] + [r for lst in pic.refs for r in lst]
+        missing = [k for k in need if k not in self.store]
+        if missing:
+            raise KeyError("sources %s not resident" % missing)
+        h, w = self.store[pic.poc].shape
+        frames = np.zeros((max(need) + 1, h, w), np.uint8)
+        for k in need:
+            frames[k] = self.store[k]
+        t = self.next_ticket
+        self.next_ticket += 1
+        self.pending[t] = oracle_handover(frames, [pic], self.enc_mode, self.ref_counts, threads=2)[0]
+        return t
+
+    def wait(self, ticket):
+        bd = self.pending[ticket]
+        return {f: np.array(bd[f]) for f in ("best_sad", "best_mv", "zz_sad", "sr_divisor", "hme_sc_x", "hme_sc_y", "do_ref")}
+
+    def done(self, ticket):
+        del self.pending[ticket]
