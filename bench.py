@@ -163,6 +163,21 @@ def main():
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
     barrier()
+    # host -> device: what putting one new source picture into the store costs (pinned staging copy, H2D, the pad /
+    # decimate kernels); every picture is put once and then read by its own search and by up to 7 later ones
+    upload_pps = None
+    if rank == 0:
+        t1 = time.perf_counter()
+        for rep in range(4):
+            for i in range(n):
+                eng.store_put(i, i, frames[i])
+        step(None)  # the searches wait for the store stream, so this drains the uploads
+        torch.cuda.synchronize()
+        t_put = time.perf_counter() - t1
+        t1 = time.perf_counter()
+        step(None)
+        torch.cuda.synchronize()
+        upload_pps = 4 * n / max(1e-9, t_put - (time.perf_counter() - t1))
     # kernels alone on the GPU: same pictures, one search stream (rank 0 reports them)
     solo = stats
     if rank == 0 and args.search_streams != 1 and args.kernel_steps > 0:
@@ -225,6 +240,7 @@ def main():
             "kernel_ms_in_timed_region": dict(zip(["hme_l0_kernel", "hme_l12_kernel", "me_plan_kernel", "me_search_kernel",
                                                    "me_finish_kernel"], [float(v) for v in ms_shared[:5]])),
             "search_streams": args.search_streams,
+            "store_put_pictures_per_s": upload_pps,
             "ops_by_stage": dict(zip(STAGES, [float(v) for v in ops])),
             "picture_ms_incl_d2h": float(ms[6]),
         }
