@@ -386,19 +386,90 @@ __device__ u64 small_search(L12Shared &S, const uint32_t *src, uint32_t *win, co
     return best;
 }
 
+// small_search for the shape every preset uses at these levels - 8 x (1..3) positions, full-width block of BWD dwords
+// (8: the 32-pixel quarter-resolution block, 16: the 64-pixel full-resolution block) - with everything unrolled:
+// lane = (position quad 0..5) x (8 chunks of BWD / 4 sampled block rows); window staged in one memory round trip.
+template <int BWD>
+__device__ u64 quick_search(L12Shared &S, const uint32_t *src, uint32_t *win, const DevPlane &ref, int rows, int wx, int wy, int sa_h) {
+    constexpr int PD  = BWD + 2; // dwords per staged row: 8 positions + the block width - 1 more pixels, rounded up
+    constexpr int RPC = BWD / 4; // sampled block rows per lane (rows <= 8 RPC); RPC x 4 BWD x 255 fits the 16-bit sums
+    constexpr int NB  = ((3 + 2 * (8 * RPC - 1)) * PD + 63) / 64;
+    const int     lane = threadIdx.x;
+    const int     n = (sa_h + 2 * (rows - 1)) * PD;
+    __syncthreads();
+    if (lane == 0) S.key = ~0ull;
+    {
+        // element i = lane + 64 k of the window; indices past the end repeat the last element (same value, same slot)
+        const uint8_t *g = ref.pix + (ptrdiff_t)wy * ref.stride + wx;
+        uint32_t       v[NB];
+#pragma unroll
+        for (int k = 0; k < NB; ++k) {
+            const int i = min(lane + 64 * k, n - 1), r = i / PD, d = i - r * PD;
+            __builtin_memcpy(&v[k], g + (ptrdiff_t)r * ref.stride + 4 * d, 4);
+        }
+#pragma unroll
+        for (int k = 0; k < NB; ++k) win[min(lane + 64 * k, n - 1)] = v[k];
+    }
+    __syncthreads();
+    const int  chunk = lane & 7, q = lane >> 3, xg = q & 1, yl = q >> 1;
+    const bool active = yl < sa_h;
+    u64        a16 = 0;
+    if (active) {
+#pragma unroll
+        for (int jj = 0; jj < RPC; ++jj) {
+            const int j = chunk * RPC + jj;
+            if (j < rows) {
+                const uint32_t *rr = win + (yl + 2 * j) * PD + xg;
+                const uint32_t *ss = src + j * 16;
+                uint32_t        rv[BWD + 1], sv[BWD];
+#pragma unroll
+                for (int d = 0; d <= BWD; ++d) rv[d] = rr[d];
+#pragma unroll
+                for (int d = 0; d < BWD; ++d) sv[d] = ss[d];
+#pragma unroll
+                for (int d = 0; d < BWD; ++d) a16 = __builtin_amdgcn_qsad_pk_u16_u8(((u64)rv[d + 1] << 32) | rv[d], sv[d], a16);
+            }
+        }
+    }
+    uint32_t a32[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        a32[i] = (uint32_t)(a16 >> (16 * i)) & 0xFFFFu;
+        a32[i] += quad_xor1(a32[i]);
+        a32[i] += quad_xor2(a32[i]);
+        a32[i] += __shfl_xor(a32[i], 4);
+    }
+    if (active && chunk == 0) {
+        u64 best = ~0ull;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const u64 kk = ((u64)a32[i] << 32) | (uint32_t)(yl * 8 + xg * 4 + i);
+            best         = kk < best ? kk : best;
+        }
+        atomicMin(&S.key, best);
+    }
+    __syncthreads();
+    const u64 best = S.key;
+    __syncthreads();
+    return best;
+}
+
 __global__ void __launch_bounds__(HI_THREADS) hme_l12_kernel(PicParams p) {
     __shared__ L12Shared              S;
     __shared__ __align__(16) uint32_t win[HI_WIN2_BYTES / 4 + 64];
     const svtme_controls &k   = p.ctrl;
-    const int             b64 = blockIdx.x;
+    const int             nw = k.num_hme_sa_w, nh = k.num_hme_sa_h;
+    const int             n_refs = p.n_ref[0] + (p.n_list == 2 ? p.n_ref[1] : 0);
+    int                   b64, item;
+    if (!b64_major_item(blockIdx.x, p.b64_w * p.b64_h, n_refs * nw * nh, b64, item)) return;
     const int             b64x = (b64 % p.b64_w) * 64, b64y = (b64 / p.b64_w) * 64;
     const int             block_w = min(p.width - b64x, 64), block_h = min(p.height - b64y, 64);
-    int                   l = 0, r = blockIdx.y;
+    int                   l = 0, r = item / (nw * nh);
+    const int             q = item - r * (nw * nh);
     if (r >= p.n_ref[0]) {
         r -= p.n_ref[0];
         l = 1;
     }
-    const int q = blockIdx.z, nw = k.num_hme_sa_w, nh = k.num_hme_sa_h;
     if (!ref_searched(p, l) || !k.enable_hme_flag || q >= nw * nh) return;
     // both levels' source blocks are fetched while the level-0 results arrive
     if (k.enable_hme_level1_flag) stage_block(S.src1, p.cur.lvl[1], b64x >> 1, b64y >> 1, block_w >> 1, block_h >> 2);
@@ -460,7 +531,12 @@ __global__ void __launch_bounds__(HI_THREADS) hme_l12_kernel(PicParams p) {
         w = (int16_t)(w < 8 ? w : (w & ~0x07));
         clip_axis(oy, org_y, h, -pad, ref.height);
         if (threadIdx.x == 0) count_ops(p, 2 + level, (unsigned long long)max((int)h, 0) * max((int)w, 0) * rows * bw);
-        const u64 key = small_search(S, level == 1 ? S.src1 : S.src2, win, ref, bw, rows, ox + org_x, oy + org_y, w, h);
+        u64 key;
+        if (block_w == 64 && w == 8 && h >= 1 && h <= 3)
+            key = level == 1 ? quick_search<8>(S, S.src1, win, ref, rows, ox + org_x, oy + org_y, h)
+                             : quick_search<16>(S, S.src2, win, ref, rows, ox + org_x, oy + org_y, h);
+        else
+            key = small_search(S, level == 1 ? S.src1 : S.src2, win, ref, bw, rows, ox + org_x, oy + org_y, w, h);
         uint32_t  sad;
         decode_key(key, w, org_x, org_y, level == 1 ? 2 : 1, cx, cy, sad);
         if (threadIdx.x == 0) {
@@ -478,7 +554,8 @@ void launch_hme_items(const PicParams &p, hipStream_t s, hipEvent_t marks[2]) {
     (void)hipMemsetAsync(p.hme_out, 0, (size_t)n_b64 * SVTME_MAX_LISTS * SVTME_MAX_REFS * sizeof(HmeRefOut), s);
     hipLaunchKernelGGL(hme_l0_kernel, dim3(n_b64, 2 + max(n_reg, 1), n_refs), dim3(HI_THREADS), 0, s, p);
     (void)hipEventRecord(marks[0], s);
-    if (p.ctrl.enable_hme_flag) hipLaunchKernelGGL(hme_l12_kernel, dim3(n_b64, n_refs, n_reg), dim3(HI_THREADS), 0, s, p);
+    if (p.ctrl.enable_hme_flag)
+        hipLaunchKernelGGL(hme_l12_kernel, dim3((n_b64 + 7) / 8 * 8 * n_refs * n_reg), dim3(HI_THREADS), 0, s, p);
     (void)hipEventRecord(marks[1], s);
 }
 

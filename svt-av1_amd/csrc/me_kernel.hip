@@ -49,10 +49,6 @@ struct MeShared {
 // z-order index of the 16x16 block in raster (row, col): svt_ext_all_sad_calculation_8x8_16x16_c's `offsets` (:366)
 __device__ __forceinline__ int z16(int row, int col) { return ((row >> 1) << 3) | ((col >> 1) << 2) | ((row & 1) << 1) | (col & 1); }
 
-// lane ^ 1 and lane ^ 2 within a quad, as DPP quad_perm moves (no LDS traffic)
-__device__ __forceinline__ uint32_t quad_xor1(uint32_t v) { return (uint32_t)__builtin_amdgcn_mov_dpp((int)v, 0xB1, 0xF, 0xF, true); }
-__device__ __forceinline__ uint32_t quad_xor2(uint32_t v) { return (uint32_t)__builtin_amdgcn_mov_dpp((int)v, 0x4E, 0xF, 0xF, true); }
-
 typedef unsigned short us2 __attribute__((ext_vector_type(2)));
 // v_pk_min_u16 / v_pk_add_u16 on two 16-bit fields
 __device__ __forceinline__ uint32_t pk_min_u16(uint32_t a, uint32_t b) {
@@ -488,9 +484,11 @@ __global__ void __launch_bounds__(ME_THREADS, 3) me_search_kernel(PicParams p) {
     }
     __syncthreads();
     // ---- this item's minima join the window's
+    // (keys only ever decrease, so a plain - possibly stale - read that is already no larger settles it without an atomic)
     for (int pu = tid; pu < SVTME_PU_COUNT; pu += ME_THREADS) {
         const u64 key = S.best[pu];
-        if (key != ~0ull) atomicMin(&p.me_keys[(size_t)(b64 * 8 + my) * SVTME_PU_COUNT + pu], key);
+        u64      *g   = &p.me_keys[(size_t)(b64 * 8 + my) * SVTME_PU_COUNT + pu];
+        if (key != ~0ull && key < *g) atomicMin(g, key);
     }
 }
 

@@ -38,6 +38,22 @@ __device__ __forceinline__ void clip_axis(int o, int16_t &org, int16_t &size, in
     if (o + org + size > dim) size = (int16_t)max(1, size - ((o + org + size) - dim));
 }
 
+// lane ^ 1 and lane ^ 2 within a quad, as DPP quad_perm moves (no LDS traffic)
+__device__ __forceinline__ uint32_t quad_xor1(uint32_t v) { return (uint32_t)__builtin_amdgcn_mov_dpp((int)v, 0xB1, 0xF, 0xF, true); }
+__device__ __forceinline__ uint32_t quad_xor2(uint32_t v) { return (uint32_t)__builtin_amdgcn_mov_dpp((int)v, 0x4E, 0xF, 0xF, true); }
+
+// Workgroup id -> (b64, item) such that all `items_per_b64` items of a b64 are dispatched next to each other and - with
+// workgroups handed to the 8 XCDs round robin - on the same XCD, whose L2 then serves the b64's source block and
+// overlapping reference windows to all of them. The grid holds ceil(n_b64 / 8) * 8 * items_per_b64 workgroups;
+// returns false for the padding ones.
+__device__ __forceinline__ bool b64_major_item(int wg, int n_b64, int items_per_b64, int &b64, int &item) {
+    const int per_group = 8 * items_per_b64;
+    const int group = wg / per_group, rem = wg - group * per_group;
+    item = rem >> 3;
+    b64  = group * 8 + (rem & 7);
+    return b64 < n_b64;
+}
+
 // Adds n to operation counter k of this workgroup's partial-sum slot.
 __device__ __forceinline__ void count_ops(const PicParams &p, int k, unsigned long long n) {
     atomicAdd(&p.ops[((blockIdx.x + 5 * blockIdx.y) & (SVTME_OPS_SLOTS - 1)) * 8 + k], n);
