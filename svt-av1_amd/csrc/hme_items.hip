@@ -88,17 +88,18 @@ __device__ uint32_t slow_sad(const DevPlane &cur, const DevPlane &ref, int ox, i
 }
 
 // The T same-parity rows x 4 columns of every unit of a staged window band, for a 16-pixel-wide block of `rows`
-// sampled rows held in src (wave-uniform). Folds each lane's best (SAD, raster index) into `best`.
-template <int T>
+// sampled rows held in src (wave-uniform); FULL: rows == 8. Folds each lane's best (SAD, raster index) into `best`.
+template <int T, bool FULL>
 __device__ __forceinline__ void strip_units(const uint32_t *win, int pd, int n_xg, int brows, bool skip_even, const uint32_t (&src)[8][4],
                                             int rows, int zero, int y_abs0, int x_abs0, int sa_w, u64 &best) {
     const int lane   = threadIdx.x;
     const int n_yg   = (brows + 2 * T - 1) / (2 * T);
     const int n_unit = n_xg * n_yg * (skip_even ? 1 : 2);
+    const uint32_t xg_magic = div_magic((uint32_t)n_xg);
     for (int ub = 0; ub < n_unit; ub += HI_THREADS) {
         const int  u     = ub + lane;
         const bool valid = u < n_unit;
-        const int  rest  = valid ? u / n_xg : 0;
+        const int  rest  = valid ? (int)__umulhi((uint32_t)u, xg_magic) : 0;
         const int  xg    = valid ? u - rest * n_xg : 0;
         const int  par   = skip_even ? 1 : (rest & 1);
         const int  yg    = skip_even ? rest : rest >> 1;
@@ -121,7 +122,7 @@ __device__ __forceinline__ void strip_units(const uint32_t *win, int pd, int n_x
                 constexpr int t = decltype(t_c)::value;
                 constexpr int m = s - t; // sampled source row of position t at this step
                 if constexpr (m >= 0 && m < 8) {
-                    if (m < rows) {
+                    if (FULL || m < rows) {
                         acc[t] = __builtin_amdgcn_qsad_pk_u16_u8(p01, src[m][0], acc[t]);
                         acc[t] = __builtin_amdgcn_qsad_pk_u16_u8(p12, src[m][1], acc[t]);
                         acc[t] = __builtin_amdgcn_qsad_pk_u16_u8(p23, src[m][2], acc[t]);
@@ -159,7 +160,7 @@ __device__ __forceinline__ void strip_units(const uint32_t *win, int pd, int n_x
 // Exhaustive search of the (bw x rows sampled rows, 2 plane rows apart) block of `cur` at (ox, oy) over the sa_w x sa_h
 // window of `ref` whose first position is plane pixel (wx, wy). Returns min (SAD << 32 | y * sa_w + x), ~0 when no
 // position was evaluated (skip_even with a single row). Whole wave.
-__device__ u64 l0_search(L0Shared &S, uint32_t *win, const DevPlane &cur, const DevPlane &ref, int ox, int oy, int bw, int rows, int wx,
+__device__ __forceinline__ u64 l0_search(L0Shared &S, uint32_t *win, const DevPlane &cur, const DevPlane &ref, int ox, int oy, int bw, int rows, int wx,
                          int wy, int sa_w, int sa_h, bool skip_even) {
     const int lane = threadIdx.x;
     u64       best = ~0ull;
@@ -197,9 +198,16 @@ __device__ u64 l0_search(L0Shared &S, uint32_t *win, const DevPlane &cur, const 
                 __syncthreads();
                 // rows per unit: as many as still give every lane a unit
                 const int cells = n_xg * ((brows + 1) >> 1); // position quads x row pairs
-                if (brows > 8 && cells >= 8 * HI_THREADS) strip_units<8>(win, pd, n_xg, brows, skip_even, src, rows, zero, y0, x0, sa_w, best);
-                else if (brows > 4 && cells >= 4 * HI_THREADS) strip_units<4>(win, pd, n_xg, brows, skip_even, src, rows, zero, y0, x0, sa_w, best);
-                else strip_units<2>(win, pd, n_xg, brows, skip_even, src, rows, zero, y0, x0, sa_w, best);
+                const int t = brows > 8 && cells >= 8 * HI_THREADS ? 8 : (brows > 4 && cells >= 4 * HI_THREADS ? 4 : 2);
+                if (rows == 8) {
+                    if (t == 8) strip_units<8, true>(win, pd, n_xg, brows, skip_even, src, rows, zero, y0, x0, sa_w, best);
+                    else if (t == 4) strip_units<4, true>(win, pd, n_xg, brows, skip_even, src, rows, zero, y0, x0, sa_w, best);
+                    else strip_units<2, true>(win, pd, n_xg, brows, skip_even, src, rows, zero, y0, x0, sa_w, best);
+                } else { // blocks of the picture's bottom edge
+                    if (t == 8) strip_units<8, false>(win, pd, n_xg, brows, skip_even, src, rows, zero, y0, x0, sa_w, best);
+                    else if (t == 4) strip_units<4, false>(win, pd, n_xg, brows, skip_even, src, rows, zero, y0, x0, sa_w, best);
+                    else strip_units<2, false>(win, pd, n_xg, brows, skip_even, src, rows, zero, y0, x0, sa_w, best);
+                }
             }
         }
     }
@@ -247,39 +255,52 @@ __global__ void __launch_bounds__(HI_THREADS, 3) hme_l0_kernel(PicParams p) {
     const int       ox = b64x >> 2, oy = b64y >> 2;
     const int       bw = block_w >> 2, bh = block_h >> 2;
     const int       rows = bh >> 1;
+    // the search this item runs: window (origin relative to the block, size), row skipping, where the result goes
+    int16_t   w = 0, h = 0, org_x = 0, org_y = 0;
+    bool      skip = false;
+    int16_t  *res_x, *res_y;
+    uint32_t *res_sad;
+    int       ops_k;
     if (sub < 2) {
         // pre-HME (prehme_b64 :1773-1823); check_prehme_early_exit :1746-1770 leaves a zero result
         if (!k.prehme_enable || (k.me_early_exit_th && zz < k.me_early_exit_th)) return;
         const svtme_sa_minmax &cfg    = k.prehme_sa_cfg[sub];
         const int              factor = scaled_dist(p.dist[l][r]);
-        int16_t w = (int16_t)(uint16_t)min((uint32_t)cfg.sa_min.width * factor, (uint32_t)cfg.sa_max.width);
-        int16_t h = (int16_t)(uint16_t)min((uint32_t)cfg.sa_min.height * factor, (uint32_t)cfg.sa_max.height);
-        int16_t org_x = (int16_t)-(int16_t)(w >> 1), org_y = (int16_t)-(int16_t)(h >> 1);
+        w     = (int16_t)(uint16_t)min((uint32_t)cfg.sa_min.width * factor, (uint32_t)cfg.sa_max.width);
+        h     = (int16_t)(uint16_t)min((uint32_t)cfg.sa_min.height * factor, (uint32_t)cfg.sa_max.height);
+        org_x = (int16_t)-(int16_t)(w >> 1);
+        org_y = (int16_t)-(int16_t)(h >> 1);
         clip_axis(ox, org_x, w, -(ref.pad - 1), ref.width);
         clip_axis(oy, org_y, h, -(ref.pad - 1), ref.height);
         // svt_sad_loop_kernel_c skips even rows only for 16-wide blocks of height <= 16
-        const bool skip = k.prehme_skip_search_line && bw == 16 && rows <= 16;
-        if (threadIdx.x == 0) count_ops(p, 1, (unsigned long long)max(skip ? h >> 1 : (int)h, 0) * max((int)w, 0) * rows * bw);
-        const u64 key = l0_search(S, win, cur, ref, ox, oy, bw, rows, ox + org_x, oy + org_y, w, h, skip);
-        if (threadIdx.x == 0) decode_key(key, w, org_x, org_y, 4, out->pre_x[sub], out->pre_y[sub], out->pre_sad[sub]);
-        return;
+        skip    = k.prehme_skip_search_line && bw == 16 && rows <= 16;
+        res_x   = &out->pre_x[sub];
+        res_y   = &out->pre_y[sub];
+        res_sad = &out->pre_sad[sub];
+        ops_k   = 1;
+    } else {
+        // level 0 (:1899-2004): a region per item; the early exit leaves zeros
+        const int q = sub - 2, nw = k.num_hme_sa_w, nh = k.num_hme_sa_h;
+        if (!k.enable_hme_flag || !k.enable_hme_level0_flag || q >= nw * nh) return;
+        if (k.me_early_exit_th && zz < (k.me_early_exit_th >> 2)) return;
+        const int sw = q % nw, sh = q / nw, i = sw * 2 + sh;
+        int16_t   sa_w = 0, sa_h = 0;
+        l0_area(p, l, r, sa_w, sa_h);
+        w     = (int16_t)((sa_w + 7) & ~0x07);
+        h     = sa_h;
+        org_x = (int16_t)(-(int16_t)((w * nw) >> 1) + (int16_t)(w * sw));
+        org_y = (int16_t)(-(int16_t)((h * nh) >> 1) + (int16_t)(h * sh));
+        clip_axis(ox, org_x, w, -(ref.pad - 1), ref.width);
+        w = (int16_t)(w < 8 ? w : (w & ~0x07));
+        clip_axis(oy, org_y, h, -(ref.pad - 1), ref.height);
+        res_x   = &out->raw_x[i];
+        res_y   = &out->raw_y[i];
+        res_sad = &out->raw_sad[i];
+        ops_k   = 2;
     }
-    // level 0 (:1899-2004): a region per item; the early exit leaves zeros
-    const int q = sub - 2, nw = k.num_hme_sa_w, nh = k.num_hme_sa_h;
-    if (!k.enable_hme_flag || !k.enable_hme_level0_flag || q >= nw * nh) return;
-    if (k.me_early_exit_th && zz < (k.me_early_exit_th >> 2)) return;
-    const int sw = q % nw, sh = q / nw, i = sw * 2 + sh;
-    int16_t   sa_w = 0, sa_h = 0;
-    l0_area(p, l, r, sa_w, sa_h);
-    int16_t w = (int16_t)((sa_w + 7) & ~0x07), h = sa_h;
-    int16_t org_x = (int16_t)(-(int16_t)((w * nw) >> 1) + (int16_t)(w * sw));
-    int16_t org_y = (int16_t)(-(int16_t)((h * nh) >> 1) + (int16_t)(h * sh));
-    clip_axis(ox, org_x, w, -(ref.pad - 1), ref.width);
-    w = (int16_t)(w < 8 ? w : (w & ~0x07));
-    clip_axis(oy, org_y, h, -(ref.pad - 1), ref.height);
-    if (threadIdx.x == 0) count_ops(p, 2, (unsigned long long)max((int)h, 0) * max((int)w, 0) * rows * bw);
-    const u64 key = l0_search(S, win, cur, ref, ox, oy, bw, rows, ox + org_x, oy + org_y, w, h, false);
-    if (threadIdx.x == 0) decode_key(key, w, org_x, org_y, 4, out->raw_x[i], out->raw_y[i], out->raw_sad[i]);
+    if (threadIdx.x == 0) count_ops(p, ops_k, (unsigned long long)max(skip ? h >> 1 : (int)h, 0) * max((int)w, 0) * rows * bw);
+    const u64 key = l0_search(S, win, cur, ref, ox, oy, bw, rows, ox + org_x, oy + org_y, w, h, skip);
+    if (threadIdx.x == 0) decode_key(key, w, org_x, org_y, 4, *res_x, *res_y, *res_sad);
 }
 
 // ---------------------------------------------------------------------------------------------------------------------

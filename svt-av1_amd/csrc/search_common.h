@@ -67,30 +67,26 @@ __device__ __forceinline__ uint32_t load_u32_any(const uint8_t *p) {
     return __builtin_amdgcn_alignbyte(hi, lo, (uint32_t)(a & 3));
 }
 
+// floor(i / d) = umulhi(i, div_magic(d)) for i * d < 2^32 (here: indices below 2^16, divisors below 2^8)
+__device__ __forceinline__ uint32_t div_magic(uint32_t d) { return (uint32_t)((0x100000000ull + d - 1) / d); }
+
 // Copies an (n_row x pd dwords) window from a plane (any byte alignment) into LDS rows of pd dwords, whole 64-lane wave,
-// with unaligned 4-byte loads. Element i = lane + 64 k goes to win[i]; NB loads are in flight per lane before the first
-// is stored, so a window of up to 64 NB dwords costs one memory round trip.
+// with unaligned 4-byte loads. Element i = lane + 64 k goes to win[i]; indices past the end repeat the last element
+// (same value into the same slot), so nothing branches. NB loads are in flight per lane before the first is stored: a
+// window of up to 64 NB dwords costs one memory round trip.
 template <int NB>
 __device__ __forceinline__ void stage_window(uint32_t *win, const uint8_t *g, int stride, int pd, int n_row) {
-    const int n    = n_row * pd;
-    const int lane = threadIdx.x & 63;
-    const int dr = 64 / pd, dd = 64 - dr * pd; // row / dword advance of 64 elements
-    int       r = lane / pd, d = lane - r * pd;
+    const int      n = n_row * pd, lane = threadIdx.x & 63;
+    const uint32_t magic = div_magic((uint32_t)pd);
     for (int base = lane; base < n; base += 64 * NB) {
         uint32_t v[NB];
 #pragma unroll
         for (int k = 0; k < NB; ++k) {
-            if (base + 64 * k < n) __builtin_memcpy(&v[k], g + (ptrdiff_t)r * stride + 4 * d, 4);
-            r += dr;
-            d += dd;
-            if (d >= pd) {
-                d -= pd;
-                ++r;
-            }
+            const uint32_t i = (uint32_t)min(base + 64 * k, n - 1), r = __umulhi(i, magic), d = i - r * (uint32_t)pd;
+            __builtin_memcpy(&v[k], g + (ptrdiff_t)(int)r * stride + 4 * d, 4);
         }
 #pragma unroll
-        for (int k = 0; k < NB; ++k)
-            if (base + 64 * k < n) win[base + 64 * k] = v[k];
+        for (int k = 0; k < NB; ++k) win[min(base + 64 * k, n - 1)] = v[k];
     }
 }
 
