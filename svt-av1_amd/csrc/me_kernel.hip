@@ -239,7 +239,7 @@ __global__ void __launch_bounds__(ME_THREADS) me_plan_kernel(PicParams p) {
     }
 }
 
-__global__ void __launch_bounds__(ME_THREADS, 3) me_search_kernel(PicParams p) {
+__global__ void __launch_bounds__(ME_THREADS, 2) me_search_kernel(PicParams p) {
     __shared__ MeShared               S;
     __shared__ __align__(16) uint32_t win[ME_WIN_BYTES / 4];
     const int tid = threadIdx.x;
@@ -266,7 +266,6 @@ __global__ void __launch_bounds__(ME_THREADS, 3) me_search_kernel(PicParams p) {
 
     const DevPlane &cur = p.cur.lvl[2];
     const DevPlane &ref = p.ref[my_l][my_r].lvl[2];
-    if (tid == 0) S.zero = 0;
     // ---- open_loop_me_fullpel_search_sblock
     for (int i = tid; i < SVTME_PU_COUNT; i += ME_THREADS) S.best[i] = ~0ull;
     {
@@ -291,18 +290,19 @@ __global__ void __launch_bounds__(ME_THREADS, 3) me_search_kernel(PicParams p) {
                 const uint8_t *g = ref.pix + (ptrdiff_t)(b64y + org_y + ty0 + (tid >> 3)) * ref.stride + (b64x + org_x + tx0 + 16 * d);
                 uint4         *dst = reinterpret_cast<uint4 *>(win) + (tid >> 3) * (ME_PD / 4) + d;
                 if (d < nq) {
-                    // nrow <= 70: at most 9 trips, all loads issued before the first store
+                    // nrow <= 70: at most 9 trips, all loads issued before the first store; trips past the last row
+                    // repeat it (same value into the same slot), so nothing is conditional
                     uint4 v[9];
 #pragma unroll
-                    for (int t = 0; t < 9; ++t)
-                        if ((tid >> 3) + 8 * t < nrow) __builtin_memcpy(&v[t], g + (ptrdiff_t)(8 * t) * ref.stride, 16);
+                    for (int t = 0; t < 9; ++t) {
+                        const int dr = min(8 * t, nrow - 1 - (tid >> 3));
+                        __builtin_memcpy(&v[t], g + (ptrdiff_t)dr * ref.stride, 16);
+                    }
 #pragma unroll
-                    for (int t = 0; t < 9; ++t)
-                        if ((tid >> 3) + 8 * t < nrow) dst[8 * t * (ME_PD / 4)] = v[t];
+                    for (int t = 0; t < 9; ++t) dst[min(8 * t, nrow - 1 - (tid >> 3)) * (ME_PD / 4)] = v[t];
                 }
             }
             __syncthreads();
-            const int opaque_zero = S.zero;
             // few runs: each parity of a run gets its own quad
             const bool split  = r1 - r0 <= ME_THREADS / 8;
             const int  n_unit = split ? 2 * (r1 - r0) : r1 - r0;
@@ -339,10 +339,6 @@ __global__ void __launch_bounds__(ME_THREADS, 3) me_search_kernel(PicParams p) {
                     const int n_pos  = valid ? min(4, max(0, (yb - yfirst + 1) >> 1)) : 0; // same in the 4 lanes of a quad
                     if (__ballot(n_pos > 0) == 0) continue;
                     const uint32_t *wrow = win + yfirst * ME_PD + xg + col * 4;
-                    // The four 8-byte operands of a step overlap by a dword. The odd pairs are read through a second
-                    // pointer the compiler cannot prove equal to the first (+ a zero it only sees at run time), so every
-                    // pair lands in its own aligned register pair straight from LDS instead of being assembled with copies.
-                    const uint32_t *wodd = wrow + 1 + opaque_zero;
                     uint32_t        ypk[4], yrk[4];
 #pragma unroll
                     for (int t = 0; t < 4; ++t) {
@@ -357,15 +353,40 @@ __global__ void __launch_bounds__(ME_THREADS, 3) me_search_kernel(PicParams p) {
                         acc0[t] = acc1[t] = 0;
                         t16[t][0] = t16[t][1] = half[t][0] = half[t][1] = topv[t][0] = topv[t][1] = 0;
                     }
-                    static_for<0, 35>([&](auto s_c) {
-                        constexpr int   s  = decltype(s_c)::value;
-                        const uint32_t *rr = wrow + (2 * s) * ME_PD, *rq = wodd + (2 * s) * ME_PD;
-                        const u64 p01 = ((u64)rr[1] << 32) | rr[0], p12 = ((u64)rq[1] << 32) | rq[0];
-                        const u64 p23 = ((u64)rr[3] << 32) | rr[2], p34 = ((u64)rq[3] << 32) | rq[2];
+                    // Row loads run one step ahead of the arithmetic (sched_barrier keeps them there), so the LDS latency of
+                    // step s + 1 hides under the 16 QSADs of step s. The two dword indices are re-derived through an empty
+                    // asm every 4 steps: the compiler then addresses 4 steps' rows as immediates off one register instead
+                    // of one add per load, and cannot merge the overlapping even / odd pairs into copies.
+                    int      ie = (int)(wrow - win), io = ie + 1;
+                    uint32_t n01[2], n12[2], n23[2], n34[2], nsw[4];
+                    auto     fetch = [&](auto s_c) {
+                        constexpr int s = decltype(s_c)::value;
+                        if constexpr ((s & 3) == 0) {
+                            if constexpr (s > 0) {
+                                ie += 8 * ME_PD;
+                                io += 8 * ME_PD;
+                            }
+                            asm volatile("" : "+v"(ie));
+                            asm volatile("" : "+v"(io));
+                        }
+                        constexpr int c = (s & 3) * 2 * ME_PD;
+                        n01[0] = win[ie + c], n01[1] = win[ie + c + 1];
+                        n12[0] = win[io + c], n12[1] = win[io + c + 1];
+                        n23[0] = win[ie + c + 2], n23[1] = win[ie + c + 3];
+                        n34[0] = win[io + c + 2], n34[1] = win[io + c + 3];
                         if constexpr (s < 32) {
                             const uint4 v = *reinterpret_cast<const uint4 *>(sbase + s * 16);
-                            sw[s & 3][0] = v.x, sw[s & 3][1] = v.y, sw[s & 3][2] = v.z, sw[s & 3][3] = v.w;
+                            nsw[0] = v.x, nsw[1] = v.y, nsw[2] = v.z, nsw[3] = v.w;
                         }
+                    };
+                    fetch(std::integral_constant<int, 0>{});
+                    static_for<0, 35>([&](auto s_c) {
+                        constexpr int s = decltype(s_c)::value;
+                        const u64 p01 = ((u64)n01[1] << 32) | n01[0], p12 = ((u64)n12[1] << 32) | n12[0];
+                        const u64 p23 = ((u64)n23[1] << 32) | n23[0], p34 = ((u64)n34[1] << 32) | n34[0];
+                        if constexpr (s < 32) sw[s & 3][0] = nsw[0], sw[s & 3][1] = nsw[1], sw[s & 3][2] = nsw[2], sw[s & 3][3] = nsw[3];
+                        if constexpr (s + 1 < 35) fetch(std::integral_constant<int, s + 1>{});
+                        __builtin_amdgcn_sched_barrier(0);
                         static_for<0, 4>([&](auto t_c) {
                             constexpr int t = decltype(t_c)::value;
                             constexpr int m = s - t; // sampled source row (source row 2m) of position t at this step
@@ -429,26 +450,32 @@ __global__ void __launch_bounds__(ME_THREADS, 3) me_search_kernel(PicParams p) {
                 }
                 // merge this lane's minima into the workgroup keys: (SAD << 32) | (y << 16) | x, window-relative.
                 // Within the lane the 4 positions differ in x only, so the first minimum wins ties.
-                if (valid && ya < yb) {
+                if (valid && ya + par0 < yb) { // (a quad that was given only the odd rows of a one-row group has nothing)
                     const uint32_t ybase = (uint32_t)(ty0 + ya), xbase = (uint32_t)(tx0 + xg * 4);
-                    // positions at or beyond the window's right edge (widths below 8 only) never win
-                    uint32_t xoff[4];
+                    // 8x8: min over the 4 columns of key16 << 2 | column (first column wins ties); windows narrower
+                    // than 8 have columns past their right edge, which must not win
+                    const bool     narrow = w < 8;
+                    uint32_t       xoff[4];
 #pragma unroll
-                    for (int i = 0; i < 4; ++i) xoff[i] = (int)(xbase + i) < w ? 0u : 0xFFFFFFFFu;
+                    for (int i = 0; i < 4; ++i) xoff[i] = narrow && (int)(xbase + i) >= w ? 0xFFFFFFFFu : 0u;
 #pragma unroll
                     for (int by = 0; by < 8; ++by)
 #pragma unroll
                         for (int c = 0; c < 2; ++c) {
-                            uint32_t kk[4], best, idx;
-                            kk[0] = (b8[by][c][0] & 0xFFFFu) | xoff[0];
-                            kk[1] = (b8[by][c][0] >> 16) | xoff[1];
-                            kk[2] = (b8[by][c][1] & 0xFFFFu) | xoff[2];
-                            kk[3] = (b8[by][c][1] >> 16) | xoff[3];
-                            min4(kk, best, idx);
-                            const u64 key = ((u64)(best >> 3) << 32) | ((ybase + (best & 7)) << 16) | (xbase + idx);
+                            const uint32_t d0 = b8[by][c][0], d1 = b8[by][c][1];
+                            uint32_t       k0 = (d0 & 0xFFFFu) << 2, k1 = ((d0 >> 16) << 2) | 1u;
+                            uint32_t       k2 = ((d1 & 0xFFFFu) << 2) | 2u, k3 = ((d1 >> 16) << 2) | 3u;
+                            if (narrow) {
+                                k0 |= xoff[0];
+                                k1 |= xoff[1];
+                                k2 |= xoff[2];
+                                k3 |= xoff[3];
+                            }
+                            const uint32_t best = min(min(k0, k1), min(k2, k3));
+                            const u64 key = ((u64)(best >> 5) << 32) | ((ybase + ((best >> 2) & 7)) << 16) | (xbase + (best & 3));
                             const int bx8 = col * 2 + c; // 8x8 block column
                             const int pu  = 21 + z16(by >> 1, bx8 >> 1) * 4 + ((by & 1) << 1) + (bx8 & 1);
-                            atomicMin(&S.best[pu], best == 0xFFFFFFFFu ? ~0ull : key);
+                            atomicMin(&S.best[pu], key);
                         }
 #pragma unroll
                     for (int a = 0; a < 4; ++a) {
@@ -457,7 +484,7 @@ __global__ void __launch_bounds__(ME_THREADS, 3) me_search_kernel(PicParams p) {
                         for (int i = 0; i < 4; ++i) kk[i] = b16[a][i] | xoff[i];
                         min4(kk, best, idx);
                         const u64 key = ((u64)(best >> 16) << 32) | ((ybase + (best & 7)) << 16) | (xbase + idx);
-                        atomicMin(&S.best[5 + z16(a, col)], best == 0xFFFFFFFFu ? ~0ull : key);
+                        atomicMin(&S.best[5 + z16(a, col)], key);
                     }
                     if ((col & 1) == 0) {
 #pragma unroll
@@ -467,7 +494,7 @@ __global__ void __launch_bounds__(ME_THREADS, 3) me_search_kernel(PicParams p) {
                             for (int i = 0; i < 4; ++i) kk[i] = b32[a][i] | xoff[i];
                             min4(kk, best, idx);
                             const u64 key = ((u64)(best >> 3) << 32) | ((ybase + (best & 7)) << 16) | (xbase + idx);
-                            atomicMin(&S.best[1 + a * 2 + (col >> 1)], best == 0xFFFFFFFFu ? ~0ull : key);
+                            atomicMin(&S.best[1 + a * 2 + (col >> 1)], key);
                         }
                     }
                     if (col == 0) {
@@ -476,7 +503,7 @@ __global__ void __launch_bounds__(ME_THREADS, 3) me_search_kernel(PicParams p) {
                         for (int i = 0; i < 4; ++i) kk[i] = b64k[i] | xoff[i];
                         min4(kk, best, idx);
                         const u64 key = ((u64)(best >> 3) << 32) | ((ybase + (best & 7)) << 16) | (xbase + idx);
-                        atomicMin(&S.best[0], best == 0xFFFFFFFFu ? ~0ull : key);
+                        atomicMin(&S.best[0], key);
                     }
                 }
             }
