@@ -99,7 +99,7 @@ __device__ __forceinline__ void strip_units(const uint32_t *win, int pd, int n_x
     for (int ub = 0; ub < n_unit; ub += HI_THREADS) {
         const int  u     = ub + lane;
         const bool valid = u < n_unit;
-        const int  rest  = valid ? (int)__umulhi((uint32_t)u, xg_magic) : 0;
+        const int  rest  = valid ? (int)magic_div((uint32_t)u, (uint32_t)n_xg, xg_magic) : 0;
         const int  xg    = valid ? u - rest * n_xg : 0;
         const int  par   = skip_even ? 1 : (rest & 1);
         const int  yg    = skip_even ? rest : rest >> 1;
@@ -112,12 +112,21 @@ __device__ __forceinline__ void strip_units(const uint32_t *win, int pd, int n_x
         u64             acc[T];
 #pragma unroll
         for (int t = 0; t < T; ++t) acc[t] = 0;
-        static_for<0, T + 7>([&](auto s_c) {
-            constexpr int s   = decltype(s_c)::value;
-            const u64     p01 = ((u64)rr[1] << 32) | rr[0], p12 = ((u64)rq[1] << 32) | rq[0];
-            const u64     p23 = ((u64)rr[3] << 32) | rr[2], p34 = ((u64)rq[3] << 32) | rq[2];
+        // row loads run one step ahead of the arithmetic (sched_barrier keeps them there)
+        uint32_t n01[2], n12[2], n23[2], n34[2];
+        auto     fetch = [&]() {
+            n01[0] = rr[0], n01[1] = rr[1], n23[0] = rr[2], n23[1] = rr[3];
+            n12[0] = rq[0], n12[1] = rq[1], n34[0] = rq[2], n34[1] = rq[3];
             rr += 2 * pd;
             rq += 2 * pd;
+        };
+        fetch();
+        static_for<0, T + 7>([&](auto s_c) {
+            constexpr int s   = decltype(s_c)::value;
+            const u64     p01 = ((u64)n01[1] << 32) | n01[0], p12 = ((u64)n12[1] << 32) | n12[0];
+            const u64     p23 = ((u64)n23[1] << 32) | n23[0], p34 = ((u64)n34[1] << 32) | n34[0];
+            if constexpr (s + 1 < T + 7) fetch();
+            __builtin_amdgcn_sched_barrier(0);
             static_for<0, T>([&](auto t_c) {
                 constexpr int t = decltype(t_c)::value;
                 constexpr int m = s - t; // sampled source row of position t at this step
@@ -185,7 +194,7 @@ __device__ __forceinline__ u64 l0_search(L0Shared &S, uint32_t *win, const DevPl
         const int zero = S.zero;
         for (int x0 = 0; x0 < sa_w; x0 += HI_XCHUNK) {
             const int n_xg = (min(HI_XCHUNK, sa_w - x0) + 3) >> 2;
-            const int pd   = n_xg + 4; // dwords per staged row: the positions + 15 more pixels, rounded up
+            const int pd   = (n_xg + 4 + 3) & ~3; // dwords per staged row: the positions + 15 more pixels, in 16-byte pieces
             // rows the LDS budget holds: a band's search rows + 14 rows under the last one + the staggered walk's
             // overrun (rows that are addressed but never used)
             const int cap  = HI_WIN_BYTES / (4 * pd);
@@ -194,7 +203,7 @@ __device__ __forceinline__ u64 l0_search(L0Shared &S, uint32_t *win, const DevPl
             for (int y0 = 0; y0 < sa_h; y0 += band) {
                 const int brows = min(band, sa_h - y0);
                 __syncthreads();
-                stage_window<16>(win, ref.pix + (ptrdiff_t)(wy + y0) * ref.stride + wx + x0, ref.stride, pd, brows + 14);
+                stage_window<5>(win, ref.pix + (ptrdiff_t)(wy + y0) * ref.stride + wx + x0, ref.stride, pd, brows + 14);
                 __syncthreads();
                 // rows per unit: as many as still give every lane a unit
                 const int cells = n_xg * ((brows + 1) >> 1); // position quads x row pairs
@@ -344,12 +353,12 @@ __device__ u64 small_search(L12Shared &S, const uint32_t *src, uint32_t *win, co
     const int rpc        = (rows + chunks - 1) >> chunk_log2; // sampled block rows per lane
     const int xc         = 64; // positions per staged column chunk
     for (int x0 = 0; x0 < sa_w; x0 += xc) {
-        const int n_xg = (min(xc, sa_w - x0) + 3) >> 2, pd = n_xg + bwd;
+        const int n_xg = (min(xc, sa_w - x0) + 3) >> 2, pd = (n_xg + bwd + 3) & ~3;
         const int band = max(HI_WIN2_BYTES / (4 * pd) - (span - 1), 1);
         for (int y0 = 0; y0 < sa_h; y0 += band) {
             const int brows = min(band, sa_h - y0);
             __syncthreads();
-            stage_window<24>(win, ref.pix + (ptrdiff_t)(wy + y0) * ref.stride + wx + x0, ref.stride, pd, brows + span - 1);
+            stage_window<6>(win, ref.pix + (ptrdiff_t)(wy + y0) * ref.stride + wx + x0, ref.stride, pd, brows + span - 1);
             __syncthreads();
             const int total = (n_xg * brows) << chunk_log2;
             for (int base = 0; base < total; base += HI_THREADS) {

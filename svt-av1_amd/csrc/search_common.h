@@ -67,26 +67,30 @@ __device__ __forceinline__ uint32_t load_u32_any(const uint8_t *p) {
     return __builtin_amdgcn_alignbyte(hi, lo, (uint32_t)(a & 3));
 }
 
-// floor(i / d) = umulhi(i, div_magic(d)) for i * d < 2^32 (here: indices below 2^16, divisors below 2^8)
+// floor(i / d) = magic_div(i, d, div_magic(d)) for i * d < 2^32 (here: indices below 2^16, divisors below 2^8);
+// d == 1 has no 32-bit magic number
 __device__ __forceinline__ uint32_t div_magic(uint32_t d) { return (uint32_t)((0x100000000ull + d - 1) / d); }
+__device__ __forceinline__ uint32_t magic_div(uint32_t i, uint32_t d, uint32_t magic) { return d == 1 ? i : __umulhi(i, magic); }
 
 // Copies an (n_row x pd dwords) window from a plane (any byte alignment) into LDS rows of pd dwords, whole 64-lane wave,
-// with unaligned 4-byte loads. Element i = lane + 64 k goes to win[i]; indices past the end repeat the last element
-// (same value into the same slot), so nothing branches. NB loads are in flight per lane before the first is stored: a
-// window of up to 64 NB dwords costs one memory round trip.
+// in 16-byte pieces (unaligned 16-byte loads); pd is a multiple of 4 and `win` 16-byte aligned. Piece i = lane + 64 k
+// goes to piece i of the window; indices past the end repeat the last piece (same value into the same slot), so
+// nothing branches. NB loads are in flight per lane before the first is stored: a window of up to 1 KiB x NB costs one
+// memory round trip. Reads pd * 4 bytes per row.
 template <int NB>
 __device__ __forceinline__ void stage_window(uint32_t *win, const uint8_t *g, int stride, int pd, int n_row) {
-    const int      n = n_row * pd, lane = threadIdx.x & 63;
-    const uint32_t magic = div_magic((uint32_t)pd);
+    const int      pr = pd >> 2, n = n_row * pr, lane = threadIdx.x & 63;
+    const uint32_t magic = div_magic((uint32_t)pr);
+    uint4         *dst = reinterpret_cast<uint4 *>(win);
     for (int base = lane; base < n; base += 64 * NB) {
-        uint32_t v[NB];
+        uint4 v[NB];
 #pragma unroll
         for (int k = 0; k < NB; ++k) {
-            const uint32_t i = (uint32_t)min(base + 64 * k, n - 1), r = __umulhi(i, magic), d = i - r * (uint32_t)pd;
-            __builtin_memcpy(&v[k], g + (ptrdiff_t)(int)r * stride + 4 * d, 4);
+            const uint32_t i = (uint32_t)min(base + 64 * k, n - 1), r = magic_div(i, (uint32_t)pr, magic), d = i - r * (uint32_t)pr;
+            __builtin_memcpy(&v[k], g + (ptrdiff_t)(int)r * stride + 16 * d, 16);
         }
 #pragma unroll
-        for (int k = 0; k < NB; ++k) win[min(base + 64 * k, n - 1)] = v[k];
+        for (int k = 0; k < NB; ++k) dst[min(base + 64 * k, n - 1)] = v[k];
     }
 }
 
