@@ -122,6 +122,8 @@ typedef struct svtme_config {
     uint32_t max_in_flight; /* pictures submitted but not yet waited for */
     uint32_t search_streams; /* 0 = default (2): pictures alternate between this many HIP streams, so that one
                                 picture's kernel tails overlap another's kernels; 1 runs pictures back to back */
+    uint32_t kernel_timing; /* 1: record an event after every kernel so that svtme_picture_timing() can report
+                               per-kernel durations (a few extra runtime calls per picture); 0: totals only */
 } svtme_config;
 
 /* Replaces nothing in the reference (the reference has no device): engine life cycle. */
@@ -202,7 +204,8 @@ int svtme_picture_done(svtme_engine *e, svtme_ticket ticket);
 /* Device time of a waited picture's kernels in milliseconds (HIP events on the stream the kernels run on):
  * [0] HME pre-HME + level-0 kernel (or the serial HME kernel), [1] HME level-1/2 kernel, [2] integer-search plan,
  * [3] integer-search kernel, [4] integer-search finish, [5] first kernel start to last kernel end,
- * [6] the same up to the end of the result copy, [7] 0. Diagnostic only. */
+ * [6] the same up to the end of the result copy, [7] 0. [0]..[4] are 0 unless the engine was created with
+ * kernel_timing = 1. Diagnostic only. */
 int svtme_picture_timing(svtme_engine *e, svtme_ticket ticket, float ms[8]);
 
 /* Number of abs-diff-accumulate operations the waited picture's searches performed (after clipping, early exits

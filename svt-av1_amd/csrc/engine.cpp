@@ -43,10 +43,11 @@ struct Slot {
     hipEvent_t ready = nullptr; // planes built (recorded on s_store)
     hipEvent_t last_read[2] = {nullptr, nullptr}; // last search kernels that read the planes, per search stream
     bool       read_recorded[2] = {false, false};
+    bool       ready_seen[2] = {false, false}; // this search stream already waits behind `ready`
 };
 
 struct Flight {
-    bool                 busy = false, waited = false;
+    bool                 busy = false, waited = false, kernel_timing = false;
     svtme_ticket         ticket = 0;
     uint32_t             n_b64 = 0;
     std::vector<int>     slots; // store slots referenced
@@ -131,7 +132,7 @@ extern "C" const char *svtme_version(void) { return "svtme 0.1 (gfx950)"; }
 
 extern "C" int svtme_create(const svtme_config *cfg, svtme_engine **out) {
     if (!cfg || !out || cfg->max_width < 64 || cfg->max_height < 64 || cfg->max_width % 8 || cfg->max_height % 8 ||
-        cfg->max_width > 16384 || cfg->max_height > 16384 || cfg->store_slots < 2 || cfg->max_in_flight < 1 || cfg->search_streams > 2)
+        cfg->max_width > 16384 || cfg->max_height > 16384 || cfg->store_slots < 2 || cfg->max_in_flight < 1 || cfg->search_streams > 2 || cfg->kernel_timing > 1)
         return SVTME_ERR_BAD_ARG;
     int n_dev = 0;
     if (hipGetDeviceCount(&n_dev) != hipSuccess || cfg->device < 0 || cfg->device >= n_dev) {
@@ -167,7 +168,7 @@ extern "C" int svtme_create(const svtme_config *cfg, svtme_engine **out) {
     for (auto &f : e->flights) {
         const size_t n = e->max_b64 * SVTME_MAX_LISTS * SVTME_MAX_REFS;
         f.layout(n);
-        if (hipMalloc((void **)&f.d_hme, n * sizeof(HmeRefOut)) != hipSuccess || hipMalloc((void **)&f.d_res, f.res_bytes) != hipSuccess ||
+        if (hipMalloc((void **)&f.d_hme, n * sizeof(HmeRefOut) + SVTME_OPS_BYTES) != hipSuccess || hipMalloc((void **)&f.d_res, f.res_bytes) != hipSuccess ||
             hipMalloc((void **)&f.d_jobs, n * sizeof(MeJob)) != hipSuccess ||
             hipMalloc((void **)&f.d_keys, n * SVTME_PU_COUNT * sizeof(unsigned long long)) != hipSuccess ||
             hipHostMalloc((void **)&f.h_res, f.res_bytes, hipHostMallocDefault) != hipSuccess)
@@ -235,6 +236,7 @@ extern "C" int svtme_store_put(svtme_engine *e, uint64_t key, uint64_t picture_n
     launch_store_build(f.pix, f.stride, s.pic, 1, e->s_store);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipEventRecord(s.ready, e->s_store));
+    s.ready_seen[0] = s.ready_seen[1] = false;
     return SVTME_OK;
 }
 
@@ -341,15 +343,26 @@ extern "C" int svtme_picture_submit(svtme_engine *e, const svtme_picture *pic, s
     p.search_results = reinterpret_cast<svtme_search_result *>(f->d_res + f->off_sr);
     p.zz_sad         = reinterpret_cast<uint32_t *>(f->d_res + f->off_zz);
     p.sr_divisor     = reinterpret_cast<uint32_t *>(f->d_res + f->off_div);
-    p.ops            = reinterpret_cast<unsigned long long *>(f->d_res + f->off_ops);
+    // the counters sit right behind this picture's HME records, so that one memset clears both
+    const size_t hme_bytes = n_b64 * SVTME_MAX_LISTS * SVTME_MAX_REFS * sizeof(HmeRefOut);
+    p.ops            = reinterpret_cast<unsigned long long *>(reinterpret_cast<uint8_t *>(f->d_hme) + hme_bytes);
+    p.ops_out        = reinterpret_cast<unsigned long long *>(f->d_res + f->off_ops);
 
     const unsigned    mi = e->cfg.search_streams == 1 ? 0 : (e->next_me++ & 1);
     const hipStream_t sm = e->s_me[mi];
-    for (int si : used) HIP_TRY(hipStreamWaitEvent(sm, e->slots[si].ready, 0));
+    for (int si : used)
+        if (!e->slots[si].ready_seen[mi]) { // later pictures on this stream are ordered behind this wait anyway
+            HIP_TRY(hipStreamWaitEvent(sm, e->slots[si].ready, 0));
+            e->slots[si].ready_seen[mi] = true;
+        }
     HIP_TRY(hipEventRecord(f->ev[0], sm));
-    HIP_TRY(hipMemsetAsync(f->d_res + f->off_ops, 0, SVTME_OPS_BYTES, sm));
-    launch_hme(p, sm, &f->ev[1]);
-    launch_me(p, sm, &f->ev[3]);
+    HIP_TRY(hipMemsetAsync(f->d_hme, 0, hme_bytes + SVTME_OPS_BYTES, sm));
+    const bool  kt = e->cfg.kernel_timing != 0;
+    hipEvent_t  hme_marks[2] = {kt ? f->ev[1] : nullptr, kt ? f->ev[2] : nullptr};
+    hipEvent_t  me_marks[3]  = {kt ? f->ev[3] : nullptr, kt ? f->ev[4] : nullptr, f->ev[5]};
+    f->kernel_timing = kt;
+    launch_hme(p, sm, hme_marks);
+    launch_me(p, sm, me_marks);
     HIP_TRY(hipGetLastError());
     for (int si : used) {
         HIP_TRY(hipEventRecord(e->slots[si].last_read[mi], sm));
@@ -426,7 +439,10 @@ extern "C" int svtme_picture_timing(svtme_engine *e, svtme_ticket ticket, float 
     std::lock_guard<std::mutex> lock(e->mu);
     Flight *f = find_flight(e, ticket);
     if (!f || !f->waited) return SVTME_ERR_NOT_FOUND;
-    for (int i = 0; i < 5; ++i) HIP_TRY(hipEventElapsedTime(&ms[i], f->ev[i], f->ev[i + 1]));
+    for (int i = 0; i < 5; ++i) {
+        ms[i] = 0.f;
+        if (f->kernel_timing) HIP_TRY(hipEventElapsedTime(&ms[i], f->ev[i], f->ev[i + 1]));
+    }
     HIP_TRY(hipEventElapsedTime(&ms[5], f->ev[0], f->ev[5]));
     HIP_TRY(hipEventElapsedTime(&ms[6], f->ev[0], f->ev[6]));
     ms[7] = 0.f;

@@ -581,12 +581,11 @@ void launch_hme_items(const PicParams &p, hipStream_t s, hipEvent_t marks[2]) {
     const int n_refs = p.n_ref[0] + (p.n_list == 2 ? p.n_ref[1] : 0);
     const int n_b64  = p.b64_w * p.b64_h;
     const int n_reg  = p.ctrl.num_hme_sa_w * p.ctrl.num_hme_sa_h;
-    (void)hipMemsetAsync(p.hme_out, 0, (size_t)n_b64 * SVTME_MAX_LISTS * SVTME_MAX_REFS * sizeof(HmeRefOut), s);
     hipLaunchKernelGGL(hme_l0_kernel, dim3(n_b64, 2 + max(n_reg, 1), n_refs), dim3(HI_THREADS), 0, s, p);
-    (void)hipEventRecord(marks[0], s);
+    if (marks[0]) (void)hipEventRecord(marks[0], s);
     if (p.ctrl.enable_hme_flag)
         hipLaunchKernelGGL(hme_l12_kernel, dim3((n_b64 + 7) / 8 * 8 * n_refs * n_reg), dim3(HI_THREADS), 0, s, p);
-    (void)hipEventRecord(marks[1], s);
+    if (marks[1]) (void)hipEventRecord(marks[1], s);
 }
 
 // resident workgroups per CU the runtime expects for the two kernels (diagnostic)

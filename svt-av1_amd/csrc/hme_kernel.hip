@@ -491,10 +491,9 @@ void launch_hme(const PicParams &p, hipStream_t s, hipEvent_t marks[2]) {
     }
     const int n_refs = p.n_ref[0] + (p.n_list == 2 ? p.n_ref[1] : 0);
     dim3      grid(p.b64_w * p.b64_h, p.serial_refs ? 1 : n_refs);
-    (void)hipMemsetAsync(p.hme_out, 0, (size_t)grid.x * SVTME_MAX_LISTS * SVTME_MAX_REFS * sizeof(HmeRefOut), s);
     hipLaunchKernelGGL(hme_kernel, grid, dim3(HME_THREADS), HME_WIN_BYTES + 64, s, p);
-    (void)hipEventRecord(marks[0], s);
-    (void)hipEventRecord(marks[1], s);
+    if (marks[0]) (void)hipEventRecord(marks[0], s);
+    if (marks[1]) (void)hipEventRecord(marks[1], s);
 }
 
 } // namespace svtme

@@ -524,6 +524,8 @@ __global__ void __launch_bounds__(ME_THREADS, 2) me_search_kernel(PicParams p) {
 __global__ void __launch_bounds__(256) me_finish_kernel(PicParams p) {
     const int n = p.b64_w * p.b64_h * 8 * SVTME_PU_COUNT;
     const int i = blockIdx.x * 256 + threadIdx.x;
+    if (blockIdx.x == 0)
+        for (int c = threadIdx.x; c < SVTME_OPS_SLOTS * 8; c += 256) p.ops_out[c] = p.ops[c];
     if (i >= n) return;
     const int   j   = i / SVTME_PU_COUNT;
     const MeJob job = p.me_jobs[j];
@@ -543,11 +545,11 @@ void launch_me(const PicParams &p, hipStream_t s, hipEvent_t marks[3]) {
     const int n_refs = p.n_ref[0] + (p.n_list == 2 ? p.n_ref[1] : 0);
     const int n_b64  = p.b64_w * p.b64_h;
     hipLaunchKernelGGL(me_plan_kernel, dim3(n_b64, n_refs), dim3(ME_THREADS), 0, s, p);
-    (void)hipEventRecord(marks[0], s);
+    if (marks[0]) (void)hipEventRecord(marks[0], s);
     hipLaunchKernelGGL(me_search_kernel, dim3(n_b64, p.me_max_items, n_refs), dim3(ME_THREADS), 0, s, p);
-    (void)hipEventRecord(marks[1], s);
+    if (marks[1]) (void)hipEventRecord(marks[1], s);
     hipLaunchKernelGGL(me_finish_kernel, dim3((n_b64 * 8 * SVTME_PU_COUNT + 255) / 256), dim3(256), 0, s, p);
-    (void)hipEventRecord(marks[2], s);
+    if (marks[2]) (void)hipEventRecord(marks[2], s);
 }
 
 // resident workgroups per CU the runtime expects for the search kernel (diagnostic)

@@ -73,6 +73,7 @@ struct PicParams {
     // that the workgroups of a picture do not all hit one address): [0] zero-MV / centre checks, [1] pre-HME,
     // [2..4] HME L0..L2, [5] integer search
     unsigned long long  *ops;
+    unsigned long long  *ops_out; // where me_finish_kernel leaves a copy of the counters for the result transfer
 };
 
 constexpr int SVTME_OPS_SLOTS = 64;
@@ -81,7 +82,8 @@ constexpr int SVTME_OPS_BYTES = SVTME_OPS_SLOTS * 8 * 8;
 // store kernels (store_kernels.hip)
 void launch_store_build(const uint8_t *luma, int luma_stride, const DevPicture &pic, int hme_level1, hipStream_t s);
 // search kernels
-// Each launcher records marks[i] on the stream after its i-th kernel (timing only).
+// Each launcher records marks[i] (when not null) on the stream after its i-th kernel (timing only). The caller has
+// zeroed hme_out and the operation counters.
 void launch_hme(const PicParams &p, hipStream_t s, hipEvent_t marks[2]); // picks the serial or the itemised kernels
 void launch_hme_items(const PicParams &p, hipStream_t s, hipEvent_t marks[2]);
 void launch_me(const PicParams &p, hipStream_t s, hipEvent_t marks[3]);

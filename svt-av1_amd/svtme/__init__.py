@@ -59,7 +59,7 @@ class PresetKey(C.Structure):
 
 class Config(C.Structure):
     _fields_ = [("device", C.c_int32), ("max_width", C.c_uint32), ("max_height", C.c_uint32),
-                ("store_slots", C.c_uint32), ("max_in_flight", C.c_uint32), ("search_streams", C.c_uint32)]
+                ("store_slots", C.c_uint32), ("max_in_flight", C.c_uint32), ("search_streams", C.c_uint32), ("kernel_timing", C.c_uint32)]
 
 
 class Picture(C.Structure):
@@ -139,10 +139,10 @@ def derive_controls(enc_mode, width, height, sc_class1=0, frame_rate=30 << 16):
 class Engine:
     """One engine = one GPU. Pictures are put into the device store once and referenced by key afterwards."""
 
-    def __init__(self, max_width, max_height, store_slots=24, max_in_flight=4, device=0, search_streams=0):
+    def __init__(self, max_width, max_height, store_slots=24, max_in_flight=4, device=0, search_streams=0, kernel_timing=1):
         self.lib = load_library()
         self.h = C.c_void_p()
-        cfg = Config(device, max_width, max_height, store_slots, max_in_flight, search_streams)
+        cfg = Config(device, max_width, max_height, store_slots, max_in_flight, search_streams, kernel_timing)
         rc = self.lib.svtme_create(C.byref(cfg), C.byref(self.h))
         if rc:
             raise SvtmeError(rc, "svtme_create")
