@@ -9,8 +9,8 @@ resident in the device picture store when the timed region starts; results (best
 centres) are copied back to pinned host memory inside the timed region. Pictures are independent, so every rank
 runs its own mini-GOPs (weak scaling, no data-path collective); rank 0 prints one JSON line.
 
-`value` comes from the timed region, in which the engine alternates pictures between two HIP streams (one picture's
-kernel tails overlap the next picture's kernels). Kernel durations measured there include that sharing, so the
+`value` comes from the timed region, in which the engine rotates pictures over three HIP streams (one picture's
+kernel tails overlap the other pictures' kernels). Kernel durations measured there include that sharing, so the
 roofline figures come from a second pass over the same pictures with one search stream (each kernel alone on the
 GPU), timed with the same HIP events on the kernels' stream; the overlapped durations are reported beside them.
 """
@@ -97,7 +97,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--workload", default="1080p_ra_m3", choices=sorted(WORKLOADS))
     ap.add_argument("--in-flight", type=int, default=6)
-    ap.add_argument("--search-streams", type=int, default=2, choices=[1, 2])
+    ap.add_argument("--search-streams", type=int, default=3, choices=[1, 2, 3])
     ap.add_argument("--kernel-steps", type=int, default=8, help="steps of the one-stream pass that times the kernels")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()

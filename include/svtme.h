@@ -120,8 +120,8 @@ typedef struct svtme_config {
     uint32_t max_height;
     uint32_t store_slots; /* capacity of the device picture store (>= references + pictures in flight) */
     uint32_t max_in_flight; /* pictures submitted but not yet waited for */
-    uint32_t search_streams; /* 0 = default (2): pictures alternate between this many HIP streams, so that one
-                                picture's kernel tails overlap another's kernels; 1 runs pictures back to back */
+    uint32_t search_streams; /* 0 = default (3), at most 3: pictures take turns on this many HIP streams, so that one
+                                picture's kernel tails overlap the others' kernels; 1 runs pictures back to back */
     uint32_t kernel_timing; /* 1: record an event after every kernel so that svtme_picture_timing() can report
                                per-kernel durations (a few extra runtime calls per picture); 0: totals only */
 } svtme_config;

@@ -1,8 +1,9 @@
 // engine.cpp - host side of the engine: device picture store, picture queue, C ABI (include/svtme.h).
 //
-// HIP streams: `s_store` carries the uploads and the store-building kernels, the `s_me` pair the search kernels
-// (pictures alternate between the two, so one picture's kernel tails overlap the other's kernels), `s_copy` the
-// result copies. A picture waits (on the device, through events) for the store slots it reads; a slot that is
+// HIP streams: `s_store` carries the uploads and the store-building kernels, the `s_me` streams the search kernels
+// (pictures take turns on up to three of them, so one picture's kernel tails overlap the others' kernels), `s_copy`
+// the result copies when fewer than three search streams are in use (with three, a picture's copy follows its kernels
+// on its own stream: four hardware queues in all). A picture waits (on the device, through events) for the store slots it reads; a slot that is
 // rewritten waits for the last picture that read it. Nothing here blocks the host except svtme_picture_wait.
 #include <hip/hip_runtime.h>
 
@@ -41,9 +42,9 @@ struct Slot {
     uint8_t   *mem = nullptr; // device
     uint8_t   *host_stage = nullptr; // pinned
     hipEvent_t ready = nullptr; // planes built (recorded on s_store)
-    hipEvent_t last_read[2] = {nullptr, nullptr}; // last search kernels that read the planes, per search stream
-    bool       read_recorded[2] = {false, false};
-    bool       ready_seen[2] = {false, false}; // this search stream already waits behind `ready`
+    hipEvent_t last_read[4] = {nullptr, nullptr, nullptr, nullptr}; // last search kernels that read the planes, per search stream
+    bool       read_recorded[4] = {false, false, false, false};
+    bool       ready_seen[4] = {false, false, false, false}; // this search stream already waits behind `ready`
 };
 
 struct Flight {
@@ -77,7 +78,7 @@ struct Flight {
 struct svtme_engine {
     svtme_config        cfg{};
     std::mutex          mu;
-    hipStream_t         s_store = nullptr, s_me[2] = {nullptr, nullptr}, s_copy = nullptr;
+    hipStream_t         s_store = nullptr, s_me[4] = {nullptr, nullptr, nullptr, nullptr}, s_copy = nullptr;
     unsigned            next_me = 0;
     std::vector<Slot>   slots;
     std::vector<Flight> flights;
@@ -132,7 +133,7 @@ extern "C" const char *svtme_version(void) { return "svtme 0.1 (gfx950)"; }
 
 extern "C" int svtme_create(const svtme_config *cfg, svtme_engine **out) {
     if (!cfg || !out || cfg->max_width < 64 || cfg->max_height < 64 || cfg->max_width % 8 || cfg->max_height % 8 ||
-        cfg->max_width > 16384 || cfg->max_height > 16384 || cfg->store_slots < 2 || cfg->max_in_flight < 1 || cfg->search_streams > 2 || cfg->kernel_timing > 1)
+        cfg->max_width > 16384 || cfg->max_height > 16384 || cfg->store_slots < 2 || cfg->max_in_flight < 1 || cfg->search_streams > 3 || cfg->kernel_timing > 1)
         return SVTME_ERR_BAD_ARG;
     int n_dev = 0;
     if (hipGetDeviceCount(&n_dev) != hipSuccess || cfg->device < 0 || cfg->device >= n_dev) {
@@ -150,6 +151,8 @@ extern "C" int svtme_create(const svtme_config *cfg, svtme_engine **out) {
     if (hipStreamCreateWithFlags(&e->s_store, hipStreamNonBlocking) != hipSuccess ||
         hipStreamCreateWithFlags(&e->s_me[0], hipStreamNonBlocking) != hipSuccess ||
         hipStreamCreateWithFlags(&e->s_me[1], hipStreamNonBlocking) != hipSuccess ||
+        hipStreamCreateWithFlags(&e->s_me[2], hipStreamNonBlocking) != hipSuccess ||
+        hipStreamCreateWithFlags(&e->s_me[3], hipStreamNonBlocking) != hipSuccess ||
         hipStreamCreateWithFlags(&e->s_copy, hipStreamNonBlocking) != hipSuccess)
         return fail(SVTME_ERR_DEVICE);
     DevPicture tmp;
@@ -161,7 +164,9 @@ extern "C" int svtme_create(const svtme_config *cfg, svtme_engine **out) {
             hipHostMalloc((void **)&s.host_stage, (size_t)cfg->max_width * cfg->max_height, hipHostMallocDefault) != hipSuccess ||
             hipEventCreateWithFlags(&s.ready, hipEventDisableTiming) != hipSuccess ||
             hipEventCreateWithFlags(&s.last_read[0], hipEventDisableTiming) != hipSuccess ||
-            hipEventCreateWithFlags(&s.last_read[1], hipEventDisableTiming) != hipSuccess)
+            hipEventCreateWithFlags(&s.last_read[1], hipEventDisableTiming) != hipSuccess ||
+            hipEventCreateWithFlags(&s.last_read[2], hipEventDisableTiming) != hipSuccess ||
+            hipEventCreateWithFlags(&s.last_read[3], hipEventDisableTiming) != hipSuccess)
             return fail(SVTME_ERR_NO_RESOURCES);
     }
     e->flights.resize(cfg->max_in_flight);
@@ -219,7 +224,7 @@ extern "C" int svtme_store_put(svtme_engine *e, uint64_t key, uint64_t picture_n
         if (si < 0) return SVTME_ERR_NO_RESOURCES;
     }
     Slot &s = e->slots[si];
-    for (int m = 0; m < 2; ++m) // rewrite after the readers
+    for (int m = 0; m < 4; ++m) // rewrite after the readers
         if (s.used && s.read_recorded[m]) HIP_TRY(hipStreamWaitEvent(e->s_store, s.last_read[m], 0));
     if (s.used) HIP_TRY(hipEventSynchronize(s.ready)); // the pinned staging buffer of this slot is free again
     s.used = true;
@@ -236,7 +241,7 @@ extern "C" int svtme_store_put(svtme_engine *e, uint64_t key, uint64_t picture_n
     launch_store_build(f.pix, f.stride, s.pic, 1, e->s_store);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipEventRecord(s.ready, e->s_store));
-    s.ready_seen[0] = s.ready_seen[1] = false;
+    s.ready_seen[0] = s.ready_seen[1] = s.ready_seen[2] = s.ready_seen[3] = false;
     return SVTME_OK;
 }
 
@@ -348,7 +353,8 @@ extern "C" int svtme_picture_submit(svtme_engine *e, const svtme_picture *pic, s
     p.ops            = reinterpret_cast<unsigned long long *>(reinterpret_cast<uint8_t *>(f->d_hme) + hme_bytes);
     p.ops_out        = reinterpret_cast<unsigned long long *>(f->d_res + f->off_ops);
 
-    const unsigned    mi = e->cfg.search_streams == 1 ? 0 : (e->next_me++ & 1);
+    const unsigned    n_sm = e->cfg.search_streams ? e->cfg.search_streams : 3;
+    const unsigned    mi = e->next_me++ % n_sm;
     const hipStream_t sm = e->s_me[mi];
     for (int si : used)
         if (!e->slots[si].ready_seen[mi]) { // later pictures on this stream are ordered behind this wait anyway
@@ -370,9 +376,12 @@ extern "C" int svtme_picture_submit(svtme_engine *e, const svtme_picture *pic, s
         e->slots[si].readers++;
     }
     // results back to pinned host memory on the copy stream, so that the next picture's kernels do not wait for PCIe
-    HIP_TRY(hipStreamWaitEvent(e->s_copy, f->ev[5], 0));
-    HIP_TRY(hipMemcpyAsync(f->h_res, f->d_res, f->res_bytes, hipMemcpyDeviceToHost, e->s_copy));
-    HIP_TRY(hipEventRecord(f->ev[6], e->s_copy));
+    // (with three search streams the copy stays on the picture's own stream: the other two keep the GPU busy, and
+    // the process stays within four hardware queues)
+    const hipStream_t sc = n_sm >= 3 ? sm : e->s_copy;
+    if (sc != sm) HIP_TRY(hipStreamWaitEvent(sc, f->ev[5], 0));
+    HIP_TRY(hipMemcpyAsync(f->h_res, f->d_res, f->res_bytes, hipMemcpyDeviceToHost, sc));
+    HIP_TRY(hipEventRecord(f->ev[6], sc));
     f->busy   = true;
     f->waited = false;
     f->n_b64  = (uint32_t)n_b64;
