@@ -971,6 +971,9 @@ static void orc_gm_detection(orc_ctx *c, const orc_pic *pic) {
 /* ------------------------------------------------------------------------------------------------ per b64 */
 
 /* motion_estimation_b64 :2930-3002 (ME_OPEN_LOOP) */
+static void orc_tail(orc_ctx *c, const orc_pic *pic);
+static void orc_dump(const orc_ctx *c, const orc_pic *pic, ref_b64_dump *out);
+
 void orc_me_b64(orc_ctx *c, const orc_pic *pic, uint32_t b64_index, ref_b64_dump *out, int run_tail) {
     const svtme_controls *k     = &pic->ctrl;
     const uint32_t        b64_w = (pic->width + 63) / 64;
@@ -992,19 +995,46 @@ void orc_me_b64(orc_ctx *c, const orc_pic *pic, uint32_t b64_index, ref_b64_dump
     if (prune_ref && (k->enable_me_sr_adjustment || k->enable_me_hme_ref_pruning)) orc_hme_prune(c, pic);
     orc_integer_search(c, pic, ox, oy);
 
-    if (run_tail) {
-        /* pa_me_data->me_results[b64] is a per-b64 buffer (zero-filled by the drivers), not thread state */
-        memset(c->total_cand, 0, sizeof(c->total_cand));
-        memset(c->mv_array, 0, sizeof(c->mv_array));
-        memset(c->cand_array, 0, sizeof(c->cand_array));
-        if (prune_ref && k->enable_me_hme_ref_pruning) orc_me_prune(c, pic);
-        if (pic->n_ref[0] == 1 && pic->n_ref[1] == 1) orc_cands_mrp_off(c, pic);
-        else orc_cands(c, pic);
-        orc_distortion(c, pic, c->block_w, c->block_h);
-        c->stationary = c->allow_gm = 0;
-        if (pic->gm_enabled) orc_gm_detection(c, pic);
-    }
+    if (run_tail) orc_tail(c, pic);
+    orc_dump(c, pic, out);
+}
 
+/* motion_estimation_b64 :2975-2999: what stays on the host when a device does the searches */
+static void orc_tail(orc_ctx *c, const orc_pic *pic) {
+    const svtme_controls *k = &pic->ctrl;
+    /* pa_me_data->me_results[b64] is a per-b64 buffer (zero-filled by the drivers), not thread state */
+    memset(c->total_cand, 0, sizeof(c->total_cand));
+    memset(c->mv_array, 0, sizeof(c->mv_array));
+    memset(c->cand_array, 0, sizeof(c->cand_array));
+    if (k->enable_hme_flag && k->enable_me_hme_ref_pruning) orc_me_prune(c, pic);
+    if (pic->n_ref[0] == 1 && pic->n_ref[1] == 1) orc_cands_mrp_off(c, pic);
+    else orc_cands(c, pic);
+    orc_distortion(c, pic, c->block_w, c->block_h);
+    c->stationary = c->allow_gm = 0;
+    if (pic->gm_enabled) orc_gm_detection(c, pic);
+}
+
+/* The host tail alone, on search results handed over in `in` (best SAD / MV, search centres, HME SADs, do_ref,
+ * zero-MV SADs, divisors): what the encoder's ME thread does after unpacking a device result. */
+void orc_tail_b64(orc_ctx *c, const orc_pic *pic, uint32_t b64_index, const ref_b64_dump *in, ref_b64_dump *out) {
+    const uint32_t b64_w = (pic->width + 63) / 64;
+    const int      ox = (int)(b64_index % b64_w) * 64, oy = (int)(b64_index / b64_w) * 64;
+    c->block_w = ORC_MIN(pic->width - (uint32_t)ox, 64u);
+    c->block_h = ORC_MIN(pic->height - (uint32_t)oy, 64u);
+    orc_init_b64(c, pic);
+    memcpy(c->best_sad, in->best_sad, sizeof(in->best_sad));
+    memcpy(c->best_mv, in->best_mv, sizeof(in->best_mv));
+    memcpy(c->sc_x, in->hme_sc_x, sizeof(in->hme_sc_x));
+    memcpy(c->sc_y, in->hme_sc_y, sizeof(in->hme_sc_y));
+    memcpy(c->hme_sad, in->hme_sad, sizeof(in->hme_sad));
+    memcpy(c->do_ref, in->do_ref, sizeof(in->do_ref));
+    memcpy(c->zz_sad, in->zz_sad, sizeof(in->zz_sad));
+    memcpy(c->sr_div, in->sr_divisor, sizeof(in->sr_divisor));
+    orc_tail(c, pic);
+    orc_dump(c, pic, out);
+}
+
+static void orc_dump(const orc_ctx *c, const orc_pic *pic, ref_b64_dump *out) {
     if (!out) return;
     memset(out, 0, sizeof(*out));
     memcpy(out->best_sad, c->best_sad, sizeof(out->best_sad));

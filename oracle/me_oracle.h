@@ -56,6 +56,8 @@ void     orc_ctx_free(orc_ctx *c);
 /* Runs motion_estimation_b64 (EbMotionEstimation.c:2930-3002) for one b64 and writes the resulting state.
  * run_tail = 0 stops after integer_search_b64 (the part the GPU engine replaces). */
 void orc_me_b64(orc_ctx *c, const orc_pic *pic, uint32_t b64_index, ref_b64_dump *out, int run_tail);
+/* Host tail only (EbMotionEstimation.c:2975-2999) on handed-over search results. */
+void orc_tail_b64(orc_ctx *c, const orc_pic *pic, uint32_t b64_index, const ref_b64_dump *in, ref_b64_dump *out);
 
 /* Algorithmic abs-diff-accumulate operation counts since the context was created:
  * [0] zz/check_00 SADs, [1] pre-HME, [2] HME-L0, [3] HME-L1, [4] HME-L2, [5] integer search. */

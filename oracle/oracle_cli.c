@@ -3,7 +3,7 @@
  * (me_oracle.c) and writes the same dump format oracle/_ref/ref_me writes, so the two can be compared byte for
  * byte. Also prints the algorithmic operation counts of the run as one JSON line.
  *
- * Usage: oracle_me <job file> <output file>
+ * Usage: oracle_me <job file> <output file> [<handover file>, mode REF_MODE_TAIL only]
  */
 #include <stdio.h>
 #include <stdlib.h>
@@ -131,6 +131,36 @@ int main(int argc, char **argv) {
             fwrite(&pd, sizeof(pd), 1, o);
             fwrite(rec, sizeof(ref_b64_dump), oh.n_b64, o);
         }
+        free(rec);
+    } else if (h.mode == REF_MODE_TAIL) {
+        if (argc < 4) die("REF_MODE_TAIL needs a handover file");
+        FILE *hf = fopen(argv[3], "rb");
+        if (!hf) die("cannot open handover file");
+        fwrite(&oh, sizeof(oh), 1, o);
+        ref_b64_dump *in = (ref_b64_dump *)calloc(oh.n_b64, sizeof(ref_b64_dump));
+        ref_b64_dump *rec = (ref_b64_dump *)calloc(oh.n_b64, sizeof(ref_b64_dump));
+        orc_ctx      *ctx = orc_ctx_new();
+        for (uint32_t pi = 0; pi < h.n_pics; ++pi) {
+            orc_pic pic;
+            fill_pic(&pic, &h, &pics[pi], planes);
+            if (fread(in, sizeof(ref_b64_dump), oh.n_b64, hf) != oh.n_b64) die("short handover data");
+            for (uint32_t b = 0; b < oh.n_b64; ++b) orc_tail_b64(ctx, &pic, b, &in[b], &rec[b]);
+            ref_pic_dump pd;
+            memset(&pd, 0, sizeof(pd));
+            pd.ctrl = pic.ctrl;
+            pd.enable_me_8x8 = pic.enable_me_8x8;
+            pd.enable_me_16x16 = pic.enable_me_16x16;
+            pd.max_cand = pic.max_cand;
+            pd.max_refs = pic.max_refs;
+            pd.max_l0 = pic.max_l0;
+            pd.input_resolution = pic.input_resolution;
+            pd.n_b64 = oh.n_b64;
+            fwrite(&pd, sizeof(pd), 1, o);
+            fwrite(rec, sizeof(ref_b64_dump), oh.n_b64, o);
+        }
+        orc_ctx_free(ctx);
+        fclose(hf);
+        free(in);
         free(rec);
     } else {
         uint32_t reps = h.reps ? h.reps : 1;

@@ -12,7 +12,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 REF_BIN = os.path.join(HERE, "_ref", "ref_me")
 ORACLE_BIN = os.path.join(HERE, "build", "oracle_me")
 
-MODE_DUMP, MODE_BENCH, MODE_PLANES, MODE_DUMP_NOTAIL = 0, 1, 2, 3
+MODE_DUMP, MODE_BENCH, MODE_PLANES, MODE_DUMP_NOTAIL, MODE_TAIL = 0, 1, 2, 3, 4
 
 SA = np.dtype([("width", "<u2"), ("height", "<u2")])
 SAMM = np.dtype([("sa_min", SA), ("sa_max", SA)])
@@ -87,7 +87,7 @@ def read_dump(path):
     assert magic == b"SVTMEO01", magic
     hdr = dict(n_pics=n_pics, n_b64=n_b64, used_avx2=avx2, mode=mode, bench_seconds=secs, bench_pictures=npic)
     out = []
-    if mode in (MODE_DUMP, MODE_DUMP_NOTAIL):
+    if mode in (MODE_DUMP, MODE_DUMP_NOTAIL, MODE_TAIL):
         assert pds == PIC_DUMP.itemsize and bds == B64_DUMP.itemsize, (pds, PIC_DUMP.itemsize, bds, B64_DUMP.itemsize)
         off = hs
         for _ in range(n_pics):
@@ -122,6 +122,22 @@ def run_binary(binary, frames, pics, enc_mode, **kw):
         hdr, recs = read_dump(out)
         hdr["stdout"] = r.stdout
         return hdr, recs
+
+
+def run_oracle_tail(frames, pics, enc_mode, handover, **kw):
+    """The host tail (me_prune_ref .. perform_gm_detection) of the restatement on handed-over search results.
+    handover: per picture, a B64_DUMP record array of which best_sad, best_mv, hme_sc_x/y, hme_sad, do_ref, zz_sad and
+    sr_divisor are read. Returns what run_oracle returns."""
+    with tempfile.TemporaryDirectory(prefix="svtme_") as td:
+        job, out, hand = os.path.join(td, "job.bin"), os.path.join(td, "out.bin"), os.path.join(td, "hand.bin")
+        write_job(job, frames, pics, enc_mode, mode=MODE_TAIL, **kw)
+        with open(hand, "wb") as f:
+            for rec in handover:
+                f.write(np.ascontiguousarray(rec, dtype=B64_DUMP).tobytes())
+        r = subprocess.run([ORACLE_BIN, job, out, hand], capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError("oracle tail failed (%d): %s" % (r.returncode, r.stderr[-2000:]))
+        return read_dump(out)
 
 
 def run_reference(frames, pics, enc_mode, **kw):

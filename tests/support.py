@@ -169,3 +169,32 @@ class OracleEngine:
 
     def done(self, ticket):
         del self.pending[ticket]
+
+
+def handover_records(results, n_b64):
+    """refio.B64_DUMP records carrying what a device hands to the encoder's ME threads (best SAD / MV, search centres,
+    HME SADs, do_ref, zero-MV SADs, search-range divisors), from an engine output dict or an oracle record array."""
+    rec = np.zeros(n_b64, refio.B64_DUMP)
+    if isinstance(results, dict):
+        sr = results["search_results"]
+        rec["best_sad"], rec["best_mv"] = results["best_sad"], results["best_mv"]
+        rec["zz_sad"], rec["sr_divisor"] = results["zz_sad"], results["sr_divisor"]
+        for f in ("hme_sc_x", "hme_sc_y", "hme_sad", "do_ref"):
+            rec[f] = sr[f]
+    else:
+        for f in ("best_sad", "best_mv", "zz_sad", "sr_divisor", "hme_sc_x", "hme_sc_y", "hme_sad", "do_ref"):
+            rec[f] = results[f]
+    return rec
+
+
+def tail_mismatches(tail_recs, golden_b64, pics, pruning):
+    """Fields of the host tail's output (candidate lists, MV arrays, distortions, GM flags, final do_ref / hme_sad)
+    that differ from a reference dump; [] when the hand-over + host tail reproduce the reference's final state."""
+    msgs = []
+    for i, ((_, bd), p) in enumerate(zip(tail_recs, pics)):
+        want = canonical(golden_b64[i], p, pruning[i])
+        got = canonical(bd, p, pruning[i])
+        for f in TAIL_FIELDS + ["best_sad", "best_mv"]:
+            if not np.array_equal(got[f], want[f]):
+                msgs.append("picture %d (poc %d): %s" % (i, p.poc, f))
+    return msgs

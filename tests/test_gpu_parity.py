@@ -83,6 +83,43 @@ def test_engine_rejects_what_it_does_not_implement():
     assert ei.value.code == svtme.ERR_UNSUPPORTED
 
 
+@pytest.mark.parametrize("name", GPU_CASES)
+def test_engine_results_through_the_host_tail_give_the_reference_final_state(name):
+    """The drop-in contract end to end: what the engine returns, unpacked per b64 and pushed through the host tail
+    (me_prune_ref, candidate construction, distortions, GM detection - the oracle's restatement of the code that stays on
+    the host), equals the real reference's final me_results / MeContext / picture statistics (tests/golden/*.npz)."""
+    c = MOD.CASES[name]
+    g = np.load(os.path.join(GOLDEN, name + ".npz"))
+    frames, pics, rc = support.make_job(c["width"], c["height"], c["n_frames"], c["enc_mode"], c["seed"],
+                                        c.get("structure", "ra"), c.get("kind", "synth"))
+    kw = dict(ref_counts=rc, sc_class1=c.get("sc_class1", 0), frame_rate=c.get("frame_rate", 30 << 16), gm_enabled=1, gm_dist_th=1)
+    outs = support.run_engine_job(frames, pics, c["enc_mode"], c.get("sc_class1", 0), c.get("frame_rate", 30 << 16))
+    n_b64 = g["b64"].shape[1]
+    hand = [support.handover_records(o, n_b64) for o in outs]
+    _, tail = refio.run_oracle_tail(frames, pics, c["enc_mode"], hand, **kw)
+    pruning = [bool(pd["ctrl"]["enable_me_hme_ref_pruning"]) for pd in g["pic"]]
+    assert not support.tail_mismatches(tail, g["b64"], pics, pruning)
+
+
+def test_scheduler_runs_a_sequence_on_the_engine_with_store_reuse():
+    """svtme.scheduler on the real engine: sources put when first needed and released after their last reader, with a
+    store smaller than the sequence (slots are reused while pictures are in flight); bit-exact with the oracle."""
+    from svtme import scheduler
+    frames, pics, rc = support.make_job(256, 128, 17, 8, seed=7)
+    recs = support.oracle_handover(frames, pics, 8, rc)
+    ctrl = svtme.derive_controls(8, 256, 128)
+    eng = svtme.Engine(256, 128, store_slots=10, max_in_flight=3)
+    try:
+        got = scheduler.run_sharded(eng, {i: frames[i] for i in range(len(frames))}, pics, ctrl, 0, 1, in_flight=3)
+    finally:
+        eng.close()
+    assert sorted(got) == list(range(len(pics)))
+    msgs = []
+    for i, p in enumerate(pics):
+        msgs += support.compare_picture(got[i], recs[i], p, "poc %d" % p.poc)
+    assert not msgs, "\n".join(msgs[:10])
+
+
 @pytest.mark.parametrize("name", sorted(MOD.DIGEST_CASES))
 def test_engine_matches_reference_digests_at_full_size(name):
     """1080p preset 8 / 720p preset 12 / 360p preset 3: sha256 of the engine's masked best SAD / MV arrays and
