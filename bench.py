@@ -110,7 +110,9 @@ def main():
     if not torch.cuda.is_available():
         sys.exit("bench.py needs a GPU: the engine has no CPU fallback")
     torch.cuda.set_device(local_rank)
-    if world > 1:
+    # under torch.distributed.run (RANK set) the group is always formed, also for one rank, so that the path is the same
+    use_dist = world > 1 or "RANK" in os.environ
+    if use_dist:
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
     import svtme
@@ -151,7 +153,7 @@ def main():
         e.done(t)
 
     def barrier():
-        if world > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -189,7 +191,7 @@ def main():
         for _ in range(args.kernel_steps):
             step(solo)
         torch.cuda.synchronize()
-    if world > 1:
+    if use_dist:
         tt = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
@@ -251,7 +253,7 @@ def main():
                 out["cpu_baseline"] = {"value": None, "unit": "pictures/s", "cores": 0, "kind": "port", "sample": "failed: %r" % (ex,)}
         print(json.dumps(out), flush=True)
     eng.close()
-    if world > 1:
+    if use_dist:
         dist.barrier()
         dist.destroy_process_group()
 

@@ -24,7 +24,7 @@ namespace svtme {
 constexpr int HI_THREADS   = 64;
 constexpr int HI_WIN_BYTES = 12288; // LDS budget of one staged reference window
 constexpr int HI_XCHUNK    = 96; // search positions per staged column chunk (level 0 / pre-HME)
-constexpr int HI_WIN2_BYTES = 8192; // levels 1 and 2
+constexpr int HI_WIN2_BYTES = 6144; // levels 1 and 2
 
 struct L0Shared {
     u64      key;
