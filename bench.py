@@ -213,6 +213,15 @@ def main():
         name = max(kernels, key=lambda k_: kernels[k_][1])
         dom_ops, dom_ms = kernels[name]
         achieved = dom_ops / (dom_ms * 1e-3) / 1e12 if dom_ms > 0 else 0.0
+        # memory-side bytes per launch of that kernel: from the committed summary of the separate rocprofv3 --pmc
+        # passes over this same command (FETCH_SIZE doubled: gfx950 tallies 128-byte read requests as 64 bytes)
+        traffic = None
+        try:
+            with open(os.path.join(ROOT, "profiles", "r01_traffic_%s.json" % args.workload)) as f:
+                t = json.load(f)["kernels"]["svtme::" + name]
+            traffic = (2.0 * t["fetch_kib"] + t["write_kib"]) * 1024.0
+        except (OSError, KeyError, ValueError):
+            pass
         # algorithmic HBM bytes of one picture: each needed plane once + results
         refs_per_pic = n_refs / len(pics)
         plane_bytes = w * h * (1 + 0.25 + 0.0625)
@@ -228,7 +237,7 @@ def main():
                        "parallelism": "pictures sharded over %d GPU(s), no data-path collective" % world},
             "roofline": {
                 "bound": "valu", "kernel": name, "achieved": achieved, "peak": PEAK_SAD_TOPS,
-                "unit": "T abs-diff-acc/s", "frac": achieved / PEAK_SAD_TOPS, "traffic": None,
+                "unit": "T abs-diff-acc/s", "frac": achieved / PEAK_SAD_TOPS, "traffic": traffic,
                 "ops_per_launch": dom_ops, "avg_launch_ms": dom_ms,
                 "measured": "HIP events on the kernels' stream, %d-step pass with one search stream after the timed region"
                             % args.kernel_steps if solo is not stats else "HIP events on the kernels' stream, timed region",
