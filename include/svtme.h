@@ -151,6 +151,25 @@ int svtme_store_release(svtme_engine *e, uint64_t key);
 int svtme_store_read(svtme_engine *e, uint64_t key, int level, uint8_t *dst, size_t dst_size,
                      uint32_t *stride, uint32_t *width, uint32_t *height, uint32_t *pad);
 
+/* Optional second stage on the device: the rest of motion_estimation_b64 after integer_search_b64
+ * (EbMotionEstimation.c:2975-2999: me_prune_ref :1576-1618, construct_me_candidate_array[_mrp_off] :2430-2685,
+ * compute_distortion :2814-2865, perform_gm_detection :2688-2811), so that the host only copies finished
+ * MotionEstimationResults and per-b64 statistics. All zero = off (the host runs that code itself). */
+typedef struct svtme_tail {
+    uint8_t enable;
+    uint8_t enable_me_8x8; /* pcs->enable_me_8x8 */
+    uint8_t enable_me_16x16; /* pcs->enable_me_16x16 */
+    uint8_t max_refs; /* pcs->pa_me_data->max_refs, <= SVTME_TAIL_MV_STRIDE */
+    uint8_t max_cand; /* pcs->pa_me_data->max_cand, <= SVTME_TAIL_CAND_STRIDE */
+    uint8_t max_l0; /* pcs->pa_me_data->max_l0 */
+    uint8_t input_resolution; /* scs->input_resolution */
+    uint8_t gm_enabled; /* pcs->gm_ctrls.enabled */
+    uint8_t gm_use_distance_based_active_th; /* pcs->gm_ctrls.use_distance_based_active_th */
+    uint8_t reserved[7];
+} svtme_tail;
+#define SVTME_TAIL_MV_STRIDE 7 /* MAX_PA_ME_MV, EbMotionEstimationLcuResults.h:23 */
+#define SVTME_TAIL_CAND_STRIDE 23 /* MAX_PA_ME_CAND, :24 */
+
 /* One picture's ME job: what motion_estimation_kernel() sets on MeContext before the b64 loop
  * (EbMotionEstimationProcess.c:795-837) plus the pcs/scs fields integer_search_b64 reads. */
 typedef struct svtme_picture {
@@ -166,6 +185,7 @@ typedef struct svtme_picture {
     uint64_t ref_key[SVTME_MAX_LISTS][SVTME_MAX_REFS]; /* store keys of pcs->ref_pa_pic_ptr_array */
     uint64_t ref_picture_number[SVTME_MAX_LISTS][SVTME_MAX_REFS];
     svtme_controls ctrl;
+    svtme_tail     tail;
 } svtme_picture;
 
 /* SearchResults, EbMotionEstimationContext.h:330-337, as left by hme_prune_ref_and_adjust_sr. */
@@ -188,6 +208,18 @@ typedef struct svtme_results {
     const svtme_search_result *search_results; /* [n_b64][2][4] */
     const uint32_t            *zz_sad; /* [n_b64][2][4], MeContext::zz_sad :471 */
     const uint32_t            *reduce_me_sr_divisor; /* [n_b64][2][4], :400 */
+    /* Only for pictures submitted with tail.enable (else NULL): MotionEstimationResults of every b64
+     * (EbMotionEstimationLcuResults.h:37-45; arrays indexed as the reference does, pu * max_refs + ... and
+     * pu * max_cand + ..., unused entries zero), MeContext::me_distortion, the pcs statistics of compute_distortion /
+     * perform_gm_detection and the final do_ref / hme_sad of me_prune_ref. */
+    const uint8_t  *total_me_candidate_index; /* [n_b64][85] */
+    const uint32_t *me_mv_array; /* [n_b64][85 * SVTME_TAIL_MV_STRIDE] */
+    const uint8_t  *me_candidate_array; /* [n_b64][85 * SVTME_TAIL_CAND_STRIDE], MeCandidate bit-fields */
+    const uint32_t *me_distortion; /* [n_b64][85] */
+    const uint32_t *b64_stats; /* [n_b64][8]: rc_me_distortion, me_64x64 / 32x32 / 16x16 / 8x8_distortion,
+                                  me_8x8_cost_variance, stationary_block_present_sb, rc_me_allow_gm */
+    const uint8_t  *final_do_ref; /* [n_b64][2][4] */
+    const uint64_t *final_hme_sad; /* [n_b64][2][4] */
 } svtme_results;
 
 typedef uint64_t svtme_ticket;

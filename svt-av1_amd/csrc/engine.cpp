@@ -68,7 +68,19 @@ struct Flight {
         off_div   = off_zz + n * 4;
         off_ops   = (off_div + n * 4 + 63) / 64 * 64;
         res_bytes = off_ops + SVTME_OPS_BYTES;
+        // the optional device-side host tail's outputs follow (copied only for pictures that asked for it)
+        const size_t nb = n / (SVTME_MAX_LISTS * SVTME_MAX_REFS);
+        off_thme  = res_bytes;
+        off_tmv   = off_thme + nb * 8 * 8;
+        off_tdist = off_tmv + nb * SVTME_PU_COUNT * SVTME_TAIL_MV_STRIDE * 4;
+        off_tstat = off_tdist + nb * SVTME_PU_COUNT * 4;
+        off_tcand = off_tstat + nb * 8 * 4;
+        off_ttot  = off_tcand + nb * SVTME_PU_COUNT * SVTME_TAIL_CAND_STRIDE;
+        off_tdo   = off_ttot + nb * SVTME_PU_COUNT;
+        tail_end  = (off_tdo + nb * 8 + 63) / 64 * 64;
     }
+    size_t off_thme = 0, off_tmv = 0, off_tdist = 0, off_tstat = 0, off_tcand = 0, off_ttot = 0, off_tdo = 0, tail_end = 0;
+    bool   tail = false;
     // start, after each of the 2 HME and 3 ME kernels, after D2H
     hipEvent_t           ev[7] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
 };
@@ -173,10 +185,10 @@ extern "C" int svtme_create(const svtme_config *cfg, svtme_engine **out) {
     for (auto &f : e->flights) {
         const size_t n = e->max_b64 * SVTME_MAX_LISTS * SVTME_MAX_REFS;
         f.layout(n);
-        if (hipMalloc((void **)&f.d_hme, n * sizeof(HmeRefOut) + SVTME_OPS_BYTES) != hipSuccess || hipMalloc((void **)&f.d_res, f.res_bytes) != hipSuccess ||
+        if (hipMalloc((void **)&f.d_hme, n * sizeof(HmeRefOut) + SVTME_OPS_BYTES) != hipSuccess || hipMalloc((void **)&f.d_res, f.tail_end) != hipSuccess ||
             hipMalloc((void **)&f.d_jobs, n * sizeof(MeJob)) != hipSuccess ||
             hipMalloc((void **)&f.d_keys, n * SVTME_PU_COUNT * sizeof(unsigned long long)) != hipSuccess ||
-            hipHostMalloc((void **)&f.h_res, f.res_bytes, hipHostMallocDefault) != hipSuccess)
+            hipHostMalloc((void **)&f.h_res, f.tail_end, hipHostMallocDefault) != hipSuccess)
             return fail(SVTME_ERR_NO_RESOURCES);
         for (auto &ev : f.ev)
             if (hipEventCreate(&ev) != hipSuccess) return fail(SVTME_ERR_NO_RESOURCES);
@@ -286,6 +298,11 @@ extern "C" int svtme_picture_submit(svtme_engine *e, const svtme_picture *pic, s
     // not implemented on the device: full-SAD integer search (no preset selects it) and the screen-content rule
     // that shrinks later references' windows from the first reference's 64x64 result (EbMotionEstimation.c:1390-1399)
     if (k.me_search_method != 0 || (k.enable_me_sr_adjustment == 2 && k.me_early_exit_th == 0)) return SVTME_ERR_UNSUPPORTED;
+    if (pic->tail.enable &&
+        (pic->tail.max_refs > SVTME_TAIL_MV_STRIDE || pic->tail.max_cand > SVTME_TAIL_CAND_STRIDE || pic->tail.max_cand < 1 ||
+         pic->tail.max_refs < pic->tail.max_l0 + (pic->num_of_list_to_search == 2 ? pic->num_of_ref_pic_to_search[1] : 0) ||
+         pic->tail.max_l0 < pic->num_of_ref_pic_to_search[0]))
+        return SVTME_ERR_BAD_ARG;
 
     std::lock_guard<std::mutex> lock(e->mu);
     HIP_TRY(hipSetDevice(e->cfg.device));
@@ -368,7 +385,25 @@ extern "C" int svtme_picture_submit(svtme_engine *e, const svtme_picture *pic, s
     hipEvent_t  me_marks[3]  = {kt ? f->ev[3] : nullptr, kt ? f->ev[4] : nullptr, f->ev[5]};
     f->kernel_timing = kt;
     launch_hme(p, sm, hme_marks);
+    // (the last ME mark is recorded after the optional tail kernel, so that it ends the picture's kernels either way)
+    hipEvent_t last_mark = me_marks[2];
+    f->tail = pic->tail.enable != 0;
+    if (f->tail) {
+        me_marks[2]    = nullptr;
+        p.tail         = pic->tail;
+        p.t_hme_sad    = reinterpret_cast<unsigned long long *>(f->d_res + f->off_thme);
+        p.t_mv_array   = reinterpret_cast<uint32_t *>(f->d_res + f->off_tmv);
+        p.t_distortion = reinterpret_cast<uint32_t *>(f->d_res + f->off_tdist);
+        p.t_stats      = reinterpret_cast<uint32_t *>(f->d_res + f->off_tstat);
+        p.t_cand_array = f->d_res + f->off_tcand;
+        p.t_total_cand = f->d_res + f->off_ttot;
+        p.t_do_ref     = f->d_res + f->off_tdo;
+    }
     launch_me(p, sm, me_marks);
+    if (f->tail) {
+        launch_tail(p, sm);
+        HIP_TRY(hipEventRecord(last_mark, sm));
+    }
     HIP_TRY(hipGetLastError());
     for (int si : used) {
         HIP_TRY(hipEventRecord(e->slots[si].last_read[mi], sm));
@@ -380,7 +415,7 @@ extern "C" int svtme_picture_submit(svtme_engine *e, const svtme_picture *pic, s
     // the process stays within four hardware queues)
     const hipStream_t sc = n_sm >= 3 ? sm : e->s_copy;
     if (sc != sm) HIP_TRY(hipStreamWaitEvent(sc, f->ev[5], 0));
-    HIP_TRY(hipMemcpyAsync(f->h_res, f->d_res, f->res_bytes, hipMemcpyDeviceToHost, sc));
+    HIP_TRY(hipMemcpyAsync(f->h_res, f->d_res, f->tail ? f->tail_end : f->res_bytes, hipMemcpyDeviceToHost, sc));
     HIP_TRY(hipEventRecord(f->ev[6], sc));
     f->busy   = true;
     f->waited = false;
@@ -430,6 +465,13 @@ extern "C" int svtme_picture_wait(svtme_engine *e, svtme_ticket ticket, svtme_re
     out->search_results       = reinterpret_cast<const svtme_search_result *>(f->h_res + f->off_sr);
     out->zz_sad               = reinterpret_cast<const uint32_t *>(f->h_res + f->off_zz);
     out->reduce_me_sr_divisor = reinterpret_cast<const uint32_t *>(f->h_res + f->off_div);
+    out->total_me_candidate_index = f->tail ? f->h_res + f->off_ttot : nullptr;
+    out->me_mv_array              = f->tail ? reinterpret_cast<const uint32_t *>(f->h_res + f->off_tmv) : nullptr;
+    out->me_candidate_array       = f->tail ? f->h_res + f->off_tcand : nullptr;
+    out->me_distortion            = f->tail ? reinterpret_cast<const uint32_t *>(f->h_res + f->off_tdist) : nullptr;
+    out->b64_stats                = f->tail ? reinterpret_cast<const uint32_t *>(f->h_res + f->off_tstat) : nullptr;
+    out->final_do_ref             = f->tail ? f->h_res + f->off_tdo : nullptr;
+    out->final_hme_sad            = f->tail ? reinterpret_cast<const uint64_t *>(f->h_res + f->off_thme) : nullptr;
     return SVTME_OK;
 }
 

@@ -74,6 +74,15 @@ struct PicParams {
     // [2..4] HME L0..L2, [5] integer search
     unsigned long long  *ops;
     unsigned long long  *ops_out; // where me_finish_kernel leaves a copy of the counters for the result transfer
+    // optional host tail on the device (tail.enable)
+    svtme_tail          tail;
+    uint8_t            *t_total_cand; // [n_b64][85]
+    uint32_t           *t_mv_array; // [n_b64][85 * 7]
+    uint8_t            *t_cand_array; // [n_b64][85 * 23]
+    uint32_t           *t_distortion; // [n_b64][85]
+    uint32_t           *t_stats; // [n_b64][8]
+    uint8_t            *t_do_ref; // [n_b64][8]
+    unsigned long long *t_hme_sad; // [n_b64][8]
 };
 
 constexpr int SVTME_OPS_SLOTS = 64;
@@ -87,6 +96,7 @@ void launch_store_build(const uint8_t *luma, int luma_stride, const DevPicture &
 void launch_hme(const PicParams &p, hipStream_t s, hipEvent_t marks[2]); // picks the serial or the itemised kernels
 void launch_hme_items(const PicParams &p, hipStream_t s, hipEvent_t marks[2]);
 void launch_me(const PicParams &p, hipStream_t s, hipEvent_t marks[3]);
+void launch_tail(const PicParams &p, hipStream_t s); // after launch_me, when p.tail.enable
 
 int  occupancy_me_search();
 void occupancy_hme_items(int out[2]);

@@ -62,13 +62,22 @@ class Config(C.Structure):
                 ("store_slots", C.c_uint32), ("max_in_flight", C.c_uint32), ("search_streams", C.c_uint32), ("kernel_timing", C.c_uint32)]
 
 
+class Tail(C.Structure):
+    _fields_ = [("enable", C.c_uint8), ("enable_me_8x8", C.c_uint8), ("enable_me_16x16", C.c_uint8), ("max_refs", C.c_uint8),
+                ("max_cand", C.c_uint8), ("max_l0", C.c_uint8), ("input_resolution", C.c_uint8), ("gm_enabled", C.c_uint8),
+                ("gm_use_distance_based_active_th", C.c_uint8), ("reserved", C.c_uint8 * 7)]
+
+
+TAIL_MV_STRIDE, TAIL_CAND_STRIDE = 7, 23
+
+
 class Picture(C.Structure):
     _fields_ = [
         ("cur_key", C.c_uint64), ("picture_number", C.c_uint64), ("width", C.c_uint32), ("height", C.c_uint32),
         ("temporal_layer_index", C.c_uint8), ("is_used_as_reference_flag", C.c_uint8),
         ("num_of_list_to_search", C.c_uint8), ("num_of_ref_pic_to_search", C.c_uint8 * 2), ("reserved", C.c_uint8 * 3),
         ("ref_key", (C.c_uint64 * MAX_REFS) * MAX_LISTS), ("ref_picture_number", (C.c_uint64 * MAX_REFS) * MAX_LISTS),
-        ("ctrl", Controls),
+        ("ctrl", Controls), ("tail", Tail),
     ]
 
 
@@ -85,7 +94,11 @@ assert SEARCH_RESULT_DTYPE.itemsize == C.sizeof(SearchResult) == 16
 class Results(C.Structure):
     _fields_ = [("n_b64", C.c_uint32), ("p_sb_best_sad", C.POINTER(C.c_uint32)), ("p_sb_best_mv", C.POINTER(C.c_uint32)),
                 ("search_results", C.POINTER(SearchResult)), ("zz_sad", C.POINTER(C.c_uint32)),
-                ("reduce_me_sr_divisor", C.POINTER(C.c_uint32))]
+                ("reduce_me_sr_divisor", C.POINTER(C.c_uint32)),
+                ("total_me_candidate_index", C.POINTER(C.c_uint8)), ("me_mv_array", C.POINTER(C.c_uint32)),
+                ("me_candidate_array", C.POINTER(C.c_uint8)), ("me_distortion", C.POINTER(C.c_uint32)),
+                ("b64_stats", C.POINTER(C.c_uint32)), ("final_do_ref", C.POINTER(C.c_uint8)),
+                ("final_hme_sad", C.POINTER(C.c_uint64))]
 
 
 EXPORTS = ("svtme_version", "svtme_derive_controls", "svtme_input_resolution", "svtme_create", "svtme_destroy",
@@ -181,8 +194,8 @@ class Engine:
         rows = ph.value + 2 * pad.value
         return buf[:rows * st.value].reshape(rows, st.value).copy()
 
-    def make_picture(self, width, height, poc, temporal_layer, is_ref, refs, ctrl, key_of=lambda poc: poc):
-        """refs: [[pocs of list 0], [pocs of list 1]]."""
+    def make_picture(self, width, height, poc, temporal_layer, is_ref, refs, ctrl, key_of=lambda poc: poc, tail=None):
+        """refs: [[pocs of list 0], [pocs of list 1]]; tail: a Tail to run the host tail on the device too."""
         p = Picture()
         p.cur_key = key_of(poc)
         p.picture_number = poc
@@ -196,6 +209,8 @@ class Engine:
                 p.ref_key[l][i] = key_of(r)
                 p.ref_picture_number[l][i] = r
         p.ctrl = ctrl
+        if tail is not None:
+            p.tail = tail
         return p
 
     def submit(self, pic):
@@ -220,6 +235,14 @@ class Engine:
         }
         sr = np.frombuffer(C.string_at(r.search_results, n * 8 * 16), SEARCH_RESULT_DTYPE).reshape(n, 2, 4)
         out["search_results"] = sr
+        if r.me_mv_array:  # the picture ran the host tail on the device
+            out["total_me_candidate_index"] = np.ctypeslib.as_array(r.total_me_candidate_index, (n, 85))
+            out["me_mv_array"] = np.ctypeslib.as_array(r.me_mv_array, (n, 85 * TAIL_MV_STRIDE))
+            out["me_candidate_array"] = np.ctypeslib.as_array(r.me_candidate_array, (n, 85 * TAIL_CAND_STRIDE))
+            out["me_distortion"] = np.ctypeslib.as_array(r.me_distortion, (n, 85))
+            out["b64_stats"] = np.ctypeslib.as_array(r.b64_stats, (n, 8))
+            out["final_do_ref"] = np.ctypeslib.as_array(r.final_do_ref, (n, 2, 4))
+            out["final_hme_sad"] = np.ctypeslib.as_array(r.final_hme_sad, (n, 2, 4))
         if copy:
             out = {k: np.array(v) for k, v in out.items()}
         return out

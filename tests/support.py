@@ -67,8 +67,9 @@ def compare_picture(out, bd, pic, where=""):
     return msgs
 
 
-def run_engine_job(frames, pics, enc_mode, sc_class1=0, frame_rate=30 << 16, engine=None):
-    """Runs every picture of the job through the engine's C ABI; returns the list of output dicts."""
+def run_engine_job(frames, pics, enc_mode, sc_class1=0, frame_rate=30 << 16, engine=None, tail=None):
+    """Runs every picture of the job through the engine's C ABI; returns the list of output dicts. tail: an
+    svtme.Tail to run the host tail on the device as well."""
     import svtme
     n, h, w = frames.shape
     own = engine is None
@@ -79,7 +80,7 @@ def run_engine_job(frames, pics, enc_mode, sc_class1=0, frame_rate=30 << 16, eng
         ctrl = svtme.derive_controls(enc_mode, w, h, sc_class1, frame_rate)
         outs = []
         for p in pics:
-            pic = eng.make_picture(w, h, p.poc, p.temporal_layer, p.is_ref, p.refs, ctrl)
+            pic = eng.make_picture(w, h, p.poc, p.temporal_layer, p.is_ref, p.refs, ctrl, tail=tail)
             outs.append(eng.run_picture(pic))
         return outs
     finally:

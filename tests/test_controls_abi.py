@@ -30,7 +30,9 @@ def test_library_exports_every_declared_symbol():
 def test_struct_sizes_match_the_header():
     assert C.sizeof(svtme.Controls) == 84 == refio.CONTROLS.itemsize
     assert C.sizeof(svtme.SearchResult) == 16
-    assert C.sizeof(svtme.Picture) == 32 + 64 + 64 + 84 + 4  # keys/poc/geometry, ref keys, ref pocs, controls, tail padding
+    assert C.sizeof(svtme.Tail) == 16
+    # keys/poc/geometry, ref keys, ref pocs, controls, device-tail parameters, tail padding
+    assert C.sizeof(svtme.Picture) == 32 + 64 + 64 + 84 + 16 + 4
 
 
 def test_bad_arguments_are_rejected_without_touching_a_device():

@@ -101,6 +101,31 @@ def test_engine_results_through_the_host_tail_give_the_reference_final_state(nam
     assert not support.tail_mismatches(tail, g["b64"], pics, pruning)
 
 
+@pytest.mark.parametrize("name", GPU_CASES)
+def test_device_side_host_tail_matches_reference_final_state(name):
+    """tail.enable: me_prune_ref, candidate construction, distortions and GM detection on the device; every array the
+    reference's motion_estimation_b64 leaves behind (tests/golden/*.npz) is reproduced."""
+    c = MOD.CASES[name]
+    g = np.load(os.path.join(GOLDEN, name + ".npz"))
+    frames, pics, _ = support.make_job(c["width"], c["height"], c["n_frames"], c["enc_mode"], c["seed"],
+                                       c.get("structure", "ra"), c.get("kind", "synth"))
+    pd0 = g["pic"][0]
+    tail = svtme.Tail(enable=1, enable_me_8x8=int(pd0["enable_me_8x8"]), enable_me_16x16=int(pd0["enable_me_16x16"]),
+                      max_refs=int(pd0["max_refs"]), max_cand=int(pd0["max_cand"]), max_l0=int(pd0["max_l0"]),
+                      input_resolution=int(pd0["input_resolution"]), gm_enabled=1, gm_use_distance_based_active_th=1)
+    outs = support.run_engine_job(frames, pics, c["enc_mode"], c.get("sc_class1", 0), c.get("frame_rate", 30 << 16), tail=tail)
+    stat_names = ["rc_me_distortion", "me_64x64_distortion", "me_32x32_distortion", "me_16x16_distortion",
+                  "me_8x8_distortion", "me_8x8_cost_variance", "stationary_block_present_sb", "rc_me_allow_gm"]
+    for i, (p, out) in enumerate(zip(pics, outs)):
+        bd = g["b64"][i]
+        for f in ("total_me_candidate_index", "me_mv_array", "me_candidate_array", "me_distortion"):
+            assert np.array_equal(out[f], bd[f]), (name, p.poc, f)
+        for j, f in enumerate(stat_names):
+            assert np.array_equal(out["b64_stats"][:, j], bd[f].astype(np.uint32)), (name, p.poc, f)
+        assert np.array_equal(out["final_do_ref"], bd["do_ref"]), (name, p.poc, "do_ref")
+        assert np.array_equal(out["final_hme_sad"], bd["hme_sad"]), (name, p.poc, "hme_sad")
+
+
 def test_scheduler_runs_a_sequence_on_the_engine_with_store_reuse():
     """svtme.scheduler on the real engine: sources put when first needed and released after their last reader, with a
     store smaller than the sequence (slots are reused while pictures are in flight); bit-exact with the oracle."""
