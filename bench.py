@@ -100,6 +100,7 @@ def main():
     ap.add_argument("--search-streams", type=int, default=3, choices=[1, 2, 3])
     ap.add_argument("--kernel-steps", type=int, default=8, help="steps of the one-stream pass that times the kernels")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--device-tail-only", action="store_true", help="--device-tail, and do not copy the search arrays back")
     ap.add_argument("--device-tail", action="store_true",
                     help="also run me_prune_ref / candidate construction / distortions / GM detection on the device")
     args = ap.parse_args()
@@ -125,7 +126,7 @@ def main():
     n_refs = sum(len(p.refs[0]) + len(p.refs[1]) for p in pics)
 
     tail = None
-    if args.device_tail:
+    if args.device_tail or args.device_tail_only:
         from svtme import gop
         b0, b1, n0, n1 = gop.mrp_counts(wl["enc_mode"])
         l0, l1 = max(b0, n0), max(b1, n1)
@@ -133,7 +134,7 @@ def main():
         m = wl["enc_mode"]
         # pcs->enable_me_8x8 / enable_me_16x16 and the me_results sizes (EbPictureControlSet.c:83-117, :1533)
         no8 = 0 if m <= 8 else ((0 if res <= 4 else 1) if m <= 9 else ((0 if res <= 2 else 1) if m <= 11 else 1))
-        tail = svtme.Tail(enable=1, enable_me_8x8=0 if no8 else 1, enable_me_16x16=1 if m <= 12 else 0, max_refs=l0 + l1,
+        tail = svtme.Tail(enable=2 if args.device_tail_only else 1, enable_me_8x8=0 if no8 else 1, enable_me_16x16=1 if m <= 12 else 0, max_refs=l0 + l1,
                           max_cand=l0 + l1 + l0 * l1 + (l0 - 1) + (1 if l1 == 3 else 0), max_l0=l0, input_resolution=res,
                           gm_enabled=1, gm_use_distance_based_active_th=1)
 
@@ -265,7 +266,7 @@ def main():
             "kernels": {k_: {"avg_ms": v[1], "ops_per_launch": v[0], "tops": v[0] / (v[1] * 1e-3) / 1e12 if v[1] > 0 else 0.0}
                         for k_, v in kernels.items()},
             "picture_kernels_ms_in_timed_region": float(ms_shared[5]),  # first kernel start to last kernel end
-            "search_streams": args.search_streams, "device_tail": bool(args.device_tail),
+            "search_streams": args.search_streams, "device_tail": (2 if args.device_tail_only else 1) if tail is not None else 0,
             "store_put_pictures_per_s": upload_pps,
             "ops_by_stage": dict(zip(STAGES, [float(v) for v in ops])),
             "picture_ms_incl_d2h": float(ms[6]),

@@ -156,7 +156,8 @@ int svtme_store_read(svtme_engine *e, uint64_t key, int level, uint8_t *dst, siz
  * compute_distortion :2814-2865, perform_gm_detection :2688-2811), so that the host only copies finished
  * MotionEstimationResults and per-b64 statistics. All zero = off (the host runs that code itself). */
 typedef struct svtme_tail {
-    uint8_t enable;
+    uint8_t enable; /* 1: tail results in addition to the search arrays; 2: tail results only (p_sb_best_sad / p_sb_best_mv
+                       stay on the device and come back NULL), which halves the result copy */
     uint8_t enable_me_8x8; /* pcs->enable_me_8x8 */
     uint8_t enable_me_16x16; /* pcs->enable_me_16x16 */
     uint8_t max_refs; /* pcs->pa_me_data->max_refs, <= SVTME_TAIL_MV_STRIDE */

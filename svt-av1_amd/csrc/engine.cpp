@@ -80,7 +80,7 @@ struct Flight {
         tail_end  = (off_tdo + nb * 8 + 63) / 64 * 64;
     }
     size_t off_thme = 0, off_tmv = 0, off_tdist = 0, off_tstat = 0, off_tcand = 0, off_ttot = 0, off_tdo = 0, tail_end = 0;
-    bool   tail = false;
+    bool   tail = false, skip_search_arrays = false;
     // start, after each of the 2 HME and 3 ME kernels, after D2H
     hipEvent_t           ev[7] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
 };
@@ -298,6 +298,7 @@ extern "C" int svtme_picture_submit(svtme_engine *e, const svtme_picture *pic, s
     // not implemented on the device: full-SAD integer search (no preset selects it) and the screen-content rule
     // that shrinks later references' windows from the first reference's 64x64 result (EbMotionEstimation.c:1390-1399)
     if (k.me_search_method != 0 || (k.enable_me_sr_adjustment == 2 && k.me_early_exit_th == 0)) return SVTME_ERR_UNSUPPORTED;
+    if (pic->tail.enable > 2) return SVTME_ERR_BAD_ARG;
     if (pic->tail.enable &&
         (pic->tail.max_refs > SVTME_TAIL_MV_STRIDE || pic->tail.max_cand > SVTME_TAIL_CAND_STRIDE || pic->tail.max_cand < 1 ||
          pic->tail.max_refs < pic->tail.max_l0 + (pic->num_of_list_to_search == 2 ? pic->num_of_ref_pic_to_search[1] : 0) ||
@@ -415,7 +416,10 @@ extern "C" int svtme_picture_submit(svtme_engine *e, const svtme_picture *pic, s
     // the process stays within four hardware queues)
     const hipStream_t sc = n_sm >= 3 ? sm : e->s_copy;
     if (sc != sm) HIP_TRY(hipStreamWaitEvent(sc, f->ev[5], 0));
-    HIP_TRY(hipMemcpyAsync(f->h_res, f->d_res, f->tail ? f->tail_end : f->res_bytes, hipMemcpyDeviceToHost, sc));
+    // tail.enable == 2: the host wants finished results only, the best SAD / MV arrays (the first two blocks) stay on the device
+    f->skip_search_arrays = f->tail && pic->tail.enable == 2;
+    const size_t c0 = f->skip_search_arrays ? f->off_sr : 0, c1 = f->tail ? f->tail_end : f->res_bytes;
+    HIP_TRY(hipMemcpyAsync(f->h_res + c0, f->d_res + c0, c1 - c0, hipMemcpyDeviceToHost, sc));
     HIP_TRY(hipEventRecord(f->ev[6], sc));
     f->busy   = true;
     f->waited = false;
@@ -460,8 +464,8 @@ extern "C" int svtme_picture_wait(svtme_engine *e, svtme_ticket ticket, svtme_re
             if (slots[s * 8 + 7]) return SVTME_ERR_DEVICE;
     }
     out->n_b64                = f->n_b64;
-    out->p_sb_best_sad        = reinterpret_cast<const uint32_t *>(f->h_res);
-    out->p_sb_best_mv         = reinterpret_cast<const uint32_t *>(f->h_res + f->off_mv);
+    out->p_sb_best_sad        = f->skip_search_arrays ? nullptr : reinterpret_cast<const uint32_t *>(f->h_res);
+    out->p_sb_best_mv         = f->skip_search_arrays ? nullptr : reinterpret_cast<const uint32_t *>(f->h_res + f->off_mv);
     out->search_results       = reinterpret_cast<const svtme_search_result *>(f->h_res + f->off_sr);
     out->zz_sad               = reinterpret_cast<const uint32_t *>(f->h_res + f->off_zz);
     out->reduce_me_sr_divisor = reinterpret_cast<const uint32_t *>(f->h_res + f->off_div);
@@ -517,8 +521,8 @@ extern "C" int svtme_unpack_b64(const svtme_results *res, uint32_t b64_index, ui
                                 svtme_search_result *search_results, uint32_t *zz_sad, uint32_t *reduce_me_sr_divisor) {
     if (!res || b64_index >= res->n_b64) return SVTME_ERR_BAD_ARG;
     const size_t n = SVTME_MAX_LISTS * SVTME_MAX_REFS;
-    if (p_sb_best_sad) memcpy(p_sb_best_sad, res->p_sb_best_sad + (size_t)b64_index * n * SVTME_PU_COUNT, n * SVTME_PU_COUNT * 4);
-    if (p_sb_best_mv) memcpy(p_sb_best_mv, res->p_sb_best_mv + (size_t)b64_index * n * SVTME_PU_COUNT, n * SVTME_PU_COUNT * 4);
+    if (p_sb_best_sad && res->p_sb_best_sad) memcpy(p_sb_best_sad, res->p_sb_best_sad + (size_t)b64_index * n * SVTME_PU_COUNT, n * SVTME_PU_COUNT * 4);
+    if (p_sb_best_mv && res->p_sb_best_mv) memcpy(p_sb_best_mv, res->p_sb_best_mv + (size_t)b64_index * n * SVTME_PU_COUNT, n * SVTME_PU_COUNT * 4);
     if (search_results) memcpy(search_results, res->search_results + (size_t)b64_index * n, n * sizeof(svtme_search_result));
     if (zz_sad) memcpy(zz_sad, res->zz_sad + (size_t)b64_index * n, n * 4);
     if (reduce_me_sr_divisor) memcpy(reduce_me_sr_divisor, res->reduce_me_sr_divisor + (size_t)b64_index * n, n * 4);

@@ -227,12 +227,14 @@ class Engine:
         if rc:
             raise SvtmeError(rc, "svtme_picture_wait")
         n = r.n_b64
-        out = {
-            "best_sad": np.ctypeslib.as_array(r.p_sb_best_sad, (n, 2, 4, 85)),
-            "best_mv": np.ctypeslib.as_array(r.p_sb_best_mv, (n, 2, 4, 85)),
+        out = {}
+        if r.p_sb_best_sad:  # NULL for pictures submitted with tail.enable == 2
+            out["best_sad"] = np.ctypeslib.as_array(r.p_sb_best_sad, (n, 2, 4, 85))
+            out["best_mv"] = np.ctypeslib.as_array(r.p_sb_best_mv, (n, 2, 4, 85))
+        out.update({
             "zz_sad": np.ctypeslib.as_array(r.zz_sad, (n, 2, 4)),
             "sr_divisor": np.ctypeslib.as_array(r.reduce_me_sr_divisor, (n, 2, 4)),
-        }
+        })
         sr = np.frombuffer(C.string_at(r.search_results, n * 8 * 16), SEARCH_RESULT_DTYPE).reshape(n, 2, 4)
         out["search_results"] = sr
         if r.me_mv_array:  # the picture ran the host tail on the device

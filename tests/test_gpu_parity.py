@@ -126,6 +126,20 @@ def test_device_side_host_tail_matches_reference_final_state(name):
         assert np.array_equal(out["final_hme_sad"], bd["hme_sad"]), (name, p.poc, "hme_sad")
 
 
+def test_tail_only_results_leave_the_search_arrays_on_the_device():
+    frames, pics, _ = support.make_job(256, 128, 5, 8, seed=3)
+    tail = svtme.Tail(enable=1, enable_me_8x8=1, enable_me_16x16=1, max_refs=4, max_cand=9, max_l0=2, input_resolution=0,
+                      gm_enabled=1, gm_use_distance_based_active_th=1)
+    both = support.run_engine_job(frames, pics, 8, tail=tail)
+    tail.enable = 2
+    only = support.run_engine_job(frames, pics, 8, tail=tail)
+    for a, b in zip(both, only):
+        assert "best_sad" in a and "best_sad" not in b and "best_mv" not in b
+        for f in ("total_me_candidate_index", "me_mv_array", "me_candidate_array", "me_distortion", "b64_stats",
+                  "final_do_ref", "final_hme_sad", "zz_sad", "sr_divisor"):
+            assert np.array_equal(a[f], b[f]), f
+
+
 def test_scheduler_runs_a_sequence_on_the_engine_with_store_reuse():
     """svtme.scheduler on the real engine: sources put when first needed and released after their last reader, with a
     store smaller than the sequence (slots are reused while pictures are in flight); bit-exact with the oracle."""
