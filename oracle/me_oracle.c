@@ -250,6 +250,44 @@ int orc_derive_controls(const svtme_preset_key *k, svtme_controls *c) {
     return 0;
 }
 
+/* tf_set_me_hme_params_oq + tf_signal_derivation_me_kernel_oq, EbMotionEstimationProcess.c:554-629, with the HME level
+ * flags signal_derivation_multi_processes_oq sets per hme_me_level (EbPictureDecisionProcess.c:1816-1841) and the search
+ * method create_me_context_and_picture_control overrides for every block (EbTemporalFiltering.c:331). */
+int orc_derive_tf_controls(uint8_t level, svtme_controls *c) {
+    if (!c || level > 2) return -1;
+    memset(c, 0, sizeof(*c));
+    c->num_hme_sa_w = c->num_hme_sa_h = 2;
+    c->hme_l1_sa = sa(16, 16);
+    c->hme_l2_sa = sa(16, 16);
+    if (level == 0) {
+        c->hme_l0_sa.sa_min = sa(30, 30);
+        c->hme_l0_sa.sa_max = sa(60, 60);
+        c->me_sa.sa_min     = sa(60, 60);
+        c->me_sa.sa_max     = sa(120, 120);
+    } else if (level == 1) {
+        c->hme_l0_sa.sa_min = sa(16, 16);
+        c->hme_l0_sa.sa_max = sa(32, 32);
+        c->me_sa.sa_min     = sa(16, 16);
+        c->me_sa.sa_max     = sa(32, 32);
+    } else {
+        c->hme_l0_sa.sa_min = sa(8, 8);
+        c->hme_l0_sa.sa_max = sa(16, 16);
+        c->me_sa.sa_min     = sa(8, 4);
+        c->me_sa.sa_max     = sa(16, 8);
+    }
+    c->enable_hme_flag        = 1;
+    c->enable_hme_level0_flag = 1;
+    c->enable_hme_level1_flag = level <= 1;
+    c->enable_hme_level2_flag = level == 0;
+    c->hme_search_method      = 1; /* FULL_SAD_SEARCH */
+    c->me_search_method       = 0; /* SUB_SAD_SEARCH */
+    c->stat_factor            = 100;
+    /* set_me_hme_ref_prune_ctrls(0), :245-249 */
+    c->prune_ref_if_hme_sad_dev_bigger_than_th = 0xFFFF;
+    c->prune_ref_if_me_sad_dev_bigger_than_th  = 0xFFFF;
+    return 0;
+}
+
 /* ----------------------------------------------------------------------------------------------- ME context */
 
 typedef struct orc_search_info {
@@ -276,6 +314,7 @@ struct orc_ctx {
     uint8_t  cand_array[85 * REF_DUMP_MAX_CAND];
     uint32_t stat[6];
     uint8_t  stationary, allow_gm;
+    uint8_t  tf_exit; /* tf_use_pred_64x64_only_th == ~0 after the tf_me_exit_th test */
     /* scratch */
     svtme_sa_minmax hme_l0_sa; /* working copy, rescaled per reference */
     uint32_t        block_w, block_h;
@@ -694,8 +733,9 @@ static void orc_me_position(uint32_t *best_sad, uint32_t *best_mv, const uint8_t
     }
 }
 
-/* check_00_center :1170-1243 (open-loop form: no MCTF penalty). Returns the SAD at the (clipped) HME centre and
- * resets the centre to (0,0) when the zero vector is at least as good. */
+/* check_00_center :1170-1243. Returns the SAD at the (clipped) HME centre and resets the centre to (0,0) when the zero
+ * vector costs no more; for ME_MCTF a centre SAD above TF_HME_MV_SAD_TH (512) is weighted by TF_HME_MV_COST_WEIGHT
+ * (125 %) first (:37-38, :1231-1241; costs are SAD << COST_PRECISION, 8 bits). */
 static uint32_t orc_check_00(orc_ctx *c, const orc_pic *pic, int l, int r, int ox, int oy, int16_t *cx, int16_t *cy) {
     const orc_plane *cur = &pic->cur->lvl[2];
     const orc_plane *ref = &pic->ref[l][r]->lvl[2];
@@ -714,7 +754,9 @@ static uint32_t orc_check_00(orc_ctx *c, const orc_pic *pic, int l, int r, int o
     uint32_t hme_sad = orc_sad(orc_block_ptr(cur, ox, oy), cur->stride << 1, orc_block_ptr(ref, ox + *cx, oy + *cy),
                                ref->stride << 1, bh, bw) << 1;
     c->ops[0] += (uint64_t)bh * bw;
-    if (zero_sad <= hme_sad) *cx = *cy = 0; /* MIN(zero_cost, hme_cost) == zero_cost */
+    uint64_t zero_cost = (uint64_t)zero_sad << 8, hme_cost = (uint64_t)hme_sad << 8;
+    if (pic->me_type == 1 && hme_sad > 512) hme_cost = hme_cost * 125 / 100;
+    if (zero_cost <= hme_cost) *cx = *cy = 0; /* MIN(zero_cost, hme_cost) == zero_cost */
     return hme_sad;
 }
 
@@ -727,7 +769,8 @@ static void orc_integer_search(orc_ctx *c, const orc_pic *pic, int ox, int oy) {
             if (!c->do_ref[l][r]) continue;
             const orc_plane *ref = &pic->ref[l][r]->lvl[2];
             int16_t cx = c->sc_x[l][r], cy = c->sc_y[l][r];
-            const uint16_t dist = orc_scaled_dist(orc_dist(pic, l, r));
+            /* the growth of the area with distance is slowed down except for ME_MCTF, :1338-1341 */
+            const uint16_t dist = pic->me_type == 1 ? orc_dist(pic, l, r) : orc_scaled_dist(orc_dist(pic, l, r));
             int16_t w = (int16_t)ORC_MIN((int16_t)k->me_sa.sa_min.width * dist, k->me_sa.sa_max.width);
             int16_t h = (int16_t)ORC_MIN((int16_t)k->me_sa.sa_min.height * dist, k->me_sa.sa_max.height);
             w = (int16_t)((ORC_MAX(1, (int)(w / c->sr_div[l][r])) + 7) & ~0x07);
@@ -970,7 +1013,7 @@ static void orc_gm_detection(orc_ctx *c, const orc_pic *pic) {
 
 /* ------------------------------------------------------------------------------------------------ per b64 */
 
-/* motion_estimation_b64 :2930-3002 (ME_OPEN_LOOP) */
+/* motion_estimation_b64 :2930-3002 (ME_OPEN_LOOP and ME_MCTF) */
 static void orc_tail(orc_ctx *c, const orc_pic *pic);
 static void orc_dump(const orc_ctx *c, const orc_pic *pic, ref_b64_dump *out);
 
@@ -991,11 +1034,18 @@ void orc_me_b64(orc_ctx *c, const orc_pic *pic, uint32_t b64_index, ref_b64_dump
         if (k->enable_hme_level2_flag) orc_hme_l2(c, pic, ox, oy);
     }
     orc_final_centre(c, pic);
-    const int prune_ref = k->enable_hme_flag;
+    c->tf_exit = 0;
+    if (pic->me_type == 1 && c->hme_sad[0][0] < pic->tf_me_exit_th) { /* :2958-2962 */
+        c->tf_exit = 1;
+        memset(c->best_sad, 0, sizeof(c->best_sad)); /* not written by this block: dumped as zeros */
+        orc_dump(c, pic, out);
+        return;
+    }
+    const int prune_ref = k->enable_hme_flag && pic->me_type != 1;
     if (prune_ref && (k->enable_me_sr_adjustment || k->enable_me_hme_ref_pruning)) orc_hme_prune(c, pic);
     orc_integer_search(c, pic, ox, oy);
 
-    if (run_tail) orc_tail(c, pic);
+    if (run_tail && pic->me_type != 1) orc_tail(c, pic); /* :2977 */
     orc_dump(c, pic, out);
 }
 
@@ -1073,6 +1123,7 @@ static void orc_dump(const orc_ctx *c, const orc_pic *pic, ref_b64_dump *out) {
     out->me_8x8_cost_variance = c->stat[5];
     out->stationary_block_present_sb = c->stationary;
     out->rc_me_allow_gm              = c->allow_gm;
+    out->tf_me_exit                  = c->tf_exit;
 }
 
 /* ---------------------------------------------------------------------------------------------- per picture */

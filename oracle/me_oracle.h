@@ -34,6 +34,8 @@ int  orc_planes_build(orc_planes *p, const uint8_t *luma, uint32_t stride, uint3
 void orc_planes_free(orc_planes *p);
 
 int     orc_derive_controls(const svtme_preset_key *key, svtme_controls *out);
+/* tf_signal_derivation_me_kernel_oq (EbMotionEstimationProcess.c:554-629) for pcs->tf_ctrls.hme_me_level 0..2 */
+int     orc_derive_tf_controls(uint8_t hme_me_level, svtme_controls *out);
 uint8_t orc_input_resolution(uint32_t width, uint32_t height);
 
 typedef struct orc_pic {
@@ -47,6 +49,10 @@ typedef struct orc_pic {
     /* host-tail configuration (pcs / pa_me_data fields) */
     uint8_t enable_me_8x8, enable_me_16x16, max_cand, max_refs, max_l0, input_resolution;
     uint8_t gm_enabled, gm_use_distance_based_active_th;
+    /* MeContext::me_type: 0 = ME_OPEN_LOOP, 1 = ME_MCTF (temporal-filter search of one neighbour frame: one list, one
+     * reference, no pruning, no host tail), and MeContext::tf_me_exit_th */
+    uint8_t  me_type;
+    uint16_t tf_me_exit_th;
 } orc_pic;
 
 typedef struct orc_ctx orc_ctx; /* per-"thread" MeContext equivalent; state persists between b64s */

@@ -56,7 +56,11 @@ static void fill_pic(orc_pic *p, const ref_job_header *h, const ref_job_pic *jp,
     key.sc_class1 = jp->sc_class1;
     key.input_resolution = orc_input_resolution(h->width, h->height);
     key.frame_rate = jp->frame_rate;
-    if (orc_derive_controls(&key, &p->ctrl)) die("bad preset");
+    if (jp->me_type == 1) {
+        if (orc_derive_tf_controls(jp->tf_hme_me_level, &p->ctrl)) die("bad temporal-filter level");
+        p->me_type = 1;
+        p->tf_me_exit_th = jp->tf_me_exit_th;
+    } else if (orc_derive_controls(&key, &p->ctrl)) die("bad preset");
     p->input_resolution = key.input_resolution;
     p->enable_me_8x8 = enable_me_8x8(jp->enc_mode, key.input_resolution);
     p->enable_me_16x16 = jp->enc_mode <= 12; /* get_enable_me_16x16, EbPictureControlSet.c:90-99 */

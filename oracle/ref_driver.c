@@ -45,6 +45,7 @@ uint8_t get_disallow_below_16x16_picture_level(EbEncMode enc_mode, EbInputResolu
                                                uint8_t is_used_as_reference_flag,
                                                uint8_t temporal_layer_index);
 uint8_t get_enable_me_16x16(EbEncMode enc_mode);
+EbErrorType tf_signal_derivation_me_kernel_oq(PictureParentControlSet *pcs_ptr, MotionEstimationContext_t *context_ptr);
 void    get_max_allocated_me_refs(uint8_t ref_count_used_list0, uint8_t ref_count_used_list1,
                                   uint8_t *max_ref_to_alloc, uint8_t *max_cand_to_alloc);
 
@@ -237,6 +238,12 @@ static void setup_pic(const Job *job, uint32_t pi, PicState *st) {
     pcs->enable_me_8x8 = !get_disallow_below_16x16_picture_level(
         pcs->enc_mode, scs->input_resolution, B_SLICE, 0, 1, 0); /* EbPictureControlSet.c:1533 */
     pcs->enable_me_16x16 = get_enable_me_16x16(pcs->enc_mode);
+    /* temporal-filter HME level flags, EbPictureDecisionProcess.c:1816-1841 */
+    pcs->tf_ctrls.hme_me_level     = jp->tf_hme_me_level;
+    pcs->tf_enable_hme_flag        = 1;
+    pcs->tf_enable_hme_level0_flag = 1;
+    pcs->tf_enable_hme_level1_flag = jp->tf_hme_me_level <= 1;
+    pcs->tf_enable_hme_level2_flag = jp->tf_hme_me_level == 0;
     pcs->gm_ctrls.enabled = jp->gm_enabled;
     pcs->gm_ctrls.use_distance_based_active_th = jp->gm_dist_th;
 
@@ -345,6 +352,8 @@ static void dump_b64(ref_b64_dump *d, const MeContext *m, const PicState *st, ui
     d->me_8x8_cost_variance = pcs->me_8x8_cost_variance[b64];
     d->stationary_block_present_sb = pcs->stationary_block_present_sb[b64];
     d->rc_me_allow_gm = pcs->rc_me_allow_gm[b64];
+    d->tf_me_exit = m->me_type == ME_MCTF && m->tf_use_pred_64x64_only_th == (uint8_t)~0;
+    if (d->tf_me_exit) memset(d->best_sad, 0, sizeof(d->best_sad)); /* left over from the previous block */
 }
 
 typedef struct Worker {
@@ -370,8 +379,16 @@ static void *worker_main(void *arg) {
     if (!m) die("out of memory");
     me_context_ctor(m);
     mectx.me_context_ptr = m;
-    m->me_type = ME_OPEN_LOOP;
-    signal_derivation_me_kernel_oq(scs, pcs, &mectx);
+    if (jp->me_type == ME_MCTF) {
+        /* the temporal filter's ME thread: tf_signal_derivation_me_kernel_oq (EbMotionEstimationProcess.c:693-694), then per
+         * block create_me_context_and_picture_control (:302-331) and the MeContext set-up of :4844-4865 */
+        m->me_type = ME_MCTF;
+        tf_signal_derivation_me_kernel_oq(pcs, &mectx);
+        m->hme_search_method = FULL_SAD_SEARCH;
+    } else {
+        m->me_type = ME_OPEN_LOOP;
+        signal_derivation_me_kernel_oq(scs, pcs, &mectx);
+    }
 
     Planes *cur = &job->planes[jp->cur_frame];
     if (wk->dump && wk->row_begin == 0) {
@@ -401,7 +418,9 @@ static void *worker_main(void *arg) {
                                                                    cur->sixteenth.origin_x + (ox >> 2)];
                 m->sixteenth_b64_buffer_stride = cur->sixteenth.stride_y;
             }
-            m->me_type = ME_OPEN_LOOP;
+            m->me_type = jp->me_type == ME_MCTF ? ME_MCTF : ME_OPEN_LOOP;
+            m->tf_me_exit_th             = jp->tf_me_exit_th;
+            m->tf_use_pred_64x64_only_th = 0;
             m->num_of_list_to_search       = jp->n_list;
             m->num_of_ref_pic_to_search[0] = jp->n_ref[0];
             if (jp->n_list == 2) m->num_of_ref_pic_to_search[1] = jp->n_ref[1];

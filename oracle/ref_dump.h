@@ -47,6 +47,11 @@ typedef struct ref_job_pic {
     uint8_t  gm_dist_th;
     uint32_t ref_frame[2][4];
     uint64_t ref_poc[2][4];
+    /* temporal-filter searches (me_type 1 = ME_MCTF, EbMotionEstimationContext.h:46; 0 = ME_OPEN_LOOP): controls come
+     * from tf_signal_derivation_me_kernel_oq with pcs->tf_ctrls.hme_me_level, and MeContext::tf_me_exit_th */
+    uint8_t  me_type;
+    uint8_t  tf_hme_me_level;
+    uint16_t tf_me_exit_th;
 } ref_job_pic;
 
 typedef struct ref_out_header {
@@ -93,6 +98,10 @@ typedef struct ref_b64_dump {
     uint32_t rc_me_distortion, me_64x64_distortion, me_32x32_distortion, me_16x16_distortion,
         me_8x8_distortion, me_8x8_cost_variance;
     uint8_t stationary_block_present_sb, rc_me_allow_gm;
+    /* ME_MCTF only: 1 when motion_estimation_b64 returned at the tf_me_exit_th test (:2958-2961), i.e. it set
+     * tf_use_pred_64x64_only_th to ~0 and searched nothing; best_sad is then dumped as zeros (the reference leaves
+     * whatever the previous block wrote). */
+    uint8_t tf_me_exit;
 } ref_b64_dump;
 #pragma pack(pop)
 #endif

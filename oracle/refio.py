@@ -51,17 +51,19 @@ B64_DUMP = np.dtype([
     ("me_mv_array", "<u4", (85 * 7,)), ("me_candidate_array", "u1", (85 * 23,)),
     ("rc_me_distortion", "<u4"), ("me_64x64_distortion", "<u4"), ("me_32x32_distortion", "<u4"),
     ("me_16x16_distortion", "<u4"), ("me_8x8_distortion", "<u4"), ("me_8x8_cost_variance", "<u4"),
-    ("stationary_block_present_sb", "u1"), ("rc_me_allow_gm", "u1"),
+    ("stationary_block_present_sb", "u1"), ("rc_me_allow_gm", "u1"), ("tf_me_exit", "u1"),
 ])
 
 _HDR = "<8sIIIIIIIIII"
-_PIC = "<IIQiBBBBBBBB8I8Q"
+_PIC = "<IIQiBBBBBBBB8I8QBBH"
 _OUT = "<8sIIIIIIdQ"
 
 
 def write_job(path, frames, pics, enc_mode, *, mode=MODE_DUMP, threads=1, use_avx2=0, reps=1,
-              frame_rate=30 << 16, sc_class1=0, gm_enabled=0, gm_dist_th=0, ref_counts=(4, 3)):
-    """frames: uint8 [n, h, w]; pics: list of svtme.gop.Picture (refs are POCs = frame indices)."""
+              frame_rate=30 << 16, sc_class1=0, gm_enabled=0, gm_dist_th=0, ref_counts=(4, 3), tf=None):
+    """frames: uint8 [n, h, w]; pics: list of svtme.gop.Picture (refs are POCs = frame indices).
+    tf = (hme_me_level, me_exit_th) runs every picture as a temporal-filter search (ME_MCTF) of its first list-0
+    reference: the controls then come from tf_signal_derivation_me_kernel_oq and enc_mode is not used."""
     n, h, w = frames.shape
     with open(path, "wb") as f:
         f.write(struct.pack(_HDR, b"SVTMEJ01", w, h, n, len(pics), mode, threads, use_avx2, reps,
@@ -75,7 +77,7 @@ def write_job(path, frames, pics, enc_mode, *, mode=MODE_DUMP, threads=1, use_av
             n_list = 2 if p.refs[1] else 1
             f.write(struct.pack(_PIC, p.poc, frame_rate, p.poc, enc_mode, p.temporal_layer, p.is_ref, n_list,
                                 len(p.refs[0]), len(p.refs[1]), sc_class1, gm_enabled, gm_dist_th,
-                                *rf[0], *rf[1], *rf[0], *rf[1]))
+                                *rf[0], *rf[1], *rf[0], *rf[1], *((1, tf[0], tf[1]) if tf else (0, 0, 0))))
 
 
 def read_dump(path):

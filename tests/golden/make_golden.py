@@ -43,6 +43,41 @@ DIGEST_CASES = {
 }
 
 
+# temporal-filter searches (ME_MCTF): level = tf_ctrls.hme_me_level, exit_th = tf_ctrls.me_exit_th
+TF_CASES = {
+    "tf0_320x192": dict(width=320, height=192, n_frames=7, level=0, exit_th=0, seed=41),
+    "tf1_256x136": dict(width=256, height=136, n_frames=5, level=1, exit_th=0, seed=42, motion=(5, 3)),
+    "tf2_exit_256x192": dict(width=256, height=192, n_frames=5, level=2, exit_th=16 * 16, seed=43, kind="half_static"),
+    "tf1_noise_192x128": dict(width=192, height=128, n_frames=3, level=1, exit_th=0, seed=44, kind="noise"),
+    "tf2_flat_128x128": dict(width=128, height=128, n_frames=3, level=2, exit_th=16 * 16, seed=45, kind="flat"),
+    "tf0_exit_200x136": dict(width=200, height=136, n_frames=5, level=0, exit_th=16 * 16, seed=46, kind="half_static",
+                             motion=(-6, 4)),
+}
+TF_DIGEST_CASES = {
+    "tf0_1920x1080": dict(width=1920, height=1080, n_frames=3, level=0, exit_th=0, seed=51, motion=(7, -3)),
+    "tf2_exit_1280x720": dict(width=1280, height=720, n_frames=5, level=2, exit_th=16 * 16, seed=52, kind="half_static"),
+}
+
+
+def tf_job(c):
+    frames, pics = support.make_tf_job(c["width"], c["height"], c["n_frames"], c["seed"], c.get("kind", "synth"),
+                                       c.get("motion", (3, -2)))
+    return frames, pics, dict(tf=(c["level"], c["exit_th"]))
+
+
+def run_tf_case(c, threads=1):
+    frames, pics, kw = tf_job(c)
+    hdr, recs = refio.run_reference(frames, pics, 0, threads=threads, use_avx2=0, **kw)
+    return frames, pics, recs
+
+
+def tf_canonical(bd):
+    """What a temporal-filter search leaves behind for list 0 / reference 0."""
+    out = {f: np.ascontiguousarray(bd[f][:, 0, 0]) for f in ("best_sad", "best_mv", "hme_sc_x", "hme_sc_y", "hme_sad")}
+    out["tf_me_exit"] = np.ascontiguousarray(bd["tf_me_exit"])
+    return out
+
+
 def run_case(c, threads=1):
     frames, pics, rc = support.make_job(c["width"], c["height"], c["n_frames"], c["enc_mode"], c["seed"],
                                         c.get("structure", "ra"), c.get("kind", "synth"))
@@ -62,7 +97,22 @@ def main():
         np.savez_compressed(os.path.join(HERE, name + ".npz"), pic=pd, b64=bd,
                             frames_sha256=np.array(hashlib.sha256(frames.tobytes()).hexdigest()))
         print(name, "pics", len(pics), "b64", bd.shape[1], "bytes", os.path.getsize(os.path.join(HERE, name + ".npz")))
+    for name, c in TF_CASES.items():
+        frames, pics, recs = run_tf_case(c)
+        pd = np.stack([r[0] for r in recs])
+        bd = np.stack([r[1] for r in recs])
+        np.savez_compressed(os.path.join(HERE, name + ".npz"), pic=pd, b64=bd,
+                            frames_sha256=np.array(hashlib.sha256(frames.tobytes()).hexdigest()))
+        print(name, "pairs", len(pics), "b64", bd.shape[1], "exits", int(bd["tf_me_exit"].sum()), "bytes",
+              os.path.getsize(os.path.join(HERE, name + ".npz")))
     digests = {}
+    for name, c in TF_DIGEST_CASES.items():
+        frames, pics, recs = run_tf_case(c, threads=8)
+        d = {"frames_sha256": hashlib.sha256(frames.tobytes()).hexdigest(), "pictures": []}
+        for (pd, bd) in recs:
+            d["pictures"].append({f: hashlib.sha256(v.tobytes()).hexdigest() for f, v in tf_canonical(bd).items()})
+        digests[name] = d
+        print(name, "digested", len(recs), "pairs")
     for name, c in DIGEST_CASES.items():
         frames, pics, recs = run_case(c, threads=8)
         d = {"frames_sha256": hashlib.sha256(frames.tobytes()).hexdigest(), "pictures": []}
@@ -72,7 +122,8 @@ def main():
         digests[name] = d
         print(name, "digested", len(recs), "pictures")
     with open(os.path.join(HERE, "digests.json"), "w") as f:
-        json.dump({"cases": {k: {kk: vv for kk, vv in v.items()} for k, v in DIGEST_CASES.items()}, "digests": digests}, f, indent=1)
+        json.dump({"cases": {k: dict(v) for k, v in list(DIGEST_CASES.items()) + list(TF_DIGEST_CASES.items())},
+                   "digests": digests}, f, indent=1)
 
 
 if __name__ == "__main__":

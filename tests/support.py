@@ -28,6 +28,21 @@ def make_job(width, height, n_frames, enc_mode, seed=1, structure="ra", kind="sy
     return frames, pics, (max(b0, n0), max(b1, n1))
 
 
+def make_tf_job(width, height, n_frames, seed=1, kind="synth", motion=(3, -2)):
+    """A temporal-filter window: the centre frame searched in every other frame of the window, one (centre, neighbour)
+    pair per picture as the temporal filter's block loop does (EbTemporalFiltering.c:4844-4873). kind "half_static"
+    freezes the left half of every frame so that those blocks take the tf_me_exit_th exit."""
+    if kind in ("synth", "half_static"):
+        frames = synth.synth_sequence(width, height, n_frames, seed=seed, motion=motion)
+        if kind == "half_static":
+            frames[:, :, :width // 2] = frames[0, :, :width // 2]
+    else:
+        frames = synth.extreme_sequence(width, height, n_frames, kind, seed=seed)
+    c = n_frames // 2
+    pics = [gop.Picture(poc=c, temporal_layer=0, is_ref=1, refs=[[j], []]) for j in range(n_frames) if j != c]
+    return frames, pics
+
+
 def oracle_handover(frames, pics, enc_mode, ref_counts, threads=8, **kw):
     """Oracle state right after integer_search_b64 for every picture: list of b64 record arrays."""
     _, recs = refio.run_oracle(frames, pics, enc_mode, mode=refio.MODE_DUMP_NOTAIL, threads=threads,
