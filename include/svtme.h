@@ -109,6 +109,14 @@ typedef struct svtme_preset_key {
  */
 int svtme_derive_controls(const svtme_preset_key *key, svtme_controls *out);
 
+/*
+ * Controls of the temporal filter's motion search: tf_signal_derivation_me_kernel_oq() with tf_set_me_hme_params_oq()
+ * (EbMotionEstimationProcess.c:554-629) for pcs->tf_ctrls.hme_me_level 0..2, the HME level flags
+ * signal_derivation_multi_processes_oq() sets for that level (EbPictureDecisionProcess.c:1816-1841) and the
+ * FULL_SAD_SEARCH HME method create_me_context_and_picture_control() forces per block (EbTemporalFiltering.c:331).
+ */
+int svtme_derive_tf_controls(uint8_t hme_me_level, svtme_controls *out);
+
 /* derive_input_resolution(), Source/Lib/Encoder/Codec/EbSequenceControlSet.c:396-415. */
 uint8_t svtme_input_resolution(uint32_t width, uint32_t height);
 
@@ -171,8 +179,22 @@ typedef struct svtme_tail {
 #define SVTME_TAIL_MV_STRIDE 7 /* MAX_PA_ME_MV, EbMotionEstimationLcuResults.h:23 */
 #define SVTME_TAIL_CAND_STRIDE 23 /* MAX_PA_ME_CAND, :24 */
 
+/* MeContext::me_type (EbMotionEstimationContext.h:44-50). */
+#define SVTME_ME_OPEN_LOOP 0 /* ME_OPEN_LOOP: the pre-analysis search of motion_estimation_kernel() */
+#define SVTME_ME_MCTF 1 /* ME_MCTF: the temporal filter's search of one neighbour frame */
+
 /* One picture's ME job: what motion_estimation_kernel() sets on MeContext before the b64 loop
- * (EbMotionEstimationProcess.c:795-837) plus the pcs/scs fields integer_search_b64 reads. */
+ * (EbMotionEstimationProcess.c:795-837) plus the pcs/scs fields integer_search_b64 reads.
+ *
+ * me_type = SVTME_ME_MCTF runs the temporal filter's form of motion_estimation_b64 for all blocks of one
+ * (centre frame, neighbour frame) pair (EbTemporalFiltering.c:4835-4873 per block): cur_key = the centre frame, one
+ * list with one reference = the neighbour, ctrl from svtme_derive_tf_controls(), temporal_layer_index /
+ * is_used_as_reference_flag of the centre picture. The differences (EbMotionEstimation.c): the integer search area grows
+ * with the plain picture distance (:1338-1341); check_00_center weights a search-centre SAD above 512 by 125 % before
+ * comparing it with the zero vector (:1231-1241); no reference pruning or search-range adjustment (:2952); a block whose
+ * HME SAD is below tf_me_exit_th is not searched at all (:2958-2962): its search_results[0][0].tf_me_exit is 1 (the
+ * caller sets tf_use_pred_64x64_only_th = ~0) and its minima read as zero; tail must be off (:2977). The
+ * tf_tot_horz_blks / tf_tot_vert_blks counters (:2365-2370) follow from search_results[0][0].hme_sc_x / hme_sc_y. */
 typedef struct svtme_picture {
     uint64_t cur_key; /* store key of the current picture */
     uint64_t picture_number; /* pcs->picture_number */
@@ -182,11 +204,13 @@ typedef struct svtme_picture {
     uint8_t  is_used_as_reference_flag;
     uint8_t  num_of_list_to_search; /* 1 for P, 2 for B */
     uint8_t  num_of_ref_pic_to_search[SVTME_MAX_LISTS]; /* ref_list{0,1}_count_try */
-    uint8_t  reserved[3];
+    uint8_t  me_type; /* SVTME_ME_OPEN_LOOP or SVTME_ME_MCTF */
+    uint8_t  reserved[2];
     uint64_t ref_key[SVTME_MAX_LISTS][SVTME_MAX_REFS]; /* store keys of pcs->ref_pa_pic_ptr_array */
     uint64_t ref_picture_number[SVTME_MAX_LISTS][SVTME_MAX_REFS];
     svtme_controls ctrl;
     svtme_tail     tail;
+    uint32_t       tf_me_exit_th; /* MeContext::tf_me_exit_th = pcs->tf_ctrls.me_exit_th; SVTME_ME_MCTF only */
 } svtme_picture;
 
 /* SearchResults, EbMotionEstimationContext.h:330-337, as left by hme_prune_ref_and_adjust_sr. */
@@ -196,7 +220,7 @@ typedef struct svtme_search_result {
     uint8_t  do_ref;
     uint8_t  list_i;
     uint8_t  ref_i;
-    uint8_t  reserved;
+    uint8_t  tf_me_exit; /* SVTME_ME_MCTF, entry [0][0] only: 1 = the block left at the tf_me_exit_th test */
     uint64_t hme_sad;
 } svtme_search_result;
 

@@ -73,6 +73,30 @@ extern "C" uint8_t svtme_input_resolution(uint32_t width, uint32_t height) {
     return r;
 }
 
+extern "C" int svtme_derive_tf_controls(uint8_t hme_me_level, svtme_controls *c) {
+    if (!c || hme_me_level > 2) return SVTME_ERR_BAD_ARG;
+    memset(c, 0, sizeof(*c));
+    // tf_set_me_hme_params_oq, EbMotionEstimationProcess.c:557-591: {HME level-0 area, integer search area} per level
+    static const svtme_sa_minmax l0_area[3] = {{{30, 30}, {60, 60}}, {{16, 16}, {32, 32}}, {{8, 8}, {16, 16}}};
+    static const svtme_sa_minmax me_area_tf[3] = {{{60, 60}, {120, 120}}, {{16, 16}, {32, 32}}, {{8, 4}, {16, 8}}};
+    c->num_hme_sa_w = c->num_hme_sa_h = 2;
+    c->hme_l0_sa = l0_area[hme_me_level];
+    c->me_sa     = me_area_tf[hme_me_level];
+    c->hme_l1_sa = c->hme_l2_sa = svtme_sa{16, 16};
+    // tf_enable_hme_*_flag, EbPictureDecisionProcess.c:1816-1841
+    c->enable_hme_flag        = 1;
+    c->enable_hme_level0_flag = 1;
+    c->enable_hme_level1_flag = hme_me_level <= 1;
+    c->enable_hme_level2_flag = hme_me_level == 0;
+    c->hme_search_method = 1; // FULL_SAD_SEARCH, EbTemporalFiltering.c:331 (overrides :609)
+    c->me_search_method  = 0; // SUB_SAD_SEARCH :611
+    // no pre-HME, no pruning, no search-range adjustment, no early exit :613-627
+    c->prune_ref_if_hme_sad_dev_bigger_than_th = 0xFFFF;
+    c->prune_ref_if_me_sad_dev_bigger_than_th  = 0xFFFF;
+    c->stat_factor = 100;
+    return SVTME_OK;
+}
+
 extern "C" int svtme_derive_controls(const svtme_preset_key *key, svtme_controls *c) {
     if (!key || !c) return SVTME_ERR_BAD_ARG;
     const int m = key->enc_mode, sc = key->sc_class1 != 0, res = key->input_resolution;

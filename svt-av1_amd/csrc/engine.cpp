@@ -298,7 +298,12 @@ extern "C" int svtme_picture_submit(svtme_engine *e, const svtme_picture *pic, s
     // not implemented on the device: full-SAD integer search (no preset selects it) and the screen-content rule
     // that shrinks later references' windows from the first reference's 64x64 result (EbMotionEstimation.c:1390-1399)
     if (k.me_search_method != 0 || (k.enable_me_sr_adjustment == 2 && k.me_early_exit_th == 0)) return SVTME_ERR_UNSUPPORTED;
-    if (pic->tail.enable > 2) return SVTME_ERR_BAD_ARG;
+    if (pic->tail.enable > 2 || pic->me_type > SVTME_ME_MCTF) return SVTME_ERR_BAD_ARG;
+    // the temporal filter searches one neighbour frame at a time and has no host tail (EbTemporalFiltering.c:4844-4847,
+    // EbMotionEstimation.c:2977)
+    if (pic->me_type == SVTME_ME_MCTF &&
+        (pic->num_of_list_to_search != 1 || pic->num_of_ref_pic_to_search[0] != 1 || pic->tail.enable))
+        return SVTME_ERR_BAD_ARG;
     if (pic->tail.enable &&
         (pic->tail.max_refs > SVTME_TAIL_MV_STRIDE || pic->tail.max_cand > SVTME_TAIL_CAND_STRIDE || pic->tail.max_cand < 1 ||
          pic->tail.max_refs < pic->tail.max_l0 + (pic->num_of_list_to_search == 2 ? pic->num_of_ref_pic_to_search[1] : 0) ||
@@ -344,6 +349,8 @@ extern "C" int svtme_picture_submit(svtme_engine *e, const svtme_picture *pic, s
     p.b64_h  = (int32_t)((pic->height + 63) / 64);
     p.temporal_layer = pic->temporal_layer_index;
     p.is_ref = pic->is_used_as_reference_flag;
+    p.me_type       = pic->me_type;
+    p.tf_me_exit_th = pic->tf_me_exit_th;
     // a reference depends on an earlier one: pre-HME list-1 early exit (:1758-1768) and the HME level-0 area
     // rescaling from the first reference's vector (:1837-1851)
     p.serial_refs = (k.prehme_enable && k.prehme_l1_early_exit && p.n_list == 2) ||

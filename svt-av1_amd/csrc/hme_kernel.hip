@@ -40,7 +40,7 @@ struct HmeShared {
     SubSearch sub[4];
     Band      band[HME_MAX_BANDS];
     int       n_band, n_batch;
-    uint32_t  src[HME_SRC_PITCH * 32];
+    uint32_t  src[HME_SRC_PITCH * 64]; // up to 64 rows: a full-resolution block with FULL_SAD_SEARCH
     uint32_t  red;
     HmeRefOut cur; // results of the reference being processed
     // state carried between references in serial mode

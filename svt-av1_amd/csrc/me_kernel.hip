@@ -150,7 +150,7 @@ __global__ void __launch_bounds__(ME_THREADS) me_plan_kernel(PicParams p) {
             S.div[i]    = 1;
         }
         // ---- hme_prune_ref_and_adjust_sr (:2373-2410), over all 2x4 entries
-        if (k.enable_hme_flag && (k.enable_me_sr_adjustment || k.enable_me_hme_ref_pruning)) {
+        if (k.enable_hme_flag && p.me_type != SVTME_ME_MCTF && (k.enable_me_sr_adjustment || k.enable_me_hme_ref_pruning)) {
             u64 best = ~0ull;
             for (int i = 0; i < 8; ++i) best = S.hsad[i] < best ? S.hsad[i] : best;
             const uint32_t th = k.prune_ref_if_hme_sad_dev_bigger_than_th;
@@ -179,7 +179,8 @@ __global__ void __launch_bounds__(ME_THREADS) me_plan_kernel(PicParams p) {
         o.do_ref   = S.do_ref[tid];
         o.list_i   = (uint8_t)l;
         o.ref_i    = (uint8_t)r;
-        o.reserved = 0;
+        // temporal filter: a block that is already well predicted is not searched (:2958-2962)
+        o.tf_me_exit = p.me_type == SVTME_ME_MCTF && tid == 0 && S.hsad[0] < p.tf_me_exit_th;
         o.hme_sad  = S.hsad[tid];
         p.sr_divisor[b64 * 8 + tid] = S.div[tid];
         const bool have = l < p.n_list && r < p.n_ref[l];
@@ -188,7 +189,7 @@ __global__ void __launch_bounds__(ME_THREADS) me_plan_kernel(PicParams p) {
     const int my = my_l * 4 + my_r;
     MeJob    *job = &p.me_jobs[b64 * 8 + my];
     for (int pu = tid; pu < SVTME_PU_COUNT; pu += ME_THREADS) p.me_keys[(size_t)(b64 * 8 + my) * SVTME_PU_COUNT + pu] = ~0ull;
-    if (!S.do_ref[my]) {
+    if (!S.do_ref[my] || (p.me_type == SVTME_ME_MCTF && S.hsad[0] < p.tf_me_exit_th)) {
         if (tid == 0) *job = MeJob{0, 0, 0, 0};
         return;
     }
@@ -197,7 +198,8 @@ __global__ void __launch_bounds__(ME_THREADS) me_plan_kernel(PicParams p) {
     const DevPlane &cur = p.cur.lvl[2];
     const DevPlane &ref = p.ref[my_l][my_r].lvl[2];
     int16_t         cx = S.sc_x[my], cy = S.sc_y[my];
-    const int       dist = scaled_dist(p.dist[my_l][my_r]);
+    // the growth of the area with the distance is slowed down, except for the temporal filter (:1338-1341)
+    const int       dist = p.me_type == SVTME_ME_MCTF ? p.dist[my_l][my_r] : scaled_dist(p.dist[my_l][my_r]);
     int16_t         w = (int16_t)min((int)(int16_t)k.me_sa.sa_min.width * dist, (int)k.me_sa.sa_max.width);
     int16_t         h = (int16_t)min((int)(int16_t)k.me_sa.sa_min.height * dist, (int)k.me_sa.sa_max.height);
     w = (int16_t)((max(1, (int)((uint32_t)w / S.div[my])) + 7) & ~0x07);
@@ -218,7 +220,11 @@ __global__ void __launch_bounds__(ME_THREADS) me_plan_kernel(PicParams p) {
             const uint32_t hme_sad = wg_block_sad(cur, ref, b64x, b64y, cx, cy, block_w, block_h >> 1, 2, &S.red) << 1;
             best_hme_sad           = hme_sad;
             if (tid == 0) count_ops(p, 0, 2ull * (block_h >> 1) * block_w);
-            if (zero_sad <= hme_sad) cx = cy = 0;
+            // costs are SAD << COST_PRECISION; the temporal filter weights a poor centre by TF_HME_MV_COST_WEIGHT
+            // (125 %) when its SAD exceeds TF_HME_MV_SAD_TH (512), :37-38, :1231-1241
+            u64 zero_cost = (u64)zero_sad << 8, hme_cost = (u64)hme_sad << 8;
+            if (p.me_type == SVTME_ME_MCTF && hme_sad > 512) hme_cost = hme_cost * 125 / 100;
+            if (zero_cost <= hme_cost) cx = cy = 0;
             if (cx == 0 && cy == 0) accurate = 0;
         }
         if (k.enable_me_sr_adjustment == 2) {

@@ -75,19 +75,23 @@ class Picture(C.Structure):
     _fields_ = [
         ("cur_key", C.c_uint64), ("picture_number", C.c_uint64), ("width", C.c_uint32), ("height", C.c_uint32),
         ("temporal_layer_index", C.c_uint8), ("is_used_as_reference_flag", C.c_uint8),
-        ("num_of_list_to_search", C.c_uint8), ("num_of_ref_pic_to_search", C.c_uint8 * 2), ("reserved", C.c_uint8 * 3),
+        ("num_of_list_to_search", C.c_uint8), ("num_of_ref_pic_to_search", C.c_uint8 * 2), ("me_type", C.c_uint8),
+        ("reserved", C.c_uint8 * 2),
         ("ref_key", (C.c_uint64 * MAX_REFS) * MAX_LISTS), ("ref_picture_number", (C.c_uint64 * MAX_REFS) * MAX_LISTS),
-        ("ctrl", Controls), ("tail", Tail),
+        ("ctrl", Controls), ("tail", Tail), ("tf_me_exit_th", C.c_uint32),
     ]
+
+
+ME_OPEN_LOOP, ME_MCTF = 0, 1
 
 
 class SearchResult(C.Structure):
     _fields_ = [("hme_sc_x", C.c_int16), ("hme_sc_y", C.c_int16), ("do_ref", C.c_uint8), ("list_i", C.c_uint8),
-                ("ref_i", C.c_uint8), ("reserved", C.c_uint8), ("hme_sad", C.c_uint64)]
+                ("ref_i", C.c_uint8), ("tf_me_exit", C.c_uint8), ("hme_sad", C.c_uint64)]
 
 
 SEARCH_RESULT_DTYPE = np.dtype([("hme_sc_x", "<i2"), ("hme_sc_y", "<i2"), ("do_ref", "u1"), ("list_i", "u1"),
-                                ("ref_i", "u1"), ("reserved", "u1"), ("hme_sad", "<u8")])
+                                ("ref_i", "u1"), ("tf_me_exit", "u1"), ("hme_sad", "<u8")])
 assert SEARCH_RESULT_DTYPE.itemsize == C.sizeof(SearchResult) == 16
 
 
@@ -101,7 +105,7 @@ class Results(C.Structure):
                 ("final_hme_sad", C.POINTER(C.c_uint64))]
 
 
-EXPORTS = ("svtme_version", "svtme_derive_controls", "svtme_input_resolution", "svtme_create", "svtme_destroy",
+EXPORTS = ("svtme_version", "svtme_derive_controls", "svtme_derive_tf_controls", "svtme_input_resolution", "svtme_create", "svtme_destroy",
            "svtme_store_put", "svtme_store_release", "svtme_store_read", "svtme_picture_submit", "svtme_picture_wait",
            "svtme_picture_done", "svtme_picture_timing", "svtme_picture_ops", "svtme_unpack_b64")
 
@@ -118,6 +122,7 @@ def load_library():
     lib = C.CDLL(LIB_PATH)
     lib.svtme_version.restype = C.c_char_p
     lib.svtme_derive_controls.argtypes = [C.POINTER(PresetKey), C.POINTER(Controls)]
+    lib.svtme_derive_tf_controls.argtypes = [C.c_uint8, C.POINTER(Controls)]
     lib.svtme_input_resolution.argtypes = [C.c_uint32, C.c_uint32]
     lib.svtme_input_resolution.restype = C.c_uint8
     lib.svtme_create.argtypes = [C.POINTER(Config), C.POINTER(C.c_void_p)]
@@ -146,6 +151,15 @@ def derive_controls(enc_mode, width, height, sc_class1=0, frame_rate=30 << 16):
     rc = load_library().svtme_derive_controls(C.byref(key), C.byref(c))
     if rc:
         raise SvtmeError(rc, "svtme_derive_controls")
+    return c
+
+
+def derive_tf_controls(hme_me_level):
+    """Controls of the temporal filter's motion search for tf_ctrls.hme_me_level 0..2."""
+    c = Controls()
+    rc = load_library().svtme_derive_tf_controls(hme_me_level, C.byref(c))
+    if rc:
+        raise SvtmeError(rc, "svtme_derive_tf_controls")
     return c
 
 
@@ -194,8 +208,10 @@ class Engine:
         rows = ph.value + 2 * pad.value
         return buf[:rows * st.value].reshape(rows, st.value).copy()
 
-    def make_picture(self, width, height, poc, temporal_layer, is_ref, refs, ctrl, key_of=lambda poc: poc, tail=None):
-        """refs: [[pocs of list 0], [pocs of list 1]]; tail: a Tail to run the host tail on the device too."""
+    def make_picture(self, width, height, poc, temporal_layer, is_ref, refs, ctrl, key_of=lambda poc: poc, tail=None,
+                     tf_me_exit_th=None):
+        """refs: [[pocs of list 0], [pocs of list 1]]; tail: a Tail to run the host tail on the device too;
+        tf_me_exit_th: not None makes it a temporal-filter search (ME_MCTF) of refs[0][0] with that exit threshold."""
         p = Picture()
         p.cur_key = key_of(poc)
         p.picture_number = poc
@@ -211,6 +227,9 @@ class Engine:
         p.ctrl = ctrl
         if tail is not None:
             p.tail = tail
+        if tf_me_exit_th is not None:
+            p.me_type = ME_MCTF
+            p.tf_me_exit_th = tf_me_exit_th
         return p
 
     def submit(self, pic):

@@ -103,6 +103,33 @@ def run_engine_job(frames, pics, enc_mode, sc_class1=0, frame_rate=30 << 16, eng
             eng.close()
 
 
+def run_engine_tf_job(frames, pics, level, exit_th, engine=None):
+    """Temporal-filter searches (ME_MCTF) of a make_tf_job window through the engine's C ABI."""
+    import svtme
+    n, h, w = frames.shape
+    own = engine is None
+    eng = engine or svtme.Engine(w, h, store_slots=n + 1, max_in_flight=2)
+    try:
+        for i in range(n):
+            eng.store_put(i, i, frames[i])
+        ctrl = svtme.derive_tf_controls(level)
+        outs = []
+        for p in pics:
+            pic = eng.make_picture(w, h, p.poc, p.temporal_layer, p.is_ref, p.refs, ctrl, tf_me_exit_th=exit_th)
+            outs.append(eng.run_picture(pic))
+        return outs
+    finally:
+        if own:
+            eng.close()
+
+
+def tf_fields(out):
+    """What a temporal-filter search hands back, in the shape of make_golden.tf_canonical."""
+    sr = out["search_results"]
+    return {"best_sad": out["best_sad"][:, 0, 0], "best_mv": out["best_mv"][:, 0, 0], "hme_sc_x": sr["hme_sc_x"][:, 0, 0],
+            "hme_sc_y": sr["hme_sc_y"][:, 0, 0], "hme_sad": sr["hme_sad"][:, 0, 0], "tf_me_exit": sr["tf_me_exit"][:, 0, 0]}
+
+
 def engine_vs_oracle(width, height, n_frames, enc_mode, seed=1, structure="ra", kind="synth", sc_class1=0,
                      frame_rate=30 << 16, max_msgs=12):
     frames, pics, rc = make_job(width, height, n_frames, enc_mode, seed, structure, kind)

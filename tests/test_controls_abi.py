@@ -31,8 +31,8 @@ def test_struct_sizes_match_the_header():
     assert C.sizeof(svtme.Controls) == 84 == refio.CONTROLS.itemsize
     assert C.sizeof(svtme.SearchResult) == 16
     assert C.sizeof(svtme.Tail) == 16
-    # keys/poc/geometry, ref keys, ref pocs, controls, device-tail parameters, tail padding
-    assert C.sizeof(svtme.Picture) == 32 + 64 + 64 + 84 + 16 + 4
+    # keys/poc/geometry, ref keys, ref pocs, controls, device-tail parameters, tf_me_exit_th
+    assert C.sizeof(svtme.Picture) == 32 + 64 + 64 + 84 + 16 + 4  # tf_me_exit_th closes the struct
 
 
 def test_bad_arguments_are_rejected_without_touching_a_device():
@@ -101,3 +101,28 @@ def test_derive_controls_equals_oracle_for_every_preset():
                     assert bytes(a) == bytes(b), (m, sc, res, fps, _as_np(a), _as_np(b))
                     n += 1
     assert n == 16 * 2 * 7 * 4
+
+
+def test_derive_tf_controls_equals_reference_goldens_and_oracle():
+    """Temporal-filter controls: golden controls dumped after tf_signal_derivation_me_kernel_oq + the per-block
+    FULL_SAD_SEARCH override, for every hme_me_level, and the oracle's restatement."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("make_golden", os.path.join(HERE, "golden", "make_golden.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    levels = set()
+    for name, c in mod.TF_CASES.items():
+        g = np.load(os.path.join(HERE, "golden", name + ".npz"))
+        mine = _as_np(svtme.derive_tf_controls(c["level"]))
+        for pd in g["pic"]:
+            assert mine.tobytes() == pd["ctrl"].tobytes(), (name, mine, pd["ctrl"])
+        levels.add(c["level"])
+    assert levels == {0, 1, 2}
+    orc = C.CDLL(os.path.join(ROOT, "oracle", "build", "libme_oracle.so"))
+    orc.orc_derive_tf_controls.argtypes = [C.c_uint8, C.POINTER(svtme.Controls)]
+    for lvl in range(3):
+        b = svtme.Controls()
+        assert orc.orc_derive_tf_controls(lvl, C.byref(b)) == 0
+        assert bytes(svtme.derive_tf_controls(lvl)) == bytes(b)
+    with pytest.raises(svtme.SvtmeError):
+        svtme.derive_tf_controls(3)

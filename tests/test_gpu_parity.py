@@ -186,6 +186,68 @@ def test_engine_matches_reference_digests_at_full_size(name):
             assert hashlib.sha256(np.ascontiguousarray(v).tobytes()).hexdigest() == dig["pictures"][i][f], (name, i, p.poc, f)
 
 
+@pytest.mark.parametrize("name", sorted(MOD.TF_CASES))
+def test_temporal_filter_search_matches_reference_goldens(name):
+    """ME_MCTF pairs (centre frame, neighbour frame): minima, vectors, search centre, HME SAD and the tf_me_exit_th exit
+    flag of every block against the real reference's dump (tests/golden/tf*.npz)."""
+    c = MOD.TF_CASES[name]
+    g = np.load(os.path.join(GOLDEN, name + ".npz"))
+    frames, pics, _ = MOD.tf_job(c)
+    outs = support.run_engine_tf_job(frames, pics, c["level"], c["exit_th"])
+    for i, (p, out) in enumerate(zip(pics, outs)):
+        want = MOD.tf_canonical(g["b64"][i])
+        for f, v in support.tf_fields(out).items():
+            assert np.array_equal(v, want[f]), (name, "neighbour %d" % p.refs[0][0], f)
+        assert np.array_equal(out["search_results"]["do_ref"][:, 0, 0], np.ones(len(v), np.uint8))
+
+
+@pytest.mark.parametrize("name", sorted(MOD.TF_DIGEST_CASES))
+def test_temporal_filter_search_matches_reference_digests_at_full_size(name):
+    with open(os.path.join(GOLDEN, "digests.json")) as f:
+        dig = json.load(f)["digests"][name]
+    c = MOD.TF_DIGEST_CASES[name]
+    frames, pics, _ = MOD.tf_job(c)
+    assert hashlib.sha256(frames.tobytes()).hexdigest() == dig["frames_sha256"]
+    outs = support.run_engine_tf_job(frames, pics, c["level"], c["exit_th"])
+    for i, out in enumerate(outs):
+        for f, v in support.tf_fields(out).items():
+            assert hashlib.sha256(np.ascontiguousarray(v).tobytes()).hexdigest() == dig["pictures"][i][f], (name, i, f)
+
+
+@pytest.mark.parametrize("w,h,n,level,exit_th,kind,motion", [
+    (264, 136, 7, 0, 0, "synth", (9, -5)), (328, 200, 5, 1, 256, "half_static", (4, 2)),
+    (192, 128, 7, 2, 256, "half_static", (-2, 1)), (256, 192, 3, 0, 0, "noise", (0, 0)),
+])
+def test_temporal_filter_search_matches_oracle(w, h, n, level, exit_th, kind, motion):
+    frames, pics = support.make_tf_job(w, h, n, seed=60 + level, kind=kind, motion=motion)
+    _, recs = refio.run_oracle(frames, pics, 0, mode=refio.MODE_DUMP_NOTAIL, threads=8, tf=(level, exit_th))
+    outs = support.run_engine_tf_job(frames, pics, level, exit_th)
+    for (pd, bd), out, p in zip(recs, outs, pics):
+        want = MOD.tf_canonical(bd)
+        for f, v in support.tf_fields(out).items():
+            assert np.array_equal(v, want[f]), ("neighbour %d" % p.refs[0][0], f)
+
+
+def test_temporal_filter_search_argument_checks():
+    frames, pics = support.make_tf_job(128, 128, 3, seed=1)
+    eng = svtme.Engine(128, 128, store_slots=4, max_in_flight=1)
+    try:
+        for i in range(3):
+            eng.store_put(i, i, frames[i])
+        ctrl = svtme.derive_tf_controls(1)
+        two = eng.make_picture(128, 128, 1, 0, 1, [[0, 2], []], ctrl, tf_me_exit_th=0)
+        with pytest.raises(svtme.SvtmeError) as ei:
+            eng.submit(two)
+        assert ei.value.code == svtme.ERR_BAD_ARG
+        tail = svtme.Tail(enable=1, enable_me_8x8=1, enable_me_16x16=1, max_refs=1, max_cand=1, max_l0=1)
+        with_tail = eng.make_picture(128, 128, 1, 0, 1, [[0], []], ctrl, tail=tail, tf_me_exit_th=0)
+        with pytest.raises(svtme.SvtmeError) as ei:
+            eng.submit(with_tail)
+        assert ei.value.code == svtme.ERR_BAD_ARG
+    finally:
+        eng.close()
+
+
 def test_device_store_planes_match_oracle():
     frames, pics, rc = support.make_job(200, 136, 3, 8, seed=5)
     _, planes = refio.run_oracle(frames, [], 8, mode=refio.MODE_PLANES, ref_counts=rc)
