@@ -36,6 +36,11 @@ WORKLOADS = {
     "720p_ld_m12": dict(width=1280, height=720, enc_mode=12, structure="ldp", n_frames=17, bit_depth=8),
     "4k_ra_m8": dict(width=3840, height=2160, enc_mode=8, structure="ra", n_frames=17, bit_depth=10),
     "8k_ra_m2": dict(width=7680, height=4320, enc_mode=2, structure="ra", n_frames=17, bit_depth=8),
+    # temporal-filter searches (ME_MCTF): a 7-frame window, the centre frame searched in each of its 6 neighbours; one
+    # "picture" = one (centre, neighbour) pair. tf = (tf_ctrls.hme_me_level, tf_ctrls.me_exit_th): level 0 is what presets
+    # up to M5 use, level 2 with the 16x16 exit threshold what the fast presets use (EbEncHandle.c:2556-2876).
+    "1080p_tf_l0": dict(width=1920, height=1080, enc_mode=0, structure="tf", n_frames=7, bit_depth=8, tf=(0, 0)),
+    "1080p_tf_l2": dict(width=1920, height=1080, enc_mode=8, structure="tf", n_frames=7, bit_depth=8, tf=(2, 256)),
 }
 STAGES = ["zz_centre", "prehme", "hme_l0", "hme_l1", "hme_l2", "integer_search"]
 # Packed-SAD peak of gfx950: 256 CUs x 4 SIMDs x 16 lanes/clk (v_sad_u8 / v_qsad_pk_u16_u8 issue at a quarter of the
@@ -47,7 +52,10 @@ PEAK_HBM_GBS = 8000.0
 def make_pictures(wl, seed):
     from svtme import gop, synth
     frames = synth.synth_sequence(wl["width"], wl["height"], wl["n_frames"], seed=seed, bit_depth=wl["bit_depth"])
-    if wl["structure"] == "ra":
+    if wl["structure"] == "tf":
+        c = wl["n_frames"] // 2
+        pics = [gop.Picture(poc=c, temporal_layer=0, is_ref=1, refs=[[j], []]) for j in range(wl["n_frames"]) if j != c]
+    elif wl["structure"] == "ra":
         pics = gop.random_access(wl["n_frames"], wl["enc_mode"])
     else:
         pics = gop.low_delay(wl["n_frames"], wl["enc_mode"], n_list=1 if wl["structure"] == "ldp" else 2)
@@ -69,7 +77,7 @@ def cpu_baseline(wl, frames, pics, budget_s=20.0):
 
         def run(reps):
             refio.write_job(job, frames, sample, wl["enc_mode"], mode=refio.MODE_BENCH, threads=threads, use_avx2=avx2,
-                            reps=reps, ref_counts=rc)
+                            reps=reps, ref_counts=rc, tf=wl.get("tf"))
             r = subprocess.run([binary, job, out], capture_output=True, text=True, timeout=600)
             if r.returncode != 0:
                 raise RuntimeError(r.stderr[-500:])
@@ -122,10 +130,13 @@ def main():
     wl = dict(WORKLOADS[args.workload], name=args.workload)
     frames, pics = make_pictures(wl, seed=1000 + rank)
     n, h, w = frames.shape
-    ctrl = svtme.derive_controls(wl["enc_mode"], w, h)
+    tf = wl.get("tf")
+    ctrl = svtme.derive_tf_controls(tf[0]) if tf else svtme.derive_controls(wl["enc_mode"], w, h)
     n_refs = sum(len(p.refs[0]) + len(p.refs[1]) for p in pics)
 
     tail = None
+    if tf and (args.device_tail or args.device_tail_only):
+        sys.exit("temporal-filter searches have no host tail")
     if args.device_tail or args.device_tail_only:
         from svtme import gop
         b0, b1, n0, n1 = gop.mrp_counts(wl["enc_mode"])
@@ -143,7 +154,8 @@ def main():
                          search_streams=search_streams, kernel_timing=kernel_timing)
         for i in range(n):
             e.store_put(i, i, frames[i])  # inputs resident in HBM before the timed region
-        return e, [e.make_picture(w, h, p.poc, p.temporal_layer, p.is_ref, p.refs, ctrl, tail=tail) for p in pics]
+        return e, [e.make_picture(w, h, p.poc, p.temporal_layer, p.is_ref, p.refs, ctrl, tail=tail,
+                                  tf_me_exit_th=tf[1] if tf else None) for p in pics]
 
     # per-kernel events only where they are needed: with one search stream they are the roofline timings
     eng, descs = make_engine(args.search_streams, 1 if args.search_streams == 1 else 0)
@@ -247,7 +259,8 @@ def main():
             "metric": "open-loop ME pictures/s", "value": pictures / elapsed, "unit": "pictures/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u8", "data": "synthetic",
-            "config": {"workload": args.workload, "width": w, "height": h, "preset": wl["enc_mode"],
+            "config": {"workload": args.workload, "width": w, "height": h,
+                       "preset": "tf hme_me_level %d, me_exit_th %d" % tf if tf else wl["enc_mode"],
                        "pred_structure": wl["structure"], "pictures_per_step": len(descs),
                        "refs_per_picture": round(refs_per_pic, 2), "bit_depth": wl["bit_depth"],
                        "parallelism": "pictures sharded over %d GPU(s), no data-path collective" % world},

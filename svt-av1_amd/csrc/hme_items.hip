@@ -17,6 +17,10 @@
 //                  (8x3) of a large block (32x32, 64x64): the block's rows are split over 8 lanes per position quad.
 //
 // The argmin is exact under the reference's rule (strict '<' in raster order): 64-bit keys (SAD << 32 | raster index).
+//
+// Both kernels exist in two forms: SUB_SAD_SEARCH (every other block row, SAD x2: every preset of the pre-analysis ME)
+// and FULL_SAD_SEARCH (all block rows: the temporal filter's searches, EbTemporalFiltering.c:331). The template
+// parameter FS selects the form; the sub-sampled form's code and resources do not depend on the other's.
 #include "search_common.h"
 
 namespace svtme {
@@ -25,12 +29,14 @@ constexpr int HI_THREADS   = 64;
 constexpr int HI_WIN_BYTES = 12288; // LDS budget of one staged reference window
 constexpr int HI_XCHUNK    = 96; // search positions per staged column chunk (level 0 / pre-HME)
 constexpr int HI_WIN2_BYTES = 6144; // levels 1 and 2
+constexpr int HI_WIN2_BYTES_FS = 8192; // the same with FULL_SAD_SEARCH: 16 + 63 rows of the 64x64 block's 16x16 window
+constexpr int HI_THREADS_FS = 64; // threads of a level-1/2 work item with FULL_SAD_SEARCH
 
 struct L0Shared {
     u64      key;
     uint32_t red;
     int      zero; // always 0, but only known at run time
-    uint32_t src[8 * 4];
+    uint32_t src[16 * 4];
 };
 
 // get_hme_l0_search_area :1827-1894 when no reference's area depends on the first reference's vector
@@ -54,16 +60,17 @@ __device__ void l0_area(const PicParams &p, int l, int r, int16_t &sa_w, int16_t
 
 // What the callers of svt_sad_loop_kernel make of its outputs: SAD x2 (rows were subsampled), position + window
 // origin, times the level's scale (:938-944, :1040-1046, :1133-1137, :1710-1716).
-__device__ __forceinline__ void decode_key(u64 key, int sa_w, int org_x, int org_y, int scale, int16_t &mx, int16_t &my, uint32_t &sad) {
+__device__ __forceinline__ void decode_key(u64 key, int sa_w, int org_x, int org_y, int scale, int16_t &mx, int16_t &my, uint32_t &sad,
+                                           bool sub_sad = true) {
     if (key == ~0ull) { // no position evaluated: svt_sad_loop_kernel leaves 0xffffff and does not touch x / y
-        sad = 0xffffffu * 2;
+        sad = sub_sad ? 0xffffffu * 2 : 0xffffffu;
         mx  = (int16_t)(org_x * scale);
         my  = (int16_t)(org_y * scale);
         return;
     }
     const int idx = (int)(uint32_t)key;
     const int y = idx / sa_w, x = idx - y * sa_w;
-    sad = (uint32_t)(key >> 32) * 2;
+    sad = (uint32_t)(key >> 32) * (sub_sad ? 2 : 1);
     mx  = (int16_t)((int16_t)(x + org_x) * scale);
     my  = (int16_t)((int16_t)(y + org_y) * scale);
 }
@@ -87,24 +94,25 @@ __device__ uint32_t slow_sad(const DevPlane &cur, const DevPlane &ref, int ox, i
     return sad;
 }
 
-// The T same-parity rows x 4 columns of every unit of a staged window band, for a 16-pixel-wide block of `rows`
-// sampled rows held in src (wave-uniform); FULL: rows == 8. Folds each lane's best (SAD, raster index) into `best`.
-template <int T, bool FULL>
-__device__ __forceinline__ void strip_units(const uint32_t *win, int pd, int n_xg, int brows, bool skip_even, const uint32_t (&src)[8][4],
+// The T search rows (STEP apart: same parity for a block sampled every other row, consecutive for a block sampled on
+// every row) x 4 columns of every unit of a staged window band, for a 16-pixel-wide block of `rows` sampled rows held in
+// src (wave-uniform); FULL: rows == NR. Folds each lane's best (SAD, raster index) into `best`.
+template <int T, bool FULL, int NR = 8, int STEP = 2>
+__device__ __forceinline__ void strip_units(const uint32_t *win, int pd, int n_xg, int brows, bool skip_even, const uint32_t (&src)[NR][4],
                                             int rows, int zero, int y_abs0, int x_abs0, int sa_w, u64 &best) {
     const int lane   = threadIdx.x;
-    const int n_yg   = (brows + 2 * T - 1) / (2 * T);
-    const int n_unit = n_xg * n_yg * (skip_even ? 1 : 2);
+    const int n_yg   = (brows + STEP * T - 1) / (STEP * T);
+    const int n_unit = n_xg * n_yg * ((skip_even || STEP == 1) ? 1 : 2);
     const uint32_t xg_magic = div_magic((uint32_t)n_xg);
     for (int ub = 0; ub < n_unit; ub += HI_THREADS) {
         const int  u     = ub + lane;
         const bool valid = u < n_unit;
         const int  rest  = valid ? (int)magic_div((uint32_t)u, (uint32_t)n_xg, xg_magic) : 0;
         const int  xg    = valid ? u - rest * n_xg : 0;
-        const int  par   = skip_even ? 1 : (rest & 1);
-        const int  yg    = skip_even ? rest : rest >> 1;
-        const int  yfirst = yg * 2 * T + par;
-        const int  n_pos  = valid ? min(T, max(0, (brows - yfirst + 1) >> 1)) : 0;
+        const int  par   = STEP == 1 ? 0 : (skip_even ? 1 : (rest & 1));
+        const int  yg    = (skip_even || STEP == 1) ? rest : rest >> 1;
+        const int  yfirst = yg * STEP * T + par;
+        const int  n_pos  = valid ? min(T, max(0, (brows - yfirst + STEP - 1) / STEP)) : 0;
         // the four 8-byte operands of a step overlap by a dword; the odd pairs are read through a second pointer the
         // compiler cannot prove equal to the first, so every pair comes from LDS in its own aligned register pair
         const uint32_t *rr = win + yfirst * pd + xg;
@@ -117,20 +125,20 @@ __device__ __forceinline__ void strip_units(const uint32_t *win, int pd, int n_x
         auto     fetch = [&]() {
             n01[0] = rr[0], n01[1] = rr[1], n23[0] = rr[2], n23[1] = rr[3];
             n12[0] = rq[0], n12[1] = rq[1], n34[0] = rq[2], n34[1] = rq[3];
-            rr += 2 * pd;
-            rq += 2 * pd;
+            rr += STEP * pd;
+            rq += STEP * pd;
         };
         fetch();
-        static_for<0, T + 7>([&](auto s_c) {
+        static_for<0, T + NR - 1>([&](auto s_c) {
             constexpr int s   = decltype(s_c)::value;
             const u64     p01 = ((u64)n01[1] << 32) | n01[0], p12 = ((u64)n12[1] << 32) | n12[0];
             const u64     p23 = ((u64)n23[1] << 32) | n23[0], p34 = ((u64)n34[1] << 32) | n34[0];
-            if constexpr (s + 1 < T + 7) fetch();
+            if constexpr (s + 1 < T + NR - 1) fetch();
             __builtin_amdgcn_sched_barrier(0);
             static_for<0, T>([&](auto t_c) {
                 constexpr int t = decltype(t_c)::value;
                 constexpr int m = s - t; // sampled source row of position t at this step
-                if constexpr (m >= 0 && m < 8) {
+                if constexpr (m >= 0 && m < NR) {
                     if (FULL || m < rows) {
                         acc[t] = __builtin_amdgcn_qsad_pk_u16_u8(p01, src[m][0], acc[t]);
                         acc[t] = __builtin_amdgcn_qsad_pk_u16_u8(p12, src[m][1], acc[t]);
@@ -140,7 +148,7 @@ __device__ __forceinline__ void strip_units(const uint32_t *win, int pd, int n_x
                 }
             });
         });
-        // per column: min over rows of SAD << 4 | t (SAD <= 8 * 16 * 255: the packed sums never carried)
+        // per column: min over rows of SAD << 4 | t (SAD <= 16 * 16 * 255 < 65536: the packed sums never carried)
         uint32_t col[4] = {~0u, ~0u, ~0u, ~0u};
 #pragma unroll
         for (int t = 0; t < T; ++t) {
@@ -157,7 +165,7 @@ __device__ __forceinline__ void strip_units(const uint32_t *win, int pd, int n_x
         for (int i = 0; i < 4; ++i) {
             const int x = x_abs0 + xg * 4 + i;
             if (col[i] != ~0u && x < sa_w) {
-                const int y = y_abs0 + yfirst + 2 * (int)(col[i] & 15);
+                const int y = y_abs0 + yfirst + STEP * (int)(col[i] & 15);
                 const u64 k = ((u64)(col[i] >> 4) << 32) | (uint32_t)(y * sa_w + x);
                 ubest       = k < ubest ? k : ubest;
             }
@@ -166,11 +174,13 @@ __device__ __forceinline__ void strip_units(const uint32_t *win, int pd, int n_x
     }
 }
 
-// Exhaustive search of the (bw x rows sampled rows, 2 plane rows apart) block of `cur` at (ox, oy) over the sa_w x sa_h
-// window of `ref` whose first position is plane pixel (wx, wy). Returns min (SAD << 32 | y * sa_w + x), ~0 when no
-// position was evaluated (skip_even with a single row). Whole wave.
+// Exhaustive search of the (bw x rows sampled rows, STEP = FS ? 1 : 2 plane rows apart) block of `cur` at (ox, oy) over
+// the sa_w x sa_h window of `ref` whose first position is plane pixel (wx, wy). Returns min (SAD << 32 | y * sa_w + x),
+// ~0 when no position was evaluated (skip_even with a single row). Whole wave. skip_even needs FS == false.
+template <bool FS>
 __device__ __forceinline__ u64 l0_search(L0Shared &S, uint32_t *win, const DevPlane &cur, const DevPlane &ref, int ox, int oy, int bw, int rows, int wx,
                          int wy, int sa_w, int sa_h, bool skip_even) {
+    constexpr int NR = FS ? 16 : 8, STEP = FS ? 1 : 2;
     const int lane = threadIdx.x;
     u64       best = ~0ull;
     if (sa_w <= 0 || sa_h <= 0 || rows <= 0) return best;
@@ -178,44 +188,45 @@ __device__ __forceinline__ u64 l0_search(L0Shared &S, uint32_t *win, const DevPl
         for (int i = lane; i < sa_w * sa_h; i += HI_THREADS) {
             const int y = i / sa_w, x = i - y * sa_w;
             if (skip_even && (y & 1) == 0) continue;
-            const u64 k = ((u64)slow_sad(cur, ref, ox, oy, wx + x, wy + y, bw, rows, 2) << 32) | (uint32_t)i;
+            const u64 k = ((u64)slow_sad(cur, ref, ox, oy, wx + x, wy + y, bw, rows, STEP) << 32) | (uint32_t)i;
             best        = k < best ? k : best;
         }
     } else {
         if (lane < rows * 4)
-            S.src[lane] = *reinterpret_cast<const uint32_t *>(cur.pix + (ptrdiff_t)(oy + 2 * (lane >> 2)) * cur.stride + ox + 4 * (lane & 3));
+            S.src[lane] = *reinterpret_cast<const uint32_t *>(cur.pix + (ptrdiff_t)(oy + STEP * (lane >> 2)) * cur.stride + ox + 4 * (lane & 3));
         if (lane == 0) S.zero = 0;
         __syncthreads();
-        uint32_t src[8][4];
+        uint32_t src[NR][4];
 #pragma unroll
-        for (int m = 0; m < 8; ++m)
+        for (int m = 0; m < NR; ++m)
 #pragma unroll
             for (int j = 0; j < 4; ++j) src[m][j] = (uint32_t)__builtin_amdgcn_readfirstlane((int)S.src[(m < rows ? m : 0) * 4 + j]);
         const int zero = S.zero;
         for (int x0 = 0; x0 < sa_w; x0 += HI_XCHUNK) {
             const int n_xg = (min(HI_XCHUNK, sa_w - x0) + 3) >> 2;
             const int pd   = (n_xg + 4 + 3) & ~3; // dwords per staged row: the positions + 15 more pixels, in 16-byte pieces
-            // rows the LDS budget holds: a band's search rows + 14 rows under the last one + the staggered walk's
-            // overrun (rows that are addressed but never used)
-            const int cap  = HI_WIN_BYTES / (4 * pd);
-            int       band = cap - 14 - 16;
+            // rows the LDS budget holds: a band's search rows + the (NR - 1) STEP rows under the last one + the staggered
+            // walk's overrun (rows that are addressed but never used)
+            constexpr int under = (NR - 1) * STEP;
+            const int     cap   = HI_WIN_BYTES / (4 * pd);
+            int           band  = cap - under - 16;
             band           = band >= 16 ? band & ~15 : max(band, 1);
             for (int y0 = 0; y0 < sa_h; y0 += band) {
                 const int brows = min(band, sa_h - y0);
                 __syncthreads();
-                stage_window<5>(win, ref.pix + (ptrdiff_t)(wy + y0) * ref.stride + wx + x0, ref.stride, pd, brows + 14);
+                stage_window<5>(win, ref.pix + (ptrdiff_t)(wy + y0) * ref.stride + wx + x0, ref.stride, pd, brows + under);
                 __syncthreads();
                 // rows per unit: as many as still give every lane a unit
-                const int cells = n_xg * ((brows + 1) >> 1); // position quads x row pairs
+                const int cells = n_xg * ((brows + STEP - 1) / STEP); // position quads x rows of one walk direction
                 const int t = brows > 8 && cells >= 8 * HI_THREADS ? 8 : (brows > 4 && cells >= 4 * HI_THREADS ? 4 : 2);
-                if (rows == 8) {
-                    if (t == 8) strip_units<8, true>(win, pd, n_xg, brows, skip_even, src, rows, zero, y0, x0, sa_w, best);
-                    else if (t == 4) strip_units<4, true>(win, pd, n_xg, brows, skip_even, src, rows, zero, y0, x0, sa_w, best);
-                    else strip_units<2, true>(win, pd, n_xg, brows, skip_even, src, rows, zero, y0, x0, sa_w, best);
+                if (rows == NR) {
+                    if (t == 8) strip_units<8, true, NR, STEP>(win, pd, n_xg, brows, skip_even, src, rows, zero, y0, x0, sa_w, best);
+                    else if (t == 4) strip_units<4, true, NR, STEP>(win, pd, n_xg, brows, skip_even, src, rows, zero, y0, x0, sa_w, best);
+                    else strip_units<2, true, NR, STEP>(win, pd, n_xg, brows, skip_even, src, rows, zero, y0, x0, sa_w, best);
                 } else { // blocks of the picture's bottom edge
-                    if (t == 8) strip_units<8, false>(win, pd, n_xg, brows, skip_even, src, rows, zero, y0, x0, sa_w, best);
-                    else if (t == 4) strip_units<4, false>(win, pd, n_xg, brows, skip_even, src, rows, zero, y0, x0, sa_w, best);
-                    else strip_units<2, false>(win, pd, n_xg, brows, skip_even, src, rows, zero, y0, x0, sa_w, best);
+                    if (t == 8) strip_units<8, false, NR, STEP>(win, pd, n_xg, brows, skip_even, src, rows, zero, y0, x0, sa_w, best);
+                    else if (t == 4) strip_units<4, false, NR, STEP>(win, pd, n_xg, brows, skip_even, src, rows, zero, y0, x0, sa_w, best);
+                    else strip_units<2, false, NR, STEP>(win, pd, n_xg, brows, skip_even, src, rows, zero, y0, x0, sa_w, best);
                 }
             }
         }
@@ -229,6 +240,7 @@ __device__ __forceinline__ u64 l0_search(L0Shared &S, uint32_t *win, const DevPl
     return best;
 }
 
+template <bool FS>
 __global__ void __launch_bounds__(HI_THREADS, 3) hme_l0_kernel(PicParams p) {
     __shared__ L0Shared               S;
     __shared__ __align__(16) uint32_t win[HI_WIN_BYTES / 4 + 64];
@@ -263,7 +275,7 @@ __global__ void __launch_bounds__(HI_THREADS, 3) hme_l0_kernel(PicParams p) {
     const DevPlane &ref = p.ref[l][r].lvl[0];
     const int       ox = b64x >> 2, oy = b64y >> 2;
     const int       bw = block_w >> 2, bh = block_h >> 2;
-    const int       rows = bh >> 1;
+    const int       rows = FS ? bh : bh >> 1;
     // the search this item runs: window (origin relative to the block, size), row skipping, where the result goes
     int16_t   w = 0, h = 0, org_x = 0, org_y = 0;
     bool      skip = false;
@@ -308,60 +320,81 @@ __global__ void __launch_bounds__(HI_THREADS, 3) hme_l0_kernel(PicParams p) {
         ops_k   = 2;
     }
     if (threadIdx.x == 0) count_ops(p, ops_k, (unsigned long long)max(skip ? h >> 1 : (int)h, 0) * max((int)w, 0) * rows * bw);
-    const u64 key = l0_search(S, win, cur, ref, ox, oy, bw, rows, ox + org_x, oy + org_y, w, h, skip);
-    if (threadIdx.x == 0) decode_key(key, w, org_x, org_y, 4, *res_x, *res_y, *res_sad);
+    const u64 key = l0_search<FS>(S, win, cur, ref, ox, oy, bw, rows, ox + org_x, oy + org_y, w, h, skip);
+    if (threadIdx.x == 0) decode_key(key, w, org_x, org_y, 4, *res_x, *res_y, *res_sad, !FS);
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
+template <bool FS>
 struct L12Shared {
     u64      key;
-    uint32_t src1[16 * 16]; // sampled rows of the quarter-resolution 32x32 block, 16 dwords apart
-    uint32_t src2[32 * 16]; // sampled rows of the full-resolution 64x64 block
+    int      zero; // always 0, but only known at run time
+    uint32_t src1[(FS ? 32 : 16) * 16]; // sampled rows of the quarter-resolution 32x32 block, 16 dwords apart
+    uint32_t src2[(FS ? 64 : 32) * 16]; // sampled rows of the full-resolution 64x64 block
 };
 
 // Exhaustive search of a small window with a large block whose sampled rows are staged at `src` (16 dwords per row):
 // position quads x block-row chunks over the lanes. bw: block width in pixels (multiple of 4 at these levels),
 // rows: sampled rows, 2 plane rows apart.
-// Sampled rows (2 plane rows apart) of the bw x rows block at (ox, oy) -> dst, 16 dwords per row. Issues its loads and
-// stores without waiting: the caller's next barrier orders them.
+// Sampled rows (STEP plane rows apart, at most 4 K of them) of the bw x rows block at (ox, oy) -> dst, 16 dwords per
+// row. Issues its loads and stores without waiting: the caller's next barrier orders them.
+template <int K = 8, int STEP = 2>
 __device__ __forceinline__ void stage_block(uint32_t *dst, const DevPlane &cur, int ox, int oy, int bw, int rows) {
+    if (threadIdx.x >= 64) return; // the first wave fetches
     const int bwd = bw >> 2, lane = threadIdx.x & 63, d = lane & 15;
     if (d >= bwd) return;
-    uint32_t v[8];
+    uint32_t v[K];
 #pragma unroll
-    for (int k = 0; k < 8; ++k) {
+    for (int k = 0; k < K; ++k) {
         const int r = (lane >> 4) + 4 * k;
-        if (r < rows) v[k] = *reinterpret_cast<const uint32_t *>(cur.pix + (ptrdiff_t)(oy + 2 * r) * cur.stride + ox + 4 * d);
+        if (r < rows) v[k] = *reinterpret_cast<const uint32_t *>(cur.pix + (ptrdiff_t)(oy + STEP * r) * cur.stride + ox + 4 * d);
     }
 #pragma unroll
-    for (int k = 0; k < 8; ++k) {
+    for (int k = 0; k < K; ++k) {
         const int r = (lane >> 4) + 4 * k;
         if (r < rows) dst[r * 16 + d] = v[k];
     }
 }
 
-__device__ u64 small_search(L12Shared &S, const uint32_t *src, uint32_t *win, const DevPlane &ref, int bw, int rows, int wx, int wy,
+// One sampled block row of BWD dwords against 4 adjacent positions of a staged window row.
+template <int BWD>
+__device__ __forceinline__ u64 row_qsad(const uint32_t *rr, const uint32_t *ss, u64 a16) {
+    uint32_t rv[BWD + 1], sv[BWD];
+#pragma unroll
+    for (int d = 0; d <= BWD; ++d) rv[d] = rr[d];
+#pragma unroll
+    for (int d = 0; d < BWD; ++d) sv[d] = ss[d];
+#pragma unroll
+    for (int d = 0; d < BWD; ++d) a16 = __builtin_amdgcn_qsad_pk_u16_u8(((u64)rv[d + 1] << 32) | rv[d], sv[d], a16);
+    return a16;
+}
+
+template <bool FS>
+__device__ u64 small_search(L12Shared<FS> &S, const uint32_t *src, uint32_t *win, const DevPlane &ref, int bw, int rows, int wx, int wy,
                             int sa_w, int sa_h) {
+    constexpr int STEP = FS ? 1 : 2; // plane rows between sampled block rows
+    constexpr int NT   = FS ? HI_THREADS_FS : HI_THREADS;
+    constexpr int WINB = FS ? HI_WIN2_BYTES_FS : HI_WIN2_BYTES;
     const int lane = threadIdx.x;
     u64       best = ~0ull;
     if (sa_w <= 0 || sa_h <= 0 || rows <= 0) return best;
     const int bwd = bw >> 2;
     __syncthreads();
     if (lane == 0) S.key = ~0ull;
-    const int span       = (rows - 1) * 2 + 1;
+    const int span       = (rows - 1) * STEP + 1;
     const int chunk_log2 = rows >= 16 ? 3 : (rows >= 4 ? 2 : 0), chunks = 1 << chunk_log2;
     const int rpc        = (rows + chunks - 1) >> chunk_log2; // sampled block rows per lane
     const int xc         = 64; // positions per staged column chunk
     for (int x0 = 0; x0 < sa_w; x0 += xc) {
         const int n_xg = (min(xc, sa_w - x0) + 3) >> 2, pd = (n_xg + bwd + 3) & ~3;
-        const int band = max(HI_WIN2_BYTES / (4 * pd) - (span - 1), 1);
+        const int band = max(WINB / (4 * pd) - (span - 1), 1);
         for (int y0 = 0; y0 < sa_h; y0 += band) {
             const int brows = min(band, sa_h - y0);
             __syncthreads();
-            stage_window<6>(win, ref.pix + (ptrdiff_t)(wy + y0) * ref.stride + wx + x0, ref.stride, pd, brows + span - 1);
+            stage_window<FS ? 2 : 6, NT>(win, ref.pix + (ptrdiff_t)(wy + y0) * ref.stride + wx + x0, ref.stride, pd, brows + span - 1);
             __syncthreads();
             const int total = (n_xg * brows) << chunk_log2;
-            for (int base = 0; base < total; base += HI_THREADS) {
+            for (int base = 0; base < total; base += NT) {
                 const int  t     = base + lane;
                 const bool valid = t < total;
                 const int  chunk = t & (chunks - 1);
@@ -373,7 +406,7 @@ __device__ u64 small_search(L12Shared &S, const uint32_t *src, uint32_t *win, co
                     u64       a16 = 0;
                     int       px  = 0;
                     for (int j = j0; j < j1; ++j) {
-                        const uint32_t *rr = win + (yl + 2 * j) * pd + xg;
+                        const uint32_t *rr = win + (yl + STEP * j) * pd + xg;
                         const uint32_t *ss = &src[j * 16];
                         if (px + bw > 256) { // keep the packed 16-bit sums below 65536
 #pragma unroll
@@ -381,11 +414,15 @@ __device__ u64 small_search(L12Shared &S, const uint32_t *src, uint32_t *win, co
                             a16 = 0;
                             px  = 0;
                         }
-                        uint32_t r0 = rr[0];
-                        for (int d = 0; d < bwd; ++d) {
-                            const uint32_t r1 = rr[d + 1];
-                            a16 = __builtin_amdgcn_qsad_pk_u16_u8(((u64)r1 << 32) | r0, ss[d], a16);
-                            r0  = r1;
+                        if (FS && bwd == 16) a16 = row_qsad<16>(rr, ss, a16);
+                        else if (FS && bwd == 8) a16 = row_qsad<8>(rr, ss, a16);
+                        else {
+                            uint32_t r0 = rr[0];
+                            for (int d = 0; d < bwd; ++d) {
+                                const uint32_t r1 = rr[d + 1];
+                                a16 = __builtin_amdgcn_qsad_pk_u16_u8(((u64)r1 << 32) | r0, ss[d], a16);
+                                r0  = r1;
+                            }
                         }
                         px += bw;
                     }
@@ -416,11 +453,109 @@ __device__ u64 small_search(L12Shared &S, const uint32_t *src, uint32_t *win, co
     return best;
 }
 
+// FULL_SAD_SEARCH levels 1 / 2 in the temporal filter's shape: a window of at most 16 x 16 positions, a full-width block
+// of NSTRIP 16-pixel column strips and up to NR rows (every row sampled), staged at `src`. Lane = (column strip) x (4
+// adjacent positions) x (T consecutive search rows): the wave covers the whole window at once. The T rows are walked
+// together, staggered by one block row, so each window row is read from LDS once per lane (four overlapping 8-byte
+// operands) and each block row once (one 16-byte read): 4 T v_qsad_pk_u16_u8 per step. The packed 16-bit sums are
+// folded into 32-bit sums every 16 block rows (16 x 16 x 255 < 65536); the strips' sums meet through DPP lane exchanges.
+template <int NSTRIP, int NR, int T>
+__device__ u64 strip_search_fs(L12Shared<true> &S, const uint32_t *src, uint32_t *win, const DevPlane &ref, int rows, int wx, int wy,
+                               int sa_w, int sa_h) {
+    constexpr int PD = 4 + 4 * NSTRIP; // dwords per staged row: 16 positions + the block width - 1 more pixels, rounded up
+    static_assert(64 / NSTRIP / 4 * T >= 16, "the wave covers 16 search rows");
+    const int lane = threadIdx.x;
+    const int n_xg = (sa_w + 3) >> 2, n_yg = (sa_h + T - 1) / T;
+    __syncthreads();
+    if (lane == 0) {
+        S.key  = ~0ull;
+        S.zero = 0;
+    }
+    stage_window<2>(win, ref.pix + (ptrdiff_t)wy * ref.stride + wx, ref.stride, PD, n_yg * T + NR - 1);
+    __syncthreads();
+    const int  zero  = S.zero;
+    const int  strip = lane % NSTRIP, unit = lane / NSTRIP, xg = unit & 3, yg = unit >> 2;
+    const bool valid = xg < n_xg && yg < n_yg;
+    const int  yfirst = valid ? yg * T : 0;
+    // the four 8-byte operands of a step overlap by a dword; the odd pairs are read through a second pointer the
+    // compiler cannot prove equal to the first, so every pair comes from LDS in its own aligned register pair
+    const uint32_t *rr = win + yfirst * PD + (valid ? xg : 0) + strip * 4;
+    const uint32_t *rq = rr + 1 + zero;
+    const uint4    *sp = reinterpret_cast<const uint4 *>(src) + strip; // block row m: sp[4 m]
+    u64             acc[T];
+    uint32_t        a32[T][4];
+#pragma unroll
+    for (int t = 0; t < T; ++t) {
+        acc[t] = 0;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) a32[t][i] = 0;
+    }
+    uint32_t n01[2], n12[2], n23[2], n34[2];
+    uint4    srow[T]; // block rows s, s - 1, .., s - T + 1 of the current step
+    auto     fetch = [&](int s) {
+        n01[0] = rr[0], n01[1] = rr[1], n23[0] = rr[2], n23[1] = rr[3];
+        n12[0] = rq[0], n12[1] = rq[1], n34[0] = rq[2], n34[1] = rq[3];
+        rr += PD;
+        rq += PD;
+        (void)s;
+    };
+    fetch(0);
+    static_for<0, NR + T - 1>([&](auto s_c) {
+        constexpr int s   = decltype(s_c)::value;
+        const u64     p01 = ((u64)n01[1] << 32) | n01[0], p12 = ((u64)n12[1] << 32) | n12[0];
+        const u64     p23 = ((u64)n23[1] << 32) | n23[0], p34 = ((u64)n34[1] << 32) | n34[0];
+        // rotate the block rows: srow[t] = row s - t
+#pragma unroll
+        for (int t = T - 1; t > 0; --t) srow[t] = srow[t - 1];
+        if constexpr (s < NR) srow[0] = sp[4 * s];
+        if constexpr (s + 1 < NR + T - 1) fetch(s + 1);
+        __builtin_amdgcn_sched_barrier(0);
+        static_for<0, T>([&](auto t_c) {
+            constexpr int t = decltype(t_c)::value;
+            constexpr int m = s - t; // block row of position t at this step
+            if constexpr (m >= 0 && m < NR) {
+                if (m < rows) {
+                    acc[t] = __builtin_amdgcn_qsad_pk_u16_u8(p01, srow[t].x, acc[t]);
+                    acc[t] = __builtin_amdgcn_qsad_pk_u16_u8(p12, srow[t].y, acc[t]);
+                    acc[t] = __builtin_amdgcn_qsad_pk_u16_u8(p23, srow[t].z, acc[t]);
+                    acc[t] = __builtin_amdgcn_qsad_pk_u16_u8(p34, srow[t].w, acc[t]);
+                }
+                if constexpr ((m & 15) == 15 || m == NR - 1) {
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) a32[t][i] += (uint32_t)(acc[t] >> (16 * i)) & 0xFFFFu;
+                    acc[t] = 0;
+                }
+            }
+        });
+    });
+    // the strips of a position: adjacent lanes
+    u64 best = ~0ull;
+#pragma unroll
+    for (int t = 0; t < T; ++t) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            uint32_t v = a32[t][i];
+            v += quad_xor1(v);
+            if constexpr (NSTRIP == 4) v += quad_xor2(v);
+            const int x = xg * 4 + i, y = yfirst + t;
+            if (valid && strip == 0 && x < sa_w && y < sa_h) {
+                const u64 kk = ((u64)v << 32) | (uint32_t)(y * sa_w + x);
+                best         = kk < best ? kk : best;
+            }
+        }
+    }
+    if (best != ~0ull) atomicMin(&S.key, best);
+    __syncthreads();
+    best = S.key;
+    __syncthreads();
+    return best;
+}
+
 // small_search for the shape every preset uses at these levels - 8 x (1..3) positions, full-width block of BWD dwords
 // (8: the 32-pixel quarter-resolution block, 16: the 64-pixel full-resolution block) - with everything unrolled:
 // lane = (position quad 0..5) x (8 chunks of BWD / 4 sampled block rows); window staged in one memory round trip.
 template <int BWD>
-__device__ u64 quick_search(L12Shared &S, const uint32_t *src, uint32_t *win, const DevPlane &ref, int rows, int wx, int wy, int sa_h) {
+__device__ u64 quick_search(L12Shared<false> &S, const uint32_t *src, uint32_t *win, const DevPlane &ref, int rows, int wx, int wy, int sa_h) {
     constexpr int PD  = BWD + 2; // dwords per staged row: 8 positions + the block width - 1 more pixels, rounded up
     constexpr int RPC = BWD / 4; // sampled block rows per lane (rows <= 8 RPC); RPC x 4 BWD x 255 fits the 16-bit sums
     constexpr int NB  = ((3 + 2 * (8 * RPC - 1)) * PD + 63) / 64;
@@ -484,9 +619,10 @@ __device__ u64 quick_search(L12Shared &S, const uint32_t *src, uint32_t *win, co
     return best;
 }
 
-__global__ void __launch_bounds__(HI_THREADS) hme_l12_kernel(PicParams p) {
-    __shared__ L12Shared              S;
-    __shared__ __align__(16) uint32_t win[HI_WIN2_BYTES / 4 + 64];
+template <bool FS>
+__global__ void __launch_bounds__(FS ? HI_THREADS_FS : HI_THREADS) hme_l12_kernel(PicParams p) {
+    __shared__ L12Shared<FS>          S;
+    __shared__ __align__(16) uint32_t win[(FS ? HI_WIN2_BYTES_FS : HI_WIN2_BYTES) / 4 + 64];
     const svtme_controls &k   = p.ctrl;
     const int             nw = k.num_hme_sa_w, nh = k.num_hme_sa_h;
     const int             n_refs = p.n_ref[0] + (p.n_list == 2 ? p.n_ref[1] : 0);
@@ -502,8 +638,13 @@ __global__ void __launch_bounds__(HI_THREADS) hme_l12_kernel(PicParams p) {
     }
     if (!ref_searched(p, l) || !k.enable_hme_flag || q >= nw * nh) return;
     // both levels' source blocks are fetched while the level-0 results arrive
-    if (k.enable_hme_level1_flag) stage_block(S.src1, p.cur.lvl[1], b64x >> 1, b64y >> 1, block_w >> 1, block_h >> 2);
-    if (k.enable_hme_level2_flag) stage_block(S.src2, p.cur.lvl[2], b64x, b64y, block_w, block_h >> 1);
+    if constexpr (FS) {
+        if (k.enable_hme_level1_flag) stage_block<8, 1>(S.src1, p.cur.lvl[1], b64x >> 1, b64y >> 1, block_w >> 1, block_h >> 1);
+        if (k.enable_hme_level2_flag) stage_block<16, 1>(S.src2, p.cur.lvl[2], b64x, b64y, block_w, block_h);
+    } else {
+        if (k.enable_hme_level1_flag) stage_block(S.src1, p.cur.lvl[1], b64x >> 1, b64y >> 1, block_w >> 1, block_h >> 2);
+        if (k.enable_hme_level2_flag) stage_block(S.src2, p.cur.lvl[2], b64x, b64y, block_w, block_h >> 1);
+    }
     const int  sw = q % nw, sh = q / nw, i = sw * 2 + sh;
     HmeRefOut *out = &p.hme_out[(b64 * SVTME_MAX_LISTS + l) * SVTME_MAX_REFS + r];
     const bool early = k.me_early_exit_th && out->zz_sad < (k.me_early_exit_th >> 2);
@@ -548,7 +689,7 @@ __global__ void __launch_bounds__(HI_THREADS) hme_l12_kernel(PicParams p) {
         const int       shift = 2 - level;
         const int       ox = b64x >> shift, oy = b64y >> shift;
         const int       bw = block_w >> shift, bh = block_h >> shift;
-        const int       rows = bh >> 1;
+        const int       rows = FS ? bh : bh >> 1;
         const int       pad  = level == 2 ? 63 : ref.pad - 1;
         const svtme_sa &sa   = level == 1 ? k.hme_l1_sa : k.hme_l2_sa;
         int16_t         w = (int16_t)(((int16_t)sa.width + 7) & ~0x07), h = (int16_t)sa.height;
@@ -562,13 +703,21 @@ __global__ void __launch_bounds__(HI_THREADS) hme_l12_kernel(PicParams p) {
         clip_axis(oy, org_y, h, -pad, ref.height);
         if (threadIdx.x == 0) count_ops(p, 2 + level, (unsigned long long)max((int)h, 0) * max((int)w, 0) * rows * bw);
         u64 key;
-        if (block_w == 64 && w == 8 && h >= 1 && h <= 3)
-            key = level == 1 ? quick_search<8>(S, S.src1, win, ref, rows, ox + org_x, oy + org_y, h)
-                             : quick_search<16>(S, S.src2, win, ref, rows, ox + org_x, oy + org_y, h);
-        else
-            key = small_search(S, level == 1 ? S.src1 : S.src2, win, ref, bw, rows, ox + org_x, oy + org_y, w, h);
+        if constexpr (!FS) {
+            if (block_w == 64 && w == 8 && h >= 1 && h <= 3)
+                key = level == 1 ? quick_search<8>(S, S.src1, win, ref, rows, ox + org_x, oy + org_y, h)
+                                 : quick_search<16>(S, S.src2, win, ref, rows, ox + org_x, oy + org_y, h);
+            else
+                key = small_search<FS>(S, level == 1 ? S.src1 : S.src2, win, ref, bw, rows, ox + org_x, oy + org_y, w, h);
+        } else {
+            if (block_w == 64 && w >= 1 && w <= 16 && h >= 1 && h <= 16)
+                key = level == 1 ? strip_search_fs<2, 32, 2>(S, S.src1, win, ref, rows, ox + org_x, oy + org_y, w, h)
+                                 : strip_search_fs<4, 64, 4>(S, S.src2, win, ref, rows, ox + org_x, oy + org_y, w, h);
+            else
+                key = small_search<FS>(S, level == 1 ? S.src1 : S.src2, win, ref, bw, rows, ox + org_x, oy + org_y, w, h);
+        }
         uint32_t  sad;
-        decode_key(key, w, org_x, org_y, level == 1 ? 2 : 1, cx, cy, sad);
+        decode_key(key, w, org_x, org_y, level == 1 ? 2 : 1, cx, cy, sad, !FS);
         if (threadIdx.x == 0) {
             out->lx[level][i]   = cx;
             out->ly[level][i]   = cy;
@@ -581,17 +730,22 @@ void launch_hme_items(const PicParams &p, hipStream_t s, hipEvent_t marks[2]) {
     const int n_refs = p.n_ref[0] + (p.n_list == 2 ? p.n_ref[1] : 0);
     const int n_b64  = p.b64_w * p.b64_h;
     const int n_reg  = p.ctrl.num_hme_sa_w * p.ctrl.num_hme_sa_h;
-    hipLaunchKernelGGL(hme_l0_kernel, dim3(n_b64, 2 + max(n_reg, 1), n_refs), dim3(HI_THREADS), 0, s, p);
+    const bool fs = p.ctrl.hme_search_method == 1; // FULL_SAD_SEARCH
+    const dim3 g0(n_b64, 2 + max(n_reg, 1), n_refs), g12((n_b64 + 7) / 8 * 8 * n_refs * n_reg);
+    if (fs) hipLaunchKernelGGL(hme_l0_kernel<true>, g0, dim3(HI_THREADS), 0, s, p);
+    else hipLaunchKernelGGL(hme_l0_kernel<false>, g0, dim3(HI_THREADS), 0, s, p);
     if (marks[0]) (void)hipEventRecord(marks[0], s);
-    if (p.ctrl.enable_hme_flag)
-        hipLaunchKernelGGL(hme_l12_kernel, dim3((n_b64 + 7) / 8 * 8 * n_refs * n_reg), dim3(HI_THREADS), 0, s, p);
+    if (p.ctrl.enable_hme_flag) {
+        if (fs) hipLaunchKernelGGL(hme_l12_kernel<true>, g12, dim3(HI_THREADS_FS), 0, s, p);
+        else hipLaunchKernelGGL(hme_l12_kernel<false>, g12, dim3(HI_THREADS), 0, s, p);
+    }
     if (marks[1]) (void)hipEventRecord(marks[1], s);
 }
 
 // resident workgroups per CU the runtime expects for the two kernels (diagnostic)
 void occupancy_hme_items(int out[2]) {
-    (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&out[0], hme_l0_kernel, HI_THREADS, 0);
-    (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&out[1], hme_l12_kernel, HI_THREADS, 0);
+    (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&out[0], hme_l0_kernel<false>, HI_THREADS, 0);
+    (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&out[1], hme_l12_kernel<false>, HI_THREADS, 0);
 }
 
 } // namespace svtme

@@ -483,9 +483,11 @@ __global__ void __launch_bounds__(HME_THREADS) hme_kernel(PicParams p) {
 }
 
 void launch_hme(const PicParams &p, hipStream_t s, hipEvent_t marks[2]) {
-    // Every search of the picture at once, unless a reference depends on an earlier one's result (or the full-SAD
-    // HME of temporal filtering is asked for): then one workgroup per b64 walks the references in order.
-    if (!p.serial_refs && p.ctrl.hme_search_method == 0) {
+    // Every search of the picture at once, unless a reference depends on an earlier one's result: then one workgroup
+    // per b64 walks the references in order. (The itemised full-SAD form has no row skipping for pre-HME; no preset
+    // combines the two.)
+    const bool fs_skip = p.ctrl.hme_search_method != 0 && p.ctrl.prehme_enable && p.ctrl.prehme_skip_search_line;
+    if (!p.serial_refs && p.ctrl.hme_search_method <= 1 && !fs_skip) {
         launch_hme_items(p, s, marks);
         return;
     }

@@ -76,21 +76,21 @@ __device__ __forceinline__ uint32_t magic_div(uint32_t i, uint32_t d, uint32_t m
 // in 16-byte pieces (unaligned 16-byte loads); pd is a multiple of 4 and `win` 16-byte aligned. Piece i = lane + 64 k
 // goes to piece i of the window; indices past the end repeat the last piece (same value into the same slot), so
 // nothing branches. NB loads are in flight per lane before the first is stored: a window of up to 1 KiB x NB costs one
-// memory round trip. Reads pd * 4 bytes per row.
-template <int NB>
+// memory round trip. Reads pd * 4 bytes per row. NT > 64: the NT threads of the workgroup share the pieces.
+template <int NB, int NT = 64>
 __device__ __forceinline__ void stage_window(uint32_t *win, const uint8_t *g, int stride, int pd, int n_row) {
-    const int      pr = pd >> 2, n = n_row * pr, lane = threadIdx.x & 63;
+    const int      pr = pd >> 2, n = n_row * pr, lane = NT == 64 ? (threadIdx.x & 63) : (int)threadIdx.x;
     const uint32_t magic = div_magic((uint32_t)pr);
     uint4         *dst = reinterpret_cast<uint4 *>(win);
-    for (int base = lane; base < n; base += 64 * NB) {
+    for (int base = lane; base < n; base += NT * NB) {
         uint4 v[NB];
 #pragma unroll
         for (int k = 0; k < NB; ++k) {
-            const uint32_t i = (uint32_t)min(base + 64 * k, n - 1), r = magic_div(i, (uint32_t)pr, magic), d = i - r * (uint32_t)pr;
+            const uint32_t i = (uint32_t)min(base + NT * k, n - 1), r = magic_div(i, (uint32_t)pr, magic), d = i - r * (uint32_t)pr;
             __builtin_memcpy(&v[k], g + (ptrdiff_t)(int)r * stride + 16 * d, 16);
         }
 #pragma unroll
-        for (int k = 0; k < NB; ++k) dst[min(base + 64 * k, n - 1)] = v[k];
+        for (int k = 0; k < NB; ++k) dst[min(base + NT * k, n - 1)] = v[k];
     }
 }
 
