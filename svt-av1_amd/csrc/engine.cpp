@@ -295,9 +295,8 @@ extern "C" int svtme_picture_submit(svtme_engine *e, const svtme_picture *pic, s
         (pic->num_of_list_to_search == 2 && (pic->num_of_ref_pic_to_search[1] < 1 || pic->num_of_ref_pic_to_search[1] > SVTME_MAX_REFS)) ||
         k.num_hme_sa_w < 1 || k.num_hme_sa_w > 2 || k.num_hme_sa_h < 1 || k.num_hme_sa_h > 2)
         return SVTME_ERR_BAD_ARG;
-    // not implemented on the device: full-SAD integer search (no preset selects it) and the screen-content rule
-    // that shrinks later references' windows from the first reference's 64x64 result (EbMotionEstimation.c:1390-1399)
-    if (k.me_search_method != 0 || (k.enable_me_sr_adjustment == 2 && k.me_early_exit_th == 0)) return SVTME_ERR_UNSUPPORTED;
+    // not implemented on the device: full-SAD integer search (nothing in the encoder selects it)
+    if (k.me_search_method != 0) return SVTME_ERR_UNSUPPORTED;
     if (pic->tail.enable > 2 || pic->me_type > SVTME_ME_MCTF) return SVTME_ERR_BAD_ARG;
     // the temporal filter searches one neighbour frame at a time and has no host tail (EbTemporalFiltering.c:4844-4847,
     // EbMotionEstimation.c:2977)

@@ -81,7 +81,8 @@ __global__ void __launch_bounds__(ME_THREADS) me_plan_kernel(PicParams p) {
     const int             b64x = (b64 % p.b64_w) * 64, b64y = (b64 / p.b64_w) * 64;
     const int             block_w = min(p.width - b64x, 64), block_h = min(p.height - b64y, 64);
 
-    int my_l = 0, my_r = blockIdx.y;
+    const int my_idx = p.me_ref0 + (int)blockIdx.y;
+    int       my_l = 0, my_r = my_idx;
     if (my_r >= p.n_ref[0]) {
         my_r -= p.n_ref[0];
         my_l = 1;
@@ -171,7 +172,7 @@ __global__ void __launch_bounds__(ME_THREADS) me_plan_kernel(PicParams p) {
     }
     __syncthreads();
     // the workgroup of the first reference publishes the per-b64 tables
-    if (blockIdx.y == 0 && tid < 8) {
+    if (my_idx == 0 && tid < 8) {
         const int            l = tid >> 2, r = tid & 3;
         svtme_search_result &o = p.search_results[b64 * 8 + tid];
         o.hme_sc_x = S.sc_x[tid];
@@ -204,6 +205,7 @@ __global__ void __launch_bounds__(ME_THREADS) me_plan_kernel(PicParams p) {
     int16_t         h = (int16_t)min((int)(int16_t)k.me_sa.sa_min.height * dist, (int)k.me_sa.sa_max.height);
     w = (int16_t)((max(1, (int)((uint32_t)w / S.div[my])) + 7) & ~0x07);
     h = (int16_t)max(3, (int)((uint32_t)h / S.div[my]));
+    const int16_t  w0 = w, h0 = h;
     const uint32_t zz = hme[my_l * SVTME_MAX_REFS + my_r].zz_sad;
     if (k.me_early_exit_th) {
         if (zz < k.me_early_exit_th / 6) w = h = 1;
@@ -229,8 +231,15 @@ __global__ void __launch_bounds__(ME_THREADS) me_plan_kernel(PicParams p) {
         }
         if (k.enable_me_sr_adjustment == 2) {
             if ((accurate && best_hme_sad < 24 * 24) || (p.is_ref && S.hsad[my] < 24 * 24)) h = (int16_t)(h / 2);
-            // (the p_sb_best_sad[0][0][0] < 5000 rule of :1390-1399 needs the first reference's result: serial mode,
-            // rejected by the host for now)
+            // :1390-1399: a good 64x64 match in the first reference halves the other references' areas. The host runs
+            // the first reference's search to completion before this plan is launched for the others.
+            if (my_idx != 0) {
+                const uint32_t sad00 = (uint32_t)(p.me_keys[(size_t)(b64 * 8) * SVTME_PU_COUNT] >> 32) << 1;
+                if (sad00 < 5000 && h == h0 && w == w0) {
+                    h = (int16_t)(h >> 1);
+                    w = (int16_t)(w >> 1);
+                }
+            }
         }
     }
     int16_t org_x = (int16_t)(cx - (w >> 1)), org_y = (int16_t)(cy - (h >> 1));
@@ -253,7 +262,7 @@ __global__ void __launch_bounds__(ME_THREADS, 2) me_search_kernel(PicParams p) {
     const int b64x = (b64 % p.b64_w) * 64, b64y = (b64 / p.b64_w) * 64;
     // references in reverse order: the closest references (smallest windows, cheapest items) are dispatched last and
     // keep the kernel's tail short
-    int       my_l = 0, my_r = (int)(gridDim.z - 1 - blockIdx.z);
+    int       my_l = 0, my_r = p.me_ref0 + (int)(gridDim.z - 1 - blockIdx.z);
     if (my_r >= p.n_ref[0]) {
         my_r -= p.n_ref[0];
         my_l = 1;
@@ -547,12 +556,26 @@ __global__ void __launch_bounds__(256) me_finish_kernel(PicParams p) {
     p.best_mv[i]  = mv;
 }
 
-void launch_me(const PicParams &p, hipStream_t s, hipEvent_t marks[3]) {
+void launch_me(const PicParams &p_in, hipStream_t s, hipEvent_t marks[3]) {
+    PicParams p      = p_in;
     const int n_refs = p.n_ref[0] + (p.n_list == 2 ? p.n_ref[1] : 0);
     const int n_b64  = p.b64_w * p.b64_h;
-    hipLaunchKernelGGL(me_plan_kernel, dim3(n_b64, n_refs), dim3(ME_THREADS), 0, s, p);
+    // The screen-content search-range rule (enable_me_sr_adjustment == 2 without the zero-MV early exit) makes every
+    // other reference's area depend on the first reference's 64x64 result (EbMotionEstimation.c:1390-1399): that
+    // reference is planned and searched first, the others after it. (When list 0 / reference 0 is not searched at all
+    // the reference code reads whatever the previous block left; protect_closest_refs rules that out for the presets
+    // that use the rule.)
+    const bool two_phase = p.ctrl.enable_me_sr_adjustment == 2 && p.ctrl.me_early_exit_th == 0 && n_refs > 1;
+    if (two_phase) {
+        p.me_ref0 = 0;
+        hipLaunchKernelGGL(me_plan_kernel, dim3(n_b64, 1), dim3(ME_THREADS), 0, s, p);
+        hipLaunchKernelGGL(me_search_kernel, dim3(n_b64, p.me_max_items, 1), dim3(ME_THREADS), 0, s, p);
+        p.me_ref0 = 1;
+    }
+    const int n_now = n_refs - p.me_ref0;
+    hipLaunchKernelGGL(me_plan_kernel, dim3(n_b64, n_now), dim3(ME_THREADS), 0, s, p);
     if (marks[0]) (void)hipEventRecord(marks[0], s);
-    hipLaunchKernelGGL(me_search_kernel, dim3(n_b64, p.me_max_items, n_refs), dim3(ME_THREADS), 0, s, p);
+    hipLaunchKernelGGL(me_search_kernel, dim3(n_b64, p.me_max_items, n_now), dim3(ME_THREADS), 0, s, p);
     if (marks[1]) (void)hipEventRecord(marks[1], s);
     hipLaunchKernelGGL(me_finish_kernel, dim3((n_b64 * 8 * SVTME_PU_COUNT + 255) / 256), dim3(256), 0, s, p);
     if (marks[2]) (void)hipEventRecord(marks[2], s);

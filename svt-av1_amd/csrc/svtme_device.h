@@ -60,6 +60,7 @@ struct PicParams {
     int32_t        serial_refs; // 1: one workgroup walks all references of a b64 in order (cross-reference dependencies)
     int32_t        me_type; // SVTME_ME_OPEN_LOOP / SVTME_ME_MCTF
     uint32_t       tf_me_exit_th;
+    int32_t        me_ref0; // first reference (list-0 references first, then list 1) the integer-search launch covers
     int32_t        me_max_items; // upper bound of search work items per (b64, ref) for this picture's controls
     // intermediates
     MeJob              *me_jobs; // [n_b64][2][4]

@@ -14,8 +14,10 @@ TAIL_FIELDS = ["do_ref", "hme_sad", "me_distortion", "total_me_candidate_index",
 
 
 def make_job(width, height, n_frames, enc_mode, seed=1, structure="ra", kind="synth", motion=(3, -2)):
-    if kind == "synth":
+    if kind in ("synth", "half_static"):
         frames = synth.synth_sequence(width, height, n_frames, seed=seed, motion=motion)
+        if kind == "half_static":  # the left half never changes: perfect zero-vector matches there
+            frames[:, :, :width // 2] = frames[0, :, :width // 2]
     else:
         frames = synth.extreme_sequence(width, height, n_frames, kind, seed=seed)
     if structure == "ra":

@@ -25,8 +25,7 @@ def _golden_mod():
 
 
 MOD = _golden_mod()
-# the engine refuses the screen-content presets whose later references depend on the first one's 64x64 result
-GPU_CASES = sorted(n for n in MOD.CASES if n != "m4_sc_128x128")
+GPU_CASES = sorted(MOD.CASES)
 
 
 @pytest.mark.parametrize("name", GPU_CASES)
@@ -76,11 +75,30 @@ def test_engine_matches_oracle_screen_content_fast_presets():
     assert not msgs, "\n".join(msgs)
 
 
+def test_engine_matches_oracle_screen_content_slow_presets():
+    """Screen content at presets <= M6: the other references' search areas depend on the first reference's 64x64
+    result (EbMotionEstimation.c:1390-1399), so that reference is searched first."""
+    for mode, seed in ((4, 21), (6, 22), (0, 23)):
+        msgs = support.engine_vs_oracle(256, 192, 9, mode, seed=seed, sc_class1=1)
+        assert not msgs, "preset %d\n" % mode + "\n".join(msgs)
+    for kind in ("flat", "half_static"):  # first-reference 64x64 SADs below the rule's threshold
+        msgs = support.engine_vs_oracle(256, 128, 9, 5, seed=24, sc_class1=1, kind=kind)
+        assert not msgs, kind + "\n" + "\n".join(msgs)
+
+
 def test_engine_rejects_what_it_does_not_implement():
-    frames, pics, _ = support.make_job(128, 128, 5, 4, seed=1)
-    with pytest.raises(svtme.SvtmeError) as ei:
-        support.run_engine_job(frames, pics, 4, sc_class1=1)
-    assert ei.value.code == svtme.ERR_UNSUPPORTED
+    frames, pics, _ = support.make_job(128, 128, 3, 8, seed=1)
+    eng = svtme.Engine(128, 128, store_slots=4, max_in_flight=1)
+    try:
+        for i in range(3):
+            eng.store_put(i, i, frames[i])
+        ctrl = svtme.derive_controls(8, 128, 128)
+        ctrl.me_search_method = 1  # FULL_SAD_SEARCH for the integer search: nothing in the encoder selects it
+        with pytest.raises(svtme.SvtmeError) as ei:
+            eng.submit(eng.make_picture(128, 128, pics[0].poc, pics[0].temporal_layer, pics[0].is_ref, pics[0].refs, ctrl))
+        assert ei.value.code == svtme.ERR_UNSUPPORTED
+    finally:
+        eng.close()
 
 
 @pytest.mark.parametrize("name", GPU_CASES)
