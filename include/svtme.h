@@ -132,6 +132,9 @@ typedef struct svtme_config {
                                 picture's kernel tails overlap the others' kernels; 1 runs pictures back to back */
     uint32_t kernel_timing; /* 1: record an event after every kernel so that svtme_picture_timing() can report
                                per-kernel durations (a few extra runtime calls per picture); 0: totals only */
+    uint32_t serial_hme; /* diagnostic, 0 = off: run pre-HME / HME with the serial kernel (one workgroup per 64x64 block
+                            walks the references in order, as the reference's loops do) instead of the kernels of
+                            independent work items; same results, slower; kept as a cross-check */
 } svtme_config;
 
 /* Replaces nothing in the reference (the reference has no device): engine life cycle. */

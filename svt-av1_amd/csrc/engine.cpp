@@ -9,6 +9,7 @@
 
 #include <algorithm>
 
+#include <chrono>
 #include <mutex>
 #include <new>
 #include <stdio.h>
@@ -145,7 +146,7 @@ extern "C" const char *svtme_version(void) { return "svtme 0.1 (gfx950)"; }
 
 extern "C" int svtme_create(const svtme_config *cfg, svtme_engine **out) {
     if (!cfg || !out || cfg->max_width < 64 || cfg->max_height < 64 || cfg->max_width % 8 || cfg->max_height % 8 ||
-        cfg->max_width > 16384 || cfg->max_height > 16384 || cfg->store_slots < 2 || cfg->max_in_flight < 1 || cfg->search_streams > 3 || cfg->kernel_timing > 1)
+        cfg->max_width > 16384 || cfg->max_height > 16384 || cfg->store_slots < 2 || cfg->max_in_flight < 1 || cfg->search_streams > 3 || cfg->kernel_timing > 1 || cfg->serial_hme > 1)
         return SVTME_ERR_BAD_ARG;
     int n_dev = 0;
     if (hipGetDeviceCount(&n_dev) != hipSuccess || cfg->device < 0 || cfg->device >= n_dev) {
@@ -351,9 +352,11 @@ extern "C" int svtme_picture_submit(svtme_engine *e, const svtme_picture *pic, s
     p.me_type       = pic->me_type;
     p.tf_me_exit_th = pic->tf_me_exit_th;
     // a reference depends on an earlier one: pre-HME list-1 early exit (:1758-1768) and the HME level-0 area
-    // rescaling from the first reference's vector (:1837-1851)
-    p.serial_refs = (k.prehme_enable && k.prehme_l1_early_exit && p.n_list == 2) ||
-        (k.enable_me_sr_adjustment && k.distance_based_hme_resizing && k.reduce_hme_l0_sr_th_min && k.reduce_hme_l0_sr_th_max);
+    // rescaling from the first reference's vector (:1837-1851): those items run in a second launch
+    p.dep_pre = k.prehme_enable && k.prehme_l1_early_exit && p.n_list == 2;
+    p.dep_l0  = k.enable_hme_flag && k.enable_hme_level0_flag && k.enable_me_sr_adjustment && k.distance_based_hme_resizing &&
+        k.reduce_hme_l0_sr_th_min && k.reduce_hme_l0_sr_th_max && p.n_ref[0] + p.n_ref[1] > 1;
+    p.serial_refs = e->cfg.serial_hme != 0;
     const size_t n_b64 = (size_t)p.b64_w * p.b64_h;
     if (n_b64 > e->max_b64) return SVTME_ERR_BAD_ARG;
     f->layout(n_b64 * SVTME_MAX_LISTS * SVTME_MAX_REFS); // never larger than the allocation (n_b64 <= max_b64)
@@ -451,7 +454,18 @@ extern "C" int svtme_picture_wait(svtme_engine *e, svtme_ticket ticket, svtme_re
         if (!f) return SVTME_ERR_NOT_FOUND;
     }
     HIP_TRY(hipSetDevice(e->cfg.device));
-    HIP_TRY(hipEventSynchronize(f->ev[6]));
+    {
+        // A picture takes tens to hundreds of microseconds: poll first (a blocking wait can cost a sleep / wake-up of
+        // that order, depending on how the process set up the device), block only when it takes longer.
+        const auto t0 = std::chrono::steady_clock::now();
+        hipError_t q;
+        while ((q = hipEventQuery(f->ev[6])) == hipErrorNotReady) {
+            if (std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(2)) break;
+            __builtin_ia32_pause();
+        }
+        if (q == hipErrorNotReady) HIP_TRY(hipEventSynchronize(f->ev[6]));
+        else if (q != hipSuccess) return SVTME_ERR_DEVICE;
+    }
     std::lock_guard<std::mutex> lock(e->mu);
     if (!f->waited) {
         f->waited = true;

@@ -39,15 +39,52 @@ struct L0Shared {
     uint32_t src[16 * 4];
 };
 
-// get_hme_l0_search_area :1827-1894 when no reference's area depends on the first reference's vector
-__device__ void l0_area(const PicParams &p, int l, int r, int16_t &sa_w, int16_t &sa_h) {
+// Level-0 vector of region (0,0) of list 0 / reference 0 as hme_level0_b64 leaves it (:1967-1999): the region's own
+// result unless it is the worst of the regions and a pre-HME result beats it; zero on the zero-MV early exit (:1916).
+__device__ void first_ref_l0_centre(const PicParams &p, int b64, int &mvx, int &mvy) {
+    const svtme_controls &k = p.ctrl;
+    const HmeRefOut      &o = p.hme_out[b64 * SVTME_MAX_LISTS * SVTME_MAX_REFS];
+    mvx = mvy = 0;
+    if (!k.enable_hme_level0_flag || (k.me_early_exit_th && o.zz_sad < (k.me_early_exit_th >> 2))) return;
+    mvx = o.raw_x[0];
+    mvy = o.raw_y[0];
+    if (k.prehme_enable) {
+        uint32_t max_sad = 0;
+        int      mi      = 0;
+        for (int h_ = 0; h_ < k.num_hme_sa_h; ++h_)
+            for (int w_ = 0; w_ < k.num_hme_sa_w; ++w_)
+                if (o.raw_sad[w_ * 2 + h_] > max_sad) {
+                    max_sad = o.raw_sad[w_ * 2 + h_];
+                    mi      = w_ * 2 + h_;
+                }
+        const int s = o.pre_sad[0] <= o.pre_sad[1] ? 0 : 1;
+        if (mi == 0 && o.pre_sad[s] < o.raw_sad[0]) {
+            mvx = o.pre_x[s];
+            mvy = o.pre_y[s];
+        }
+    }
+}
+
+// get_hme_l0_search_area :1827-1894. With p.dep_l0 every reference but the first reads the first one's level-0
+// vector, which the items of the first phase have written.
+__device__ void l0_area(const PicParams &p, int b64, int l, int r, int16_t &sa_w, int16_t &sa_h) {
     const svtme_controls &k  = p.ctrl;
     svtme_sa_minmax       sa = k.hme_l0_sa;
     if (k.enable_me_sr_adjustment && k.distance_based_hme_resizing) {
-        sa.sa_min.width  = (uint16_t)(sa.sa_min.width / (1 + r));
-        sa.sa_min.height = (uint16_t)(sa.sa_min.height / (1 + r));
-        sa.sa_max.width  = (uint16_t)(sa.sa_max.width / (1 + r));
-        sa.sa_max.height = (uint16_t)(sa.sa_max.height / (1 + r));
+        int is_hor = 1, is_ver = 1, is_still = 0;
+        if (k.reduce_hme_l0_sr_th_min && k.reduce_hme_l0_sr_th_max && (l || r)) {
+            int mvx, mvy;
+            first_ref_l0_centre(p, b64, mvx, mvy);
+            is_ver   = abs(mvx) < k.reduce_hme_l0_sr_th_min && abs(mvy) > k.reduce_hme_l0_sr_th_max;
+            is_hor   = abs(mvx) > k.reduce_hme_l0_sr_th_max && abs(mvy) < k.reduce_hme_l0_sr_th_min;
+            is_still = abs(mvx) < k.reduce_hme_l0_sr_th_min * 3 && abs(mvy) < k.reduce_hme_l0_sr_th_min * 3;
+        }
+        int x_off = is_hor ? 1 : 2, y_off = is_ver ? 1 : 2;
+        if (k.enable_me_sr_adjustment == 2 && is_still) x_off = y_off = 4;
+        sa.sa_min.width  = (uint16_t)(sa.sa_min.width / (x_off + r));
+        sa.sa_min.height = (uint16_t)(sa.sa_min.height / (y_off + r));
+        sa.sa_max.width  = (uint16_t)(sa.sa_max.width / (x_off + r));
+        sa.sa_max.height = (uint16_t)(sa.sa_max.height / (y_off + r));
     }
     const int factor = scaled_dist(p.dist[l][r]);
     int16_t   w      = (int16_t)(sa.sa_min.width / k.num_hme_sa_w);
@@ -256,6 +293,11 @@ __global__ void __launch_bounds__(HI_THREADS, 3) hme_l0_kernel(PicParams p) {
         l = 1;
     }
     const int  sub      = blockIdx.y; // 0, 1: pre-HME shapes; 2..: level-0 regions in the reference's visiting order
+    // items that read another reference's result run in a second launch
+    if (p.hme_phase) {
+        const bool dependent = sub < 2 ? (p.dep_pre && l == 1) : (p.dep_l0 && (l || r));
+        if (dependent != (p.hme_phase == 2)) return;
+    }
     const bool searched = ref_searched(p, l);
     HmeRefOut *out      = &p.hme_out[(b64 * SVTME_MAX_LISTS + l) * SVTME_MAX_REFS + r];
     const bool header   = sub == 2; // this item also writes the per-reference fields
@@ -285,6 +327,21 @@ __global__ void __launch_bounds__(HI_THREADS, 3) hme_l0_kernel(PicParams p) {
     if (sub < 2) {
         // pre-HME (prehme_b64 :1773-1823); check_prehme_early_exit :1746-1770 leaves a zero result
         if (!k.prehme_enable || (k.me_early_exit_th && zz < k.me_early_exit_th)) return;
+        if (k.prehme_l1_early_exit && l == 1) {
+            // a list-1 search is skipped when the list-0 search of the same index found a good or a short vector: it
+            // mirrors that result (:1759-1768)
+            const HmeRefOut &o0 = p.hme_out[(b64 * SVTME_MAX_LISTS + 0) * SVTME_MAX_REFS + r];
+            const int16_t    x0 = o0.pre_x[sub], y0 = o0.pre_y[sub];
+            const uint32_t   s0 = o0.pre_sad[sub];
+            if (s0 < 32 * 32 || (abs(x0) < 16 && abs(y0) < 16)) {
+                if (threadIdx.x == 0) {
+                    out->pre_x[sub]   = (int16_t)-x0;
+                    out->pre_y[sub]   = (int16_t)-y0;
+                    out->pre_sad[sub] = s0;
+                }
+                return;
+            }
+        }
         const svtme_sa_minmax &cfg    = k.prehme_sa_cfg[sub];
         const int              factor = scaled_dist(p.dist[l][r]);
         w     = (int16_t)(uint16_t)min((uint32_t)cfg.sa_min.width * factor, (uint32_t)cfg.sa_max.width);
@@ -306,7 +363,7 @@ __global__ void __launch_bounds__(HI_THREADS, 3) hme_l0_kernel(PicParams p) {
         if (k.me_early_exit_th && zz < (k.me_early_exit_th >> 2)) return;
         const int sw = q % nw, sh = q / nw, i = sw * 2 + sh;
         int16_t   sa_w = 0, sa_h = 0;
-        l0_area(p, l, r, sa_w, sa_h);
+        l0_area(p, b64, l, r, sa_w, sa_h);
         w     = (int16_t)((sa_w + 7) & ~0x07);
         h     = sa_h;
         org_x = (int16_t)(-(int16_t)((w * nw) >> 1) + (int16_t)(w * sw));
@@ -732,8 +789,13 @@ void launch_hme_items(const PicParams &p, hipStream_t s, hipEvent_t marks[2]) {
     const int n_reg  = p.ctrl.num_hme_sa_w * p.ctrl.num_hme_sa_h;
     const bool fs = p.ctrl.hme_search_method == 1; // FULL_SAD_SEARCH
     const dim3 g0(n_b64, 2 + max(n_reg, 1), n_refs), g12((n_b64 + 7) / 8 * 8 * n_refs * n_reg);
-    if (fs) hipLaunchKernelGGL(hme_l0_kernel<true>, g0, dim3(HI_THREADS), 0, s, p);
-    else hipLaunchKernelGGL(hme_l0_kernel<false>, g0, dim3(HI_THREADS), 0, s, p);
+    PicParams  q = p;
+    const int  n_phase = (p.dep_pre || p.dep_l0) ? 2 : 1;
+    for (int phase = 1; phase <= n_phase; ++phase) {
+        q.hme_phase = n_phase == 1 ? 0 : phase;
+        if (fs) hipLaunchKernelGGL(hme_l0_kernel<true>, g0, dim3(HI_THREADS), 0, s, q);
+        else hipLaunchKernelGGL(hme_l0_kernel<false>, g0, dim3(HI_THREADS), 0, s, q);
+    }
     if (marks[0]) (void)hipEventRecord(marks[0], s);
     if (p.ctrl.enable_hme_flag) {
         if (fs) hipLaunchKernelGGL(hme_l12_kernel<true>, g12, dim3(HI_THREADS_FS), 0, s, p);

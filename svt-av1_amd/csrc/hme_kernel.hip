@@ -469,7 +469,7 @@ __global__ void __launch_bounds__(HME_THREADS) hme_kernel(PicParams p) {
             }
     }
     __syncthreads();
-    if (p.serial_refs) {
+    if (gridDim.y == 1) {
         for (int l = 0; l < p.n_list; ++l)
             for (int r = 0; r < p.n_ref[l]; ++r) hme_one_ref(p, S, win, b64, l, r);
     } else {
@@ -483,16 +483,16 @@ __global__ void __launch_bounds__(HME_THREADS) hme_kernel(PicParams p) {
 }
 
 void launch_hme(const PicParams &p, hipStream_t s, hipEvent_t marks[2]) {
-    // Every search of the picture at once, unless a reference depends on an earlier one's result: then one workgroup
-    // per b64 walks the references in order. (The itemised full-SAD form has no row skipping for pre-HME; no preset
-    // combines the two.)
+    // Kernels of independent work items, unless the caller asked for the serial kernel (one workgroup per b64 walks the
+    // references in order). (The itemised full-SAD form has no row skipping for pre-HME; no preset combines the two.)
     const bool fs_skip = p.ctrl.hme_search_method != 0 && p.ctrl.prehme_enable && p.ctrl.prehme_skip_search_line;
     if (!p.serial_refs && p.ctrl.hme_search_method <= 1 && !fs_skip) {
         launch_hme_items(p, s, marks);
         return;
     }
     const int n_refs = p.n_ref[0] + (p.n_list == 2 ? p.n_ref[1] : 0);
-    dim3      grid(p.b64_w * p.b64_h, p.serial_refs ? 1 : n_refs);
+    const bool dep = p.dep_pre || p.dep_l0 || p.serial_refs;
+    dim3       grid(p.b64_w * p.b64_h, dep ? 1 : n_refs);
     hipLaunchKernelGGL(hme_kernel, grid, dim3(HME_THREADS), HME_WIN_BYTES + 64, s, p);
     if (marks[0]) (void)hipEventRecord(marks[0], s);
     if (marks[1]) (void)hipEventRecord(marks[1], s);

@@ -57,7 +57,10 @@ struct PicParams {
     int32_t        n_ref[SVTME_MAX_LISTS];
     int32_t        temporal_layer;
     int32_t        is_ref;
-    int32_t        serial_refs; // 1: one workgroup walks all references of a b64 in order (cross-reference dependencies)
+    int32_t        serial_refs; // 1: one workgroup walks all references of a b64 in order (the serial HME kernel)
+    int32_t        dep_pre; // list-1 pre-HME searches read the list-0 results (check_prehme_early_exit :1759-1768)
+    int32_t        dep_l0; // the level-0 area of every reference but the first depends on the first one's vector (:1838-1850)
+    int32_t        hme_phase; // 0: every level-0 / pre-HME item; 1: the items others depend on; 2: the dependent items
     int32_t        me_type; // SVTME_ME_OPEN_LOOP / SVTME_ME_MCTF
     uint32_t       tf_me_exit_th;
     int32_t        me_ref0; // first reference (list-0 references first, then list 1) the integer-search launch covers

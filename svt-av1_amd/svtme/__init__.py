@@ -59,7 +59,8 @@ class PresetKey(C.Structure):
 
 class Config(C.Structure):
     _fields_ = [("device", C.c_int32), ("max_width", C.c_uint32), ("max_height", C.c_uint32),
-                ("store_slots", C.c_uint32), ("max_in_flight", C.c_uint32), ("search_streams", C.c_uint32), ("kernel_timing", C.c_uint32)]
+                ("store_slots", C.c_uint32), ("max_in_flight", C.c_uint32), ("search_streams", C.c_uint32), ("kernel_timing", C.c_uint32),
+                ("serial_hme", C.c_uint32)]
 
 
 class Tail(C.Structure):
@@ -166,10 +167,11 @@ def derive_tf_controls(hme_me_level):
 class Engine:
     """One engine = one GPU. Pictures are put into the device store once and referenced by key afterwards."""
 
-    def __init__(self, max_width, max_height, store_slots=24, max_in_flight=4, device=0, search_streams=0, kernel_timing=1):
+    def __init__(self, max_width, max_height, store_slots=24, max_in_flight=4, device=0, search_streams=0, kernel_timing=1,
+                 serial_hme=0):
         self.lib = load_library()
         self.h = C.c_void_p()
-        cfg = Config(device, max_width, max_height, store_slots, max_in_flight, search_streams, kernel_timing)
+        cfg = Config(device, max_width, max_height, store_slots, max_in_flight, search_streams, kernel_timing, serial_hme)
         rc = self.lib.svtme_create(C.byref(cfg), C.byref(self.h))
         if rc:
             raise SvtmeError(rc, "svtme_create")

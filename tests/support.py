@@ -84,13 +84,13 @@ def compare_picture(out, bd, pic, where=""):
     return msgs
 
 
-def run_engine_job(frames, pics, enc_mode, sc_class1=0, frame_rate=30 << 16, engine=None, tail=None):
+def run_engine_job(frames, pics, enc_mode, sc_class1=0, frame_rate=30 << 16, engine=None, tail=None, serial_hme=0):
     """Runs every picture of the job through the engine's C ABI; returns the list of output dicts. tail: an
     svtme.Tail to run the host tail on the device as well."""
     import svtme
     n, h, w = frames.shape
     own = engine is None
-    eng = engine or svtme.Engine(w, h, store_slots=n + 1, max_in_flight=2)
+    eng = engine or svtme.Engine(w, h, store_slots=n + 1, max_in_flight=2, serial_hme=serial_hme)
     try:
         for i in range(n):
             eng.store_put(i, i, frames[i])
@@ -105,12 +105,12 @@ def run_engine_job(frames, pics, enc_mode, sc_class1=0, frame_rate=30 << 16, eng
             eng.close()
 
 
-def run_engine_tf_job(frames, pics, level, exit_th, engine=None):
+def run_engine_tf_job(frames, pics, level, exit_th, engine=None, serial_hme=0):
     """Temporal-filter searches (ME_MCTF) of a make_tf_job window through the engine's C ABI."""
     import svtme
     n, h, w = frames.shape
     own = engine is None
-    eng = engine or svtme.Engine(w, h, store_slots=n + 1, max_in_flight=2)
+    eng = engine or svtme.Engine(w, h, store_slots=n + 1, max_in_flight=2, serial_hme=serial_hme)
     try:
         for i in range(n):
             eng.store_put(i, i, frames[i])
@@ -133,10 +133,10 @@ def tf_fields(out):
 
 
 def engine_vs_oracle(width, height, n_frames, enc_mode, seed=1, structure="ra", kind="synth", sc_class1=0,
-                     frame_rate=30 << 16, max_msgs=12):
+                     frame_rate=30 << 16, max_msgs=12, serial_hme=0):
     frames, pics, rc = make_job(width, height, n_frames, enc_mode, seed, structure, kind)
     recs = oracle_handover(frames, pics, enc_mode, rc, sc_class1=sc_class1, frame_rate=frame_rate)
-    outs = run_engine_job(frames, pics, enc_mode, sc_class1, frame_rate)
+    outs = run_engine_job(frames, pics, enc_mode, sc_class1, frame_rate, serial_hme=serial_hme)
     msgs = []
     for p, out, bd in zip(pics, outs, recs):
         msgs += compare_picture(out, bd, p, "poc %d (layer %d, refs %s)" % (p.poc, p.temporal_layer, p.refs))

@@ -58,6 +58,7 @@ def test_engine_matches_reference_goldens(name):
 @pytest.mark.parametrize("w,h,n,mode,structure", [
     (320, 192, 17, 8, "ra"), (328, 200, 17, 12, "ra"), (264, 136, 17, 3, "ra"), (256, 192, 6, 12, "ldp"),
     (320, 192, 9, 10, "ldb"), (200, 136, 17, 13, "ra"), (192, 128, 9, 1, "ra"), (128, 128, 4, -2, "ldb"),
+    (320, 192, 17, 11, "ra"), (256, 192, 9, 13, "ldb"), (264, 200, 9, 12, "ldb"),
 ])
 def test_engine_matches_oracle_small(w, h, n, mode, structure):
     msgs = support.engine_vs_oracle(w, h, n, mode, seed=100 + mode, structure=structure)
@@ -84,6 +85,25 @@ def test_engine_matches_oracle_screen_content_slow_presets():
     for kind in ("flat", "half_static"):  # first-reference 64x64 SADs below the rule's threshold
         msgs = support.engine_vs_oracle(256, 128, 9, 5, seed=24, sc_class1=1, kind=kind)
         assert not msgs, kind + "\n" + "\n".join(msgs)
+
+
+@pytest.mark.parametrize("w,h,n,mode,structure", [(264, 136, 17, 12, "ra"), (256, 192, 9, 13, "ldb"), (256, 192, 9, 11, "ra"),
+                                                  (320, 192, 9, 8, "ra")])
+def test_serial_hme_kernel_matches_oracle(w, h, n, mode, structure):
+    """The diagnostic serial HME kernel (svtme_config.serial_hme) is a second implementation of the same stages."""
+    msgs = support.engine_vs_oracle(w, h, n, mode, seed=200 + mode, structure=structure, serial_hme=1)
+    assert not msgs, "\n".join(msgs)
+
+
+def test_serial_hme_kernel_matches_reference_temporal_filter_golden():
+    c = MOD.TF_CASES["tf0_320x192"]
+    g = np.load(os.path.join(GOLDEN, "tf0_320x192.npz"))
+    frames, pics, _ = MOD.tf_job(c)
+    outs = support.run_engine_tf_job(frames, pics, c["level"], c["exit_th"], serial_hme=1)
+    for i, out in enumerate(outs):
+        want = MOD.tf_canonical(g["b64"][i])
+        for f, v in support.tf_fields(out).items():
+            assert np.array_equal(v, want[f]), (i, f)
 
 
 def test_engine_rejects_what_it_does_not_implement():
@@ -350,10 +370,12 @@ def test_identical_pictures_give_zero_vectors():
     assert (out["search_results"]["do_ref"][:, 0, 0] == 1).all()
 
 
-def test_global_translation_is_recovered():
+@pytest.mark.parametrize("w,h,mode", [(1920, 1080, 6), (3840, 2160, 8), (7680, 4320, 2), (1280, 720, 12)])
+def test_global_translation_is_recovered(w, h, mode):
     """A picture that is a pure translation of its reference: every interior block finds exactly that vector with
-    SAD 0 (noise content makes the match unique); checked at 1080p through the whole HME + integer-search chain."""
-    w, h, dx, dy = 1920, 1080, 8, -4
+    SAD 0 (noise content makes the match unique); checked at the benchmark's full picture sizes (1080p, 4K, 8K, 720p with
+    the presets of those configurations) through the whole pre-HME / HME / integer-search chain."""
+    dx, dy = 8, -4
     big = support.synth.extreme_sequence(w + 64, h + 64, 1, "noise", seed=8)[0]
     ref = big[32:32 + h, 32:32 + w]
     cur = big[32 + dy:32 + dy + h, 32 + dx:32 + dx + w]  # cur(x, y) = ref(x + dx, y + dy)
@@ -361,12 +383,13 @@ def test_global_translation_is_recovered():
     try:
         eng.store_put(0, 0, ref)
         eng.store_put(1, 1, cur)
-        ctrl = svtme.derive_controls(6, w, h)
+        ctrl = svtme.derive_controls(mode, w, h)
         out = eng.run_picture(eng.make_picture(w, h, 1, 1, 1, [[0], []], ctrl))
     finally:
         eng.close()
-    sad = out["best_sad"][:, 0, 0, :].reshape(17, 30, 85)
-    mv = out["best_mv"][:, 0, 0, :].reshape(17, 30, 85)
+    bh, bw = (h + 63) // 64, (w + 63) // 64
+    sad = out["best_sad"][:, 0, 0, :].reshape(bh, bw, 85)
+    mv = out["best_mv"][:, 0, 0, :].reshape(bh, bw, 85)
     expect = ((dy * 4) & 0xFFFF) << 16 | ((dx * 4) & 0xFFFF)
     assert (sad[1:-1, 1:-1] == 0).all()
     assert (mv[1:-1, 1:-1] == expect).all()

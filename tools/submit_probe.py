@@ -6,15 +6,16 @@ for _p in ("svt-av1_amd", "oracle", "tests"):
     sys.path.insert(0, os.path.join(ROOT, _p))
 sys.path.insert(0, ROOT)
 import bench, svtme
-if os.environ.get("PROBE_TORCH"):
+if os.environ.get("PROBE_TORCH") == "1":
     import torch
     torch.cuda.set_device(0)
     torch.cuda.synchronize()
     print("torch initialised")
-wl = dict(bench.WORKLOADS["1080p_ra_m3"], name="1080p_ra_m3")
+WL = sys.argv[1] if len(sys.argv) > 1 else "1080p_ra_m3"
+wl = dict(bench.WORKLOADS[WL], name=WL)
 frames, pics = bench.make_pictures(wl, 1000)
 n, h, w = frames.shape
-eng = svtme.Engine(w, h, store_slots=n + 1, max_in_flight=6, device=0)
+eng = svtme.Engine(w, h, store_slots=n + 1, max_in_flight=6, device=0, kernel_timing=0)
 for i in range(n):
     eng.store_put(i, i, frames[i])
 ctrl = svtme.derive_controls(wl["enc_mode"], w, h)
@@ -35,10 +36,15 @@ for rep in range(3):
     print("rep", rep, "submit us", ["%.0f" % x for x in ts], "all submits %.0f us, drain %.0f us" % ((t1 - t0) * 1e6, (t2 - t1) * 1e6))
 eng.close()
 
-eng = svtme.Engine(w, h, store_slots=n + 1, max_in_flight=6, device=0)
+eng = svtme.Engine(w, h, store_slots=n + 1, max_in_flight=6, device=0, kernel_timing=0)
 for i in range(n):
     eng.store_put(i, i, frames[i])
 descs = [eng.make_picture(w, h, p.poc, p.temporal_layer, p.is_ref, p.refs, ctrl) for p in pics]
+if os.environ.get("PROBE_TORCH") == "late":
+    import torch
+    torch.cuda.set_device(0)
+    torch.cuda.synchronize()
+    print("torch initialised after the engine")
 for mode in ("plain", "timing", "timing+ops", "plain"):
     for rep in range(2):
         tickets = []
