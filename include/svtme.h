@@ -227,12 +227,15 @@ typedef struct svtme_search_result {
     uint64_t hme_sad;
 } svtme_search_result;
 
-/* Per-b64 outputs, in the layout of the MeContext arrays they are copied into. Pointers are engine-owned
- * pinned host memory, valid until svtme_picture_done(). n_b64 = ceil(w/64)*ceil(h/64), raster order. */
+/* Per-b64 outputs. Pointers are engine-owned pinned host memory, valid until svtme_picture_done().
+ * n_b64 = ceil(w/64)*ceil(h/64), raster order. The small arrays are in the layout of the MeContext arrays they are copied
+ * into; the two big ones hold one plane of [n_b64][85] entries per searched reference (list-0 references first, then
+ * list 1: plane = r for list 0, n_ref[0] + r for list 1), so that only references the picture has cross PCIe.
+ * svtme_unpack_b64() turns a block's entries back into MeContext's [2][4][85] arrays. */
 typedef struct svtme_results {
     uint32_t                   n_b64;
-    const uint32_t            *p_sb_best_sad; /* [n_b64][2][4][85], EbMotionEstimationContext.h:367 */
-    const uint32_t            *p_sb_best_mv; /* [n_b64][2][4][85], (y_qpel << 16) | (x_qpel & 0xffff), :368 */
+    const uint32_t            *p_sb_best_sad; /* [n_ref[0] + n_ref[1]][n_b64][85], MeContext::p_sb_best_sad, EbMotionEstimationContext.h:367 */
+    const uint32_t            *p_sb_best_mv; /* same shape, (y_qpel << 16) | (x_qpel & 0xffff), :368 */
     const svtme_search_result *search_results; /* [n_b64][2][4] */
     const uint32_t            *zz_sad; /* [n_b64][2][4], MeContext::zz_sad :471 */
     const uint32_t            *reduce_me_sr_divisor; /* [n_b64][2][4], :400 */
@@ -248,6 +251,7 @@ typedef struct svtme_results {
                                   me_8x8_cost_variance, stationary_block_present_sb, rc_me_allow_gm */
     const uint8_t  *final_do_ref; /* [n_b64][2][4] */
     const uint64_t *final_hme_sad; /* [n_b64][2][4] */
+    uint32_t        n_ref[SVTME_MAX_LISTS]; /* references per list of the picture = planes of the two big arrays */
 } svtme_results;
 
 typedef uint64_t svtme_ticket;

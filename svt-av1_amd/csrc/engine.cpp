@@ -60,27 +60,34 @@ struct Flight {
     uint8_t             *d_res = nullptr; // best_sad | best_mv | search_results | zz | div
     // pinned host mirror of d_res
     uint8_t             *h_res = nullptr;
-    size_t               off_mv = 0, off_sr = 0, off_zz = 0, off_div = 0, off_ops = 0, res_bytes = 0;
-    // result arrays of n (b64, list, ref) entries, packed back to back so that one copy brings them all to the host
-    void layout(size_t n) {
-        off_mv    = n * SVTME_PU_COUNT * 4;
-        off_sr    = off_mv * 2;
+    size_t               off_sad = 0, off_mv = 0, off_sr = 0, off_zz = 0, off_div = 0, off_ops = 0, res_bytes = 0;
+    // One block, laid out per picture so that a single copy brings exactly what the host asked for:
+    //   [search results | zz | divisors | counters] [device-tail outputs, when the picture has a tail]
+    //   [best SAD planes] [best MV planes]: one plane of n_b64 x 85 entries per searched reference (list-0 references
+    //   first, then list 1), so that references a picture does not have cost nothing on the way to the host.
+    void layout(size_t nb, size_t n_refs, bool with_tail) {
+        const size_t n = nb * SVTME_MAX_LISTS * SVTME_MAX_REFS;
+        off_sr    = 0;
         off_zz    = off_sr + n * sizeof(svtme_search_result);
         off_div   = off_zz + n * 4;
         off_ops   = (off_div + n * 4 + 63) / 64 * 64;
-        res_bytes = off_ops + SVTME_OPS_BYTES;
-        // the optional device-side host tail's outputs follow (copied only for pictures that asked for it)
-        const size_t nb = n / (SVTME_MAX_LISTS * SVTME_MAX_REFS);
-        off_thme  = res_bytes;
-        off_tmv   = off_thme + nb * 8 * 8;
-        off_tdist = off_tmv + nb * SVTME_PU_COUNT * SVTME_TAIL_MV_STRIDE * 4;
-        off_tstat = off_tdist + nb * SVTME_PU_COUNT * 4;
-        off_tcand = off_tstat + nb * 8 * 4;
-        off_ttot  = off_tcand + nb * SVTME_PU_COUNT * SVTME_TAIL_CAND_STRIDE;
-        off_tdo   = off_ttot + nb * SVTME_PU_COUNT;
-        tail_end  = (off_tdo + nb * 8 + 63) / 64 * 64;
+        off_thme  = off_ops + SVTME_OPS_BYTES;
+        tail_end  = off_thme;
+        if (with_tail) {
+            off_tmv   = off_thme + nb * 8 * 8;
+            off_tdist = off_tmv + nb * SVTME_PU_COUNT * SVTME_TAIL_MV_STRIDE * 4;
+            off_tstat = off_tdist + nb * SVTME_PU_COUNT * 4;
+            off_tcand = off_tstat + nb * 8 * 4;
+            off_ttot  = off_tcand + nb * SVTME_PU_COUNT * SVTME_TAIL_CAND_STRIDE;
+            off_tdo   = off_ttot + nb * SVTME_PU_COUNT;
+            tail_end  = (off_tdo + nb * 8 + 63) / 64 * 64;
+        }
+        off_sad   = tail_end;
+        off_mv    = off_sad + n_refs * nb * SVTME_PU_COUNT * 4;
+        res_bytes = off_mv + n_refs * nb * SVTME_PU_COUNT * 4;
     }
     size_t off_thme = 0, off_tmv = 0, off_tdist = 0, off_tstat = 0, off_tcand = 0, off_ttot = 0, off_tdo = 0, tail_end = 0;
+    uint32_t n_ref[2] = {0, 0};
     bool   tail = false, skip_search_arrays = false;
     // start, after each of the 2 HME and 3 ME kernels, after D2H
     hipEvent_t           ev[7] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
@@ -185,11 +192,11 @@ extern "C" int svtme_create(const svtme_config *cfg, svtme_engine **out) {
     e->flights.resize(cfg->max_in_flight);
     for (auto &f : e->flights) {
         const size_t n = e->max_b64 * SVTME_MAX_LISTS * SVTME_MAX_REFS;
-        f.layout(n);
-        if (hipMalloc((void **)&f.d_hme, n * sizeof(HmeRefOut) + SVTME_OPS_BYTES) != hipSuccess || hipMalloc((void **)&f.d_res, f.tail_end) != hipSuccess ||
+        f.layout(e->max_b64, SVTME_MAX_LISTS * SVTME_MAX_REFS, true); // the largest a picture can ask for
+        if (hipMalloc((void **)&f.d_hme, n * sizeof(HmeRefOut) + SVTME_OPS_BYTES) != hipSuccess || hipMalloc((void **)&f.d_res, f.res_bytes) != hipSuccess ||
             hipMalloc((void **)&f.d_jobs, n * sizeof(MeJob)) != hipSuccess ||
             hipMalloc((void **)&f.d_keys, n * SVTME_PU_COUNT * sizeof(unsigned long long)) != hipSuccess ||
-            hipHostMalloc((void **)&f.h_res, f.tail_end, hipHostMallocDefault) != hipSuccess)
+            hipHostMalloc((void **)&f.h_res, f.res_bytes, hipHostMallocDefault) != hipSuccess)
             return fail(SVTME_ERR_NO_RESOURCES);
         for (auto &ev : f.ev)
             if (hipEventCreate(&ev) != hipSuccess) return fail(SVTME_ERR_NO_RESOURCES);
@@ -359,7 +366,9 @@ extern "C" int svtme_picture_submit(svtme_engine *e, const svtme_picture *pic, s
     p.serial_refs = e->cfg.serial_hme != 0;
     const size_t n_b64 = (size_t)p.b64_w * p.b64_h;
     if (n_b64 > e->max_b64) return SVTME_ERR_BAD_ARG;
-    f->layout(n_b64 * SVTME_MAX_LISTS * SVTME_MAX_REFS); // never larger than the allocation (n_b64 <= max_b64)
+    f->layout(n_b64, (size_t)(p.n_ref[0] + p.n_ref[1]), pic->tail.enable != 0); // never larger than the allocation (n_b64 <= max_b64)
+    f->n_ref[0] = (uint32_t)p.n_ref[0];
+    f->n_ref[1] = (uint32_t)p.n_ref[1];
     p.hme_out        = f->d_hme;
     p.me_jobs        = f->d_jobs;
     p.me_keys        = f->d_keys;
@@ -370,7 +379,7 @@ extern "C" int svtme_picture_submit(svtme_engine *e, const svtme_picture *pic, s
         const int w_max = (std::max<int>(k.me_sa.sa_max.width, 1) + 7) & ~7, h_max = std::max<int>(k.me_sa.sa_max.height, 3);
         p.me_max_items  = ((w_max + 63) / 64) * ((h_max + 7) / 8);
     }
-    p.best_sad       = reinterpret_cast<uint32_t *>(f->d_res);
+    p.best_sad       = reinterpret_cast<uint32_t *>(f->d_res + f->off_sad);
     p.best_mv        = reinterpret_cast<uint32_t *>(f->d_res + f->off_mv);
     p.search_results = reinterpret_cast<svtme_search_result *>(f->d_res + f->off_sr);
     p.zz_sad         = reinterpret_cast<uint32_t *>(f->d_res + f->off_zz);
@@ -427,8 +436,8 @@ extern "C" int svtme_picture_submit(svtme_engine *e, const svtme_picture *pic, s
     if (sc != sm) HIP_TRY(hipStreamWaitEvent(sc, f->ev[5], 0));
     // tail.enable == 2: the host wants finished results only, the best SAD / MV arrays (the first two blocks) stay on the device
     f->skip_search_arrays = f->tail && pic->tail.enable == 2;
-    const size_t c0 = f->skip_search_arrays ? f->off_sr : 0, c1 = f->tail ? f->tail_end : f->res_bytes;
-    HIP_TRY(hipMemcpyAsync(f->h_res + c0, f->d_res + c0, c1 - c0, hipMemcpyDeviceToHost, sc));
+    const size_t c1 = f->skip_search_arrays ? f->tail_end : f->res_bytes;
+    HIP_TRY(hipMemcpyAsync(f->h_res, f->d_res, c1, hipMemcpyDeviceToHost, sc));
     HIP_TRY(hipEventRecord(f->ev[6], sc));
     f->busy   = true;
     f->waited = false;
@@ -484,8 +493,10 @@ extern "C" int svtme_picture_wait(svtme_engine *e, svtme_ticket ticket, svtme_re
             if (slots[s * 8 + 7]) return SVTME_ERR_DEVICE;
     }
     out->n_b64                = f->n_b64;
-    out->p_sb_best_sad        = f->skip_search_arrays ? nullptr : reinterpret_cast<const uint32_t *>(f->h_res);
+    out->p_sb_best_sad        = f->skip_search_arrays ? nullptr : reinterpret_cast<const uint32_t *>(f->h_res + f->off_sad);
     out->p_sb_best_mv         = f->skip_search_arrays ? nullptr : reinterpret_cast<const uint32_t *>(f->h_res + f->off_mv);
+    out->n_ref[0]             = f->n_ref[0];
+    out->n_ref[1]             = f->n_ref[1];
     out->search_results       = reinterpret_cast<const svtme_search_result *>(f->h_res + f->off_sr);
     out->zz_sad               = reinterpret_cast<const uint32_t *>(f->h_res + f->off_zz);
     out->reduce_me_sr_divisor = reinterpret_cast<const uint32_t *>(f->h_res + f->off_div);
@@ -541,8 +552,20 @@ extern "C" int svtme_unpack_b64(const svtme_results *res, uint32_t b64_index, ui
                                 svtme_search_result *search_results, uint32_t *zz_sad, uint32_t *reduce_me_sr_divisor) {
     if (!res || b64_index >= res->n_b64) return SVTME_ERR_BAD_ARG;
     const size_t n = SVTME_MAX_LISTS * SVTME_MAX_REFS;
-    if (p_sb_best_sad && res->p_sb_best_sad) memcpy(p_sb_best_sad, res->p_sb_best_sad + (size_t)b64_index * n * SVTME_PU_COUNT, n * SVTME_PU_COUNT * 4);
-    if (p_sb_best_mv && res->p_sb_best_mv) memcpy(p_sb_best_mv, res->p_sb_best_mv + (size_t)b64_index * n * SVTME_PU_COUNT, n * SVTME_PU_COUNT * 4);
+    if (res->n_ref[0] > SVTME_MAX_REFS || res->n_ref[1] > SVTME_MAX_REFS) return SVTME_ERR_BAD_ARG;
+    // the planes of the searched references -> MeContext's [list][ref][pu] arrays; references the picture does not have read as zero
+    const uint32_t *src[2] = {res->p_sb_best_sad, res->p_sb_best_mv};
+    uint32_t       *dst[2] = {p_sb_best_sad, p_sb_best_mv};
+    for (int a = 0; a < 2; ++a) {
+        if (!dst[a] || !src[a]) continue;
+        memset(dst[a], 0, n * SVTME_PU_COUNT * 4);
+        for (uint32_t l = 0; l < SVTME_MAX_LISTS; ++l)
+            for (uint32_t r = 0; r < res->n_ref[l]; ++r) {
+                const size_t plane = l ? res->n_ref[0] + r : r;
+                memcpy(dst[a] + (l * SVTME_MAX_REFS + r) * SVTME_PU_COUNT, src[a] + (plane * res->n_b64 + b64_index) * SVTME_PU_COUNT,
+                       SVTME_PU_COUNT * 4);
+            }
+    }
     if (search_results) memcpy(search_results, res->search_results + (size_t)b64_index * n, n * sizeof(svtme_search_result));
     if (zz_sad) memcpy(zz_sad, res->zz_sad + (size_t)b64_index * n, n * 4);
     if (reduce_me_sr_divisor) memcpy(reduce_me_sr_divisor, res->reduce_me_sr_divisor + (size_t)b64_index * n, n * 4);

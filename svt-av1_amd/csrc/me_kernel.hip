@@ -534,20 +534,23 @@ __global__ void __launch_bounds__(ME_THREADS, 2) me_search_kernel(PicParams p) {
     }
 }
 
-// ---- results: p_sb_best_sad / p_sb_best_mv. SADs were taken on every other row: x2 (:248-305). References that were
-// not searched (absent or pruned) read as zero.
+// ---- results: p_sb_best_sad / p_sb_best_mv, one plane per reference of the picture. SADs were taken on every other
+// row: x2 (:248-305). References that were not searched (pruned) read as zero.
 __global__ void __launch_bounds__(256) me_finish_kernel(PicParams p) {
-    const int n = p.b64_w * p.b64_h * 8 * SVTME_PU_COUNT;
+    const int n_b64 = p.b64_w * p.b64_h, per_plane = n_b64 * SVTME_PU_COUNT;
+    const int n = (p.n_ref[0] + p.n_ref[1]) * per_plane;
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (blockIdx.x == 0)
         for (int c = threadIdx.x; c < SVTME_OPS_SLOTS * 8; c += 256) p.ops_out[c] = p.ops[c];
     if (i >= n) return;
-    const int   j   = i / SVTME_PU_COUNT;
+    // output plane q = reference (l, r), list-0 references first
+    const int   q = i / per_plane, rest = i - q * per_plane, b64 = rest / SVTME_PU_COUNT, pu = rest - b64 * SVTME_PU_COUNT;
+    const int   l = q >= p.n_ref[0] ? 1 : 0, r = l ? q - p.n_ref[0] : q;
+    const int   j = b64 * 8 + l * 4 + r;
     const MeJob job = p.me_jobs[j];
-    const u64   key = p.me_keys[i];
+    const u64   key = p.me_keys[(size_t)j * SVTME_PU_COUNT + pu];
     uint32_t    sad = 0, mv = 0;
-    const int   l = (j >> 2) & 1, r = j & 3;
-    if (l < p.n_list && r < p.n_ref[l] && job.w > 0) {
+    if (job.w > 0) {
         const int py = (int)((key >> 16) & 0xFFFF) + job.org_y, px = (int)(key & 0xFFFF) + job.org_x;
         sad = (uint32_t)(key >> 32) << 1;
         mv  = ((uint32_t)(uint16_t)py << 18) | (uint16_t)((uint16_t)px << 2); // :474-476
@@ -577,7 +580,7 @@ void launch_me(const PicParams &p_in, hipStream_t s, hipEvent_t marks[3]) {
     if (marks[0]) (void)hipEventRecord(marks[0], s);
     hipLaunchKernelGGL(me_search_kernel, dim3(n_b64, p.me_max_items, n_now), dim3(ME_THREADS), 0, s, p);
     if (marks[1]) (void)hipEventRecord(marks[1], s);
-    hipLaunchKernelGGL(me_finish_kernel, dim3((n_b64 * 8 * SVTME_PU_COUNT + 255) / 256), dim3(256), 0, s, p);
+    hipLaunchKernelGGL(me_finish_kernel, dim3((n_b64 * n_refs * SVTME_PU_COUNT + 255) / 256), dim3(256), 0, s, p);
     if (marks[2]) (void)hipEventRecord(marks[2], s);
 }
 

@@ -70,8 +70,8 @@ struct PicParams {
     unsigned long long *me_keys; // [n_b64][2][4][85] running minima (SAD << 32 | y << 16 | x), window-relative
     // outputs
     HmeRefOut           *hme_out; // [n_b64][2][4]
-    uint32_t            *best_sad; // [n_b64][2][4][85]
-    uint32_t            *best_mv; // [n_b64][2][4][85]
+    uint32_t            *best_sad; // [n_ref[0] + n_ref[1]][n_b64][85]: a plane per reference, list 0 first
+    uint32_t            *best_mv; // same shape
     svtme_search_result *search_results; // [n_b64][2][4]
     uint32_t            *zz_sad; // [n_b64][2][4]
     uint32_t            *sr_divisor; // [n_b64][2][4]

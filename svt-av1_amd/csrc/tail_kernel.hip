@@ -48,8 +48,12 @@ __global__ void __launch_bounds__(TAIL_THREADS) me_tail_kernel(PicParams p) {
     const int             b64  = blockIdx.x;
     const int             b64x = (b64 % p.b64_w) * 64, b64y = (b64 / p.b64_w) * 64;
     const uint32_t        block_w = (uint32_t)min(p.width - b64x, 64), block_h = (uint32_t)min(p.height - b64y, 64);
-    const uint32_t       *bs = p.best_sad + (size_t)b64 * 8 * SVTME_PU_COUNT; // [2][4][85]
-    const uint32_t       *bm = p.best_mv + (size_t)b64 * 8 * SVTME_PU_COUNT;
+    // best SAD / MV of reference (l, r), partition n: one plane per reference of the picture, list 0 first
+    const size_t plane = (size_t)p.b64_w * p.b64_h * SVTME_PU_COUNT;
+    auto         at = [&](const uint32_t *a, int l, int r, int n) -> uint32_t {
+        return a[(size_t)(l ? p.n_ref[0] + r : r) * plane + (size_t)b64 * SVTME_PU_COUNT + n];
+    };
+    const uint32_t *bs = p.best_sad, *bm = p.best_mv;
     const svtme_search_result *sr = p.search_results + (size_t)b64 * 8;
     uint8_t  *o_total = p.t_total_cand + (size_t)b64 * SVTME_PU_COUNT;
     uint32_t *o_mv    = p.t_mv_array + (size_t)b64 * SVTME_PU_COUNT * SVTME_TAIL_MV_STRIDE;
@@ -78,7 +82,7 @@ __global__ void __launch_bounds__(TAIL_THREADS) me_tail_kernel(PicParams p) {
             for (int r = 0; r < p.n_ref[l]; ++r) {
                 const int i = l * 4 + r;
                 u64       v = (u64)SVTME_MAX_SAD_VALUE * 64;
-                if (S.do_ref[i]) v = wave_sum(bs[i * SVTME_PU_COUNT + 21 + lane]);
+                if (S.do_ref[i]) v = wave_sum(at(bs, l, r, 21 + lane));
                 __syncthreads();
                 if (lane == 0) S.hme_sad[i] = v;
             }
@@ -117,13 +121,13 @@ __global__ void __launch_bounds__(TAIL_THREADS) me_tail_kernel(PicParams p) {
             if (n_list < 2 || !S.do_ref[4]) n_list = 1;
             const uint32_t prune_th = (org[0] && org[1]) ? (uint32_t)k.prune_me_candidates_th : 0;
             uint8_t        dr[2] = {org[0], org[1]};
-            const uint32_t s0 = bs[n], s1 = bs[4 * SVTME_PU_COUNT + n];
+            const uint32_t s0 = at(bs, 0, 0, n), s1 = at(bs, 1, 0, n);
             const uint32_t best = prune_th > 0 ? min(s0, s1) : ~0u;
             int            min_list = -1;
             if (k.use_best_unipred_cand_only && dr[0] && dr[1]) min_list = s0 < s1 ? 0 : 1;
             for (uint32_t l = 0; l < n_list && (use || off == 0); ++l) {
                 if (!dr[l]) continue;
-                const uint32_t sad = l ? s1 : s0, mv = bm[l * 4 * SVTME_PU_COUNT + n];
+                const uint32_t sad = l ? s1 : s0, mv = at(bm, (int)l, 0, n);
                 if (prune_th > 0) {
                     const uint32_t d = (sad - best) * 100;
                     if (d > best * prune_th) {
@@ -156,12 +160,12 @@ __global__ void __launch_bounds__(TAIL_THREADS) me_tail_kernel(PicParams p) {
             if (prune_th > 0)
                 for (int l = 0; l < p.n_list; ++l)
                     for (int r = 0; r < p.n_ref[l]; ++r)
-                        if (S.do_ref[l * 4 + r]) best = min(best, bs[(l * 4 + r) * SVTME_PU_COUNT + n]);
+                        if (S.do_ref[l * 4 + r]) best = min(best, at(bs, l, r, n));
             for (int l = 0; l < p.n_list && (use || off == 0); ++l)
                 for (int r = 0; r < p.n_ref[l] && (use || off == 0); ++r) {
                     dr[l][r] = S.do_ref[l * 4 + r];
                     if (!dr[l][r]) continue;
-                    const uint32_t sad = bs[(l * 4 + r) * SVTME_PU_COUNT + n];
+                    const uint32_t sad = at(bs, l, r, n);
                     if (prune_th > 0) {
                         const uint32_t d = (sad - best) * 100;
                         if (d > best * prune_th) {
@@ -173,7 +177,7 @@ __global__ void __launch_bounds__(TAIL_THREADS) me_tail_kernel(PicParams p) {
                     if (use) {
                         ca[off] = me_cand(l, r, r, 0, l == 1 ? 1 : 0);
                         if (off == 0) S.first_cand[pu] = ca[0];
-                        o_mv[pu * t.max_refs + (l ? t.max_l0 : 0) + r] = bm[(l * 4 + r) * SVTME_PU_COUNT + n];
+                        o_mv[pu * t.max_refs + (l ? t.max_l0 : 0) + r] = at(bm, l, r, n);
                     }
                     off++;
                 }
@@ -245,7 +249,7 @@ __global__ void __launch_bounds__(TAIL_THREADS) me_tail_kernel(PicParams p) {
             const int     dist = (int)(uint16_t)p.dist[l][r];
             const int     th = low_res ? (t.gm_use_distance_based_active_th ? max(dist >> 1, 4) : 4)
                                        : (t.gm_use_distance_based_active_th ? max(dist * 16, 32) : 32);
-            const uint32_t mv = bm[(l * 4 + r) * SVTME_PU_COUNT + idx];
+            const uint32_t mv = at(bm, l, r, idx);
             const int      mx = (int16_t)(mv & 0xFFFF), my = (int16_t)(mv >> 16);
             uint32_t      *c  = &S.cnt[(l * 4 + r) * 4];
             if (mx < -th) atomicAdd(&c[0], 1u);

@@ -103,7 +103,7 @@ class Results(C.Structure):
                 ("total_me_candidate_index", C.POINTER(C.c_uint8)), ("me_mv_array", C.POINTER(C.c_uint32)),
                 ("me_candidate_array", C.POINTER(C.c_uint8)), ("me_distortion", C.POINTER(C.c_uint32)),
                 ("b64_stats", C.POINTER(C.c_uint32)), ("final_do_ref", C.POINTER(C.c_uint8)),
-                ("final_hme_sad", C.POINTER(C.c_uint64))]
+                ("final_hme_sad", C.POINTER(C.c_uint64)), ("n_ref", C.c_uint32 * MAX_LISTS)]
 
 
 EXPORTS = ("svtme_version", "svtme_derive_controls", "svtme_derive_tf_controls", "svtme_input_resolution", "svtme_create", "svtme_destroy",
@@ -249,9 +249,16 @@ class Engine:
             raise SvtmeError(rc, "svtme_picture_wait")
         n = r.n_b64
         out = {}
-        if r.p_sb_best_sad:  # NULL for pictures submitted with tail.enable == 2
-            out["best_sad"] = np.ctypeslib.as_array(r.p_sb_best_sad, (n, 2, 4, 85))
-            out["best_mv"] = np.ctypeslib.as_array(r.p_sb_best_mv, (n, 2, 4, 85))
+        if r.p_sb_best_sad and copy:  # NULL for pictures submitted with tail.enable == 2
+            # one [n_b64][85] plane per reference of the picture (list 0 first) -> MeContext's [list][ref][pu] order
+            n_ref = [int(r.n_ref[0]), int(r.n_ref[1])]
+            for name, ptr in (("best_sad", r.p_sb_best_sad), ("best_mv", r.p_sb_best_mv)):
+                planes = np.ctypeslib.as_array(ptr, (n_ref[0] + n_ref[1], n, 85))
+                full = np.zeros((n, 2, 4, 85), np.uint32)
+                for l in range(2):
+                    for i in range(n_ref[l]):
+                        full[:, l, i] = planes[(n_ref[0] if l else 0) + i]
+                out[name] = full
         out.update({
             "zz_sad": np.ctypeslib.as_array(r.zz_sad, (n, 2, 4)),
             "sr_divisor": np.ctypeslib.as_array(r.reduce_me_sr_divisor, (n, 2, 4)),
