@@ -288,6 +288,31 @@ int orc_derive_tf_controls(uint8_t level, svtme_controls *c) {
     return 0;
 }
 
+/* first_pass_signal_derivation_me_kernel, firstpass.c:674-716: set_first_pass_me_hme_params_oq (:627-662), every HME
+ * level on (first_pass_signal_derivation_multi_processes :488-491) except level 2 with reduce_me_search, no pre-HME, no
+ * pruning, no search-range adjustment. */
+int orc_derive_first_pass_controls(uint8_t res, uint32_t frame_rate, uint8_t reduce_me_search, svtme_controls *c) {
+    if (!c || res > 6) return -1;
+    memset(c, 0, sizeof(*c));
+    c->stat_factor  = 100;
+    c->num_hme_sa_w = c->num_hme_sa_h = 2;
+    c->me_sa.sa_min = reduce_me_search ? sa(8, 3) : sa(8, 8);
+    c->me_sa.sa_max = reduce_me_search ? sa(8, 5) : sa(8, 8);
+    c->hme_l0_sa.sa_min = res < 4 ? sa(4, 4) : sa(8, 8); /* INPUT_SIZE_1080p_RANGE = 4 */
+    c->hme_l0_sa.sa_max = sa(96, 96);
+    c->hme_l1_sa = sa(8, 8);
+    c->hme_l2_sa = sa(8, 8);
+    if ((frame_rate >> 16) < 50) {
+        c->me_sa.sa_min.width  = (uint16_t)((c->me_sa.sa_min.width * 3) >> 1);
+        c->me_sa.sa_min.height = (uint16_t)((c->me_sa.sa_min.height * 3) >> 1);
+    }
+    c->enable_hme_flag = c->enable_hme_level0_flag = c->enable_hme_level1_flag = 1;
+    c->enable_hme_level2_flag = !reduce_me_search;
+    c->prune_ref_if_hme_sad_dev_bigger_than_th = 0xFFFF;
+    c->prune_ref_if_me_sad_dev_bigger_than_th  = 0xFFFF;
+    return 0;
+}
+
 /* ----------------------------------------------------------------------------------------------- ME context */
 
 typedef struct orc_search_info {
@@ -781,7 +806,8 @@ static void orc_integer_search(orc_ctx *c, const orc_pic *pic, int ox, int oy) {
                 if (c->zz_sad[l][r] < k->me_early_exit_th / 6) w = h = 1;
             } else {
                 int accurate = 1;
-                if ((cx != 0 || cy != 0) && pic->is_ref) {
+                /* :1363-1364: the first pass may bypass the zero-vector check */
+                if (!(pic->me_type == 4 && pic->bypass_zz_check) && (cx != 0 || cy != 0) && pic->is_ref) {
                     best_hme_sad = orc_check_00(c, pic, l, r, ox, oy, &cx, &cy);
                     if (cx == 0 && cy == 0) accurate = 0;
                 }
@@ -1059,7 +1085,7 @@ static void orc_tail(orc_ctx *c, const orc_pic *pic) {
     if (k->enable_hme_flag && k->enable_me_hme_ref_pruning) orc_me_prune(c, pic);
     if (pic->n_ref[0] == 1 && pic->n_ref[1] == 1) orc_cands_mrp_off(c, pic);
     else orc_cands(c, pic);
-    orc_distortion(c, pic, c->block_w, c->block_h);
+    if (pic->me_type != 4) orc_distortion(c, pic, c->block_w, c->block_h); /* :2990 */
     c->stationary = c->allow_gm = 0;
     if (pic->gm_enabled) orc_gm_detection(c, pic);
 }

@@ -36,6 +36,8 @@ void orc_planes_free(orc_planes *p);
 int     orc_derive_controls(const svtme_preset_key *key, svtme_controls *out);
 /* tf_signal_derivation_me_kernel_oq (EbMotionEstimationProcess.c:554-629) for pcs->tf_ctrls.hme_me_level 0..2 */
 int     orc_derive_tf_controls(uint8_t hme_me_level, svtme_controls *out);
+/* first_pass_signal_derivation_me_kernel (firstpass.c:674-716) with set_first_pass_me_hme_params_oq (:627-662) */
+int     orc_derive_first_pass_controls(uint8_t input_resolution, uint32_t frame_rate, uint8_t reduce_me_search, svtme_controls *out);
 uint8_t orc_input_resolution(uint32_t width, uint32_t height);
 
 typedef struct orc_pic {
@@ -50,8 +52,10 @@ typedef struct orc_pic {
     uint8_t enable_me_8x8, enable_me_16x16, max_cand, max_refs, max_l0, input_resolution;
     uint8_t gm_enabled, gm_use_distance_based_active_th;
     /* MeContext::me_type: 0 = ME_OPEN_LOOP, 1 = ME_MCTF (temporal-filter search of one neighbour frame: one list, one
-     * reference, no pruning, no host tail), and MeContext::tf_me_exit_th */
+     * reference, no pruning, no host tail), 4 = ME_FIRST_PASS (no compute_distortion; check_00_center skipped when
+     * bypass_zz_check), and MeContext::tf_me_exit_th */
     uint8_t  me_type;
+    uint8_t  bypass_zz_check; /* scs->ipp_pass_ctrls.bypass_zz_check, ME_FIRST_PASS only */
     uint16_t tf_me_exit_th;
 } orc_pic;
 

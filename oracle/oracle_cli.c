@@ -60,6 +60,11 @@ static void fill_pic(orc_pic *p, const ref_job_header *h, const ref_job_pic *jp,
         if (orc_derive_tf_controls(jp->tf_hme_me_level, &p->ctrl)) die("bad temporal-filter level");
         p->me_type = 1;
         p->tf_me_exit_th = jp->tf_me_exit_th;
+    } else if (jp->me_type == 4) {
+        if (orc_derive_first_pass_controls(key.input_resolution, jp->frame_rate, (jp->tf_hme_me_level >> 1) & 1, &p->ctrl))
+            die("bad first-pass controls");
+        p->me_type = 4;
+        p->bypass_zz_check = jp->tf_hme_me_level & 1;
     } else if (orc_derive_controls(&key, &p->ctrl)) die("bad preset");
     p->input_resolution = key.input_resolution;
     p->enable_me_8x8 = enable_me_8x8(jp->enc_mode, key.input_resolution);
@@ -71,6 +76,12 @@ static void fill_pic(orc_pic *p, const ref_job_header *h, const ref_job_pic *jp,
     p->max_l0 = (uint8_t)l0;
     p->gm_enabled = jp->gm_enabled;
     p->gm_use_distance_based_active_th = jp->gm_dist_th;
+    if (jp->me_type == 4) { /* firstpass.c:1273-1276 and set_gm_controls(pcs, 0), :702-703 */
+        p->max_cand = 3;
+        p->max_refs = 2;
+        p->max_l0 = 1;
+        p->gm_enabled = 0;
+    }
 }
 
 int main(int argc, char **argv) {

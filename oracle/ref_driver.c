@@ -46,6 +46,8 @@ uint8_t get_disallow_below_16x16_picture_level(EbEncMode enc_mode, EbInputResolu
                                                uint8_t temporal_layer_index);
 uint8_t get_enable_me_16x16(EbEncMode enc_mode);
 EbErrorType tf_signal_derivation_me_kernel_oq(PictureParentControlSet *pcs_ptr, MotionEstimationContext_t *context_ptr);
+EbErrorType first_pass_signal_derivation_me_kernel(SequenceControlSet *scs_ptr, PictureParentControlSet *pcs_ptr,
+                                                   MotionEstimationContext_t *context_ptr);
 void    get_max_allocated_me_refs(uint8_t ref_count_used_list0, uint8_t ref_count_used_list1,
                                   uint8_t *max_ref_to_alloc, uint8_t *max_cand_to_alloc);
 
@@ -207,6 +209,10 @@ static void setup_pic(const Job *job, uint32_t pi, PicState *st) {
     scs->static_config.enc_mode                 = (int8_t)jp->enc_mode;
     scs->sb_sz                                  = 64;
     scs->ipp_pass_ctrls.bypass_zz_check         = 0;
+    if (jp->me_type == ME_FIRST_PASS) { /* what EbEncHandle.c:3040-3070 sets per first-pass level */
+        scs->ipp_pass_ctrls.bypass_zz_check  = jp->tf_hme_me_level & 1;
+        scs->ipp_pass_ctrls.reduce_me_search = (jp->tf_hme_me_level >> 1) & 1;
+    }
 
     pcs->scs_ptr        = scs;
     pcs->picture_number = jp->picture_number;
@@ -234,6 +240,8 @@ static void setup_pic(const Job *job, uint32_t pi, PicState *st) {
         pcs->enable_hme_level1_flag = 0;
         pcs->enable_hme_level2_flag = 0;
     }
+    if (jp->me_type == ME_FIRST_PASS) /* first_pass_signal_derivation_multi_processes, firstpass.c:488-491 */
+        pcs->enable_hme_level1_flag = pcs->enable_hme_level2_flag = 1;
     pcs->use_best_me_unipred_cand_only = pcs->enc_mode <= ENC_M9 ? 0 : 1; /* :2058-2061 */
     pcs->enable_me_8x8 = !get_disallow_below_16x16_picture_level(
         pcs->enc_mode, scs->input_resolution, B_SLICE, 0, 1, 0); /* EbPictureControlSet.c:1533 */
@@ -276,6 +284,11 @@ static void setup_pic(const Job *job, uint32_t pi, PicState *st) {
     md->max_cand = max_cand;
     md->max_refs = max_refs;
     md->max_l0   = (uint8_t)job->hdr.ref_count_used_list0;
+    if (jp->me_type == ME_FIRST_PASS) { /* "assume max 2 references for first pass", firstpass.c:1273-1276 */
+        md->max_cand = 3;
+        md->max_refs = 2;
+        md->max_l0   = 1;
+    }
     md->me_results = (MeSbResults **)calloc(st->n_b64, sizeof(MeSbResults *));
     for (uint32_t i = 0; i < st->n_b64; ++i) {
         MeSbResults *r = (MeSbResults *)calloc(1, sizeof(*r));
@@ -385,6 +398,11 @@ static void *worker_main(void *arg) {
         m->me_type = ME_MCTF;
         tf_signal_derivation_me_kernel_oq(pcs, &mectx);
         m->hme_search_method = FULL_SAD_SEARCH;
+    } else if (jp->me_type == ME_FIRST_PASS) {
+        /* first_pass_me's thread: EbMotionEstimationProcess.c:687-689 / :696, then first_pass_setup_me_context per block
+         * (firstpass.c:1166-1188) */
+        m->me_type = ME_FIRST_PASS;
+        first_pass_signal_derivation_me_kernel(scs, pcs, &mectx);
     } else {
         m->me_type = ME_OPEN_LOOP;
         signal_derivation_me_kernel_oq(scs, pcs, &mectx);
@@ -418,7 +436,7 @@ static void *worker_main(void *arg) {
                                                                    cur->sixteenth.origin_x + (ox >> 2)];
                 m->sixteenth_b64_buffer_stride = cur->sixteenth.stride_y;
             }
-            m->me_type = jp->me_type == ME_MCTF ? ME_MCTF : ME_OPEN_LOOP;
+            m->me_type = jp->me_type == ME_MCTF ? ME_MCTF : (jp->me_type == ME_FIRST_PASS ? ME_FIRST_PASS : ME_OPEN_LOOP);
             m->tf_me_exit_th             = jp->tf_me_exit_th;
             m->tf_use_pred_64x64_only_th = 0;
             m->num_of_list_to_search       = jp->n_list;

@@ -47,8 +47,10 @@ typedef struct ref_job_pic {
     uint8_t  gm_dist_th;
     uint32_t ref_frame[2][4];
     uint64_t ref_poc[2][4];
-    /* temporal-filter searches (me_type 1 = ME_MCTF, EbMotionEstimationContext.h:46; 0 = ME_OPEN_LOOP): controls come
-     * from tf_signal_derivation_me_kernel_oq with pcs->tf_ctrls.hme_me_level, and MeContext::tf_me_exit_th */
+    /* me_type 0 = ME_OPEN_LOOP. 1 = ME_MCTF (EbMotionEstimationContext.h:46), the temporal filter's search: controls from
+     * tf_signal_derivation_me_kernel_oq with pcs->tf_ctrls.hme_me_level = tf_hme_me_level, MeContext::tf_me_exit_th.
+     * 4 = ME_FIRST_PASS (:49), the first pass of a two-pass encode: controls from first_pass_signal_derivation_me_kernel
+     * with scs->ipp_pass_ctrls.bypass_zz_check = tf_hme_me_level & 1 and .reduce_me_search = (tf_hme_me_level >> 1) & 1 */
     uint8_t  me_type;
     uint8_t  tf_hme_me_level;
     uint16_t tf_me_exit_th;

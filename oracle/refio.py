@@ -60,10 +60,13 @@ _OUT = "<8sIIIIIIdQ"
 
 
 def write_job(path, frames, pics, enc_mode, *, mode=MODE_DUMP, threads=1, use_avx2=0, reps=1,
-              frame_rate=30 << 16, sc_class1=0, gm_enabled=0, gm_dist_th=0, ref_counts=(4, 3), tf=None):
+              frame_rate=30 << 16, sc_class1=0, gm_enabled=0, gm_dist_th=0, ref_counts=(4, 3), tf=None, first_pass=None):
     """frames: uint8 [n, h, w]; pics: list of svtme.gop.Picture (refs are POCs = frame indices).
     tf = (hme_me_level, me_exit_th) runs every picture as a temporal-filter search (ME_MCTF) of its first list-0
-    reference: the controls then come from tf_signal_derivation_me_kernel_oq and enc_mode is not used."""
+    reference: the controls then come from tf_signal_derivation_me_kernel_oq and enc_mode is not used.
+    first_pass = (bypass_zz_check, reduce_me_search) runs every picture as first-pass ME (ME_FIRST_PASS): controls from
+    first_pass_signal_derivation_me_kernel; enc_mode only selects the HME level flags."""
+    variant = (1, tf[0], tf[1]) if tf else ((4, (first_pass[0] & 1) | ((first_pass[1] & 1) << 1), 0) if first_pass else (0, 0, 0))
     n, h, w = frames.shape
     with open(path, "wb") as f:
         f.write(struct.pack(_HDR, b"SVTMEJ01", w, h, n, len(pics), mode, threads, use_avx2, reps,
@@ -77,7 +80,7 @@ def write_job(path, frames, pics, enc_mode, *, mode=MODE_DUMP, threads=1, use_av
             n_list = 2 if p.refs[1] else 1
             f.write(struct.pack(_PIC, p.poc, frame_rate, p.poc, enc_mode, p.temporal_layer, p.is_ref, n_list,
                                 len(p.refs[0]), len(p.refs[1]), sc_class1, gm_enabled, gm_dist_th,
-                                *rf[0], *rf[1], *rf[0], *rf[1], *((1, tf[0], tf[1]) if tf else (0, 0, 0))))
+                                *rf[0], *rf[1], *rf[0], *rf[1], *variant))
 
 
 def read_dump(path):

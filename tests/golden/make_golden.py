@@ -59,6 +59,23 @@ TF_DIGEST_CASES = {
 }
 
 
+# first-pass ME of two-pass encodes (ME_FIRST_PASS): bypass_zz / reduce_me = scs->ipp_pass_ctrls.bypass_zz_check / reduce_me_search
+FP_CASES = {
+    "fp_320x192": dict(width=320, height=192, n_frames=5, bypass_zz=0, reduce_me=0, seed=61),
+    "fp_fast_264x136": dict(width=264, height=136, n_frames=5, bypass_zz=1, reduce_me=1, seed=62, motion=(5, 3)),
+    "fp_static_256x128": dict(width=256, height=128, n_frames=4, bypass_zz=0, reduce_me=1, seed=63, kind="half_static"),
+    "fp_fps60_1280x720": dict(width=1280, height=720, n_frames=3, bypass_zz=1, reduce_me=0, seed=64, frame_rate=60 << 16,
+                              motion=(-7, 2)),
+}
+
+
+def fp_job(c):
+    frames, pics = support.make_first_pass_job(c["width"], c["height"], c["n_frames"], c["seed"], c.get("kind", "synth"),
+                                               c.get("motion", (3, -2)))
+    return frames, pics, dict(first_pass=(c["bypass_zz"], c["reduce_me"]), frame_rate=c.get("frame_rate", 30 << 16),
+                              ref_counts=(2, 0), gm_enabled=1, gm_dist_th=1)
+
+
 def tf_job(c):
     frames, pics = support.make_tf_job(c["width"], c["height"], c["n_frames"], c["seed"], c.get("kind", "synth"),
                                        c.get("motion", (3, -2)))
@@ -105,6 +122,14 @@ def main():
                             frames_sha256=np.array(hashlib.sha256(frames.tobytes()).hexdigest()))
         print(name, "pairs", len(pics), "b64", bd.shape[1], "exits", int(bd["tf_me_exit"].sum()), "bytes",
               os.path.getsize(os.path.join(HERE, name + ".npz")))
+    for name, c in FP_CASES.items():
+        frames, pics, kw = fp_job(c)
+        hdr, recs = refio.run_reference(frames, pics, 8, threads=1, use_avx2=0, **kw)
+        pd = np.stack([r[0] for r in recs])
+        bd = np.stack([r[1] for r in recs])
+        np.savez_compressed(os.path.join(HERE, name + ".npz"), pic=pd, b64=bd,
+                            frames_sha256=np.array(hashlib.sha256(frames.tobytes()).hexdigest()))
+        print(name, "pics", len(pics), "b64", bd.shape[1], "bytes", os.path.getsize(os.path.join(HERE, name + ".npz")))
     digests = {}
     for name, c in TF_DIGEST_CASES.items():
         frames, pics, recs = run_tf_case(c, threads=8)

@@ -45,6 +45,20 @@ def make_tf_job(width, height, n_frames, seed=1, kind="synth", motion=(3, -2)):
     return frames, pics
 
 
+def make_first_pass_job(width, height, n_frames, seed=1, kind="synth", motion=(3, -2)):
+    """First-pass ME of a two-pass encode: every frame after the first searches the previous frame and, from the third
+    frame on, the first ("golden") frame as well: one list, base layer, used as reference (firstpass.c:1166-1186)."""
+    if kind in ("synth", "half_static"):
+        frames = synth.synth_sequence(width, height, n_frames, seed=seed, motion=motion)
+        if kind == "half_static":
+            frames[:, :, :width // 2] = frames[0, :, :width // 2]
+    else:
+        frames = synth.extreme_sequence(width, height, n_frames, kind, seed=seed)
+    pics = [gop.Picture(poc=i, temporal_layer=0, is_ref=1, refs=[[i - 1] + ([0] if i >= 2 else []), []])
+            for i in range(1, n_frames)]
+    return frames, pics
+
+
 def oracle_handover(frames, pics, enc_mode, ref_counts, threads=8, **kw):
     """Oracle state right after integer_search_b64 for every picture: list of b64 record arrays."""
     _, recs = refio.run_oracle(frames, pics, enc_mode, mode=refio.MODE_DUMP_NOTAIL, threads=threads,
