@@ -117,6 +117,14 @@ int svtme_derive_controls(const svtme_preset_key *key, svtme_controls *out);
  */
 int svtme_derive_tf_controls(uint8_t hme_me_level, svtme_controls *out);
 
+/*
+ * Controls of the first pass of a two-pass encode: first_pass_signal_derivation_me_kernel() with
+ * set_first_pass_me_hme_params_oq() (firstpass.c:627-716) and the HME level flags of
+ * first_pass_signal_derivation_multi_processes() (:488-491). reduce_me_search = scs->ipp_pass_ctrls.reduce_me_search.
+ */
+int svtme_derive_first_pass_controls(uint8_t input_resolution, uint32_t frame_rate, uint8_t reduce_me_search,
+                                     svtme_controls *out);
+
 /* derive_input_resolution(), Source/Lib/Encoder/Codec/EbSequenceControlSet.c:396-415. */
 uint8_t svtme_input_resolution(uint32_t width, uint32_t height);
 
@@ -185,6 +193,7 @@ typedef struct svtme_tail {
 /* MeContext::me_type (EbMotionEstimationContext.h:44-50). */
 #define SVTME_ME_OPEN_LOOP 0 /* ME_OPEN_LOOP: the pre-analysis search of motion_estimation_kernel() */
 #define SVTME_ME_MCTF 1 /* ME_MCTF: the temporal filter's search of one neighbour frame */
+#define SVTME_ME_FIRST_PASS 4 /* ME_FIRST_PASS: the first pass of a two-pass encode (firstpass.c:1237-1300) */
 
 /* One picture's ME job: what motion_estimation_kernel() sets on MeContext before the b64 loop
  * (EbMotionEstimationProcess.c:795-837) plus the pcs/scs fields integer_search_b64 reads.
@@ -197,7 +206,14 @@ typedef struct svtme_tail {
  * comparing it with the zero vector (:1231-1241); no reference pruning or search-range adjustment (:2952); a block whose
  * HME SAD is below tf_me_exit_th is not searched at all (:2958-2962): its search_results[0][0].tf_me_exit is 1 (the
  * caller sets tf_use_pred_64x64_only_th = ~0) and its minima read as zero; tail must be off (:2977). The
- * tf_tot_horz_blks / tf_tot_vert_blks counters (:2365-2370) follow from search_results[0][0].hme_sc_x / hme_sc_y. */
+ * tf_tot_horz_blks / tf_tot_vert_blks counters (:2365-2370) follow from search_results[0][0].hme_sc_x / hme_sc_y.
+ *
+ * me_type = SVTME_ME_FIRST_PASS is first_pass_me()'s call (firstpass.c:1237-1300): one list of up to two references (the
+ * previous and the golden frame, :1177-1186), temporal layer 0, used as reference, ctrl from
+ * svtme_derive_first_pass_controls(). Differences: check_00_center is skipped when bypass_zz_check
+ * (scs->ipp_pass_ctrls.bypass_zz_check, EbMotionEstimation.c:1363-1364) and the host tail has no compute_distortion
+ * (:2990; a device tail leaves those statistics zero). Skipped frames and blocks (MeContext::skip_frame,
+ * bypass_blk_step) are the caller's business: it does not submit / does not read them. */
 typedef struct svtme_picture {
     uint64_t cur_key; /* store key of the current picture */
     uint64_t picture_number; /* pcs->picture_number */
@@ -207,8 +223,9 @@ typedef struct svtme_picture {
     uint8_t  is_used_as_reference_flag;
     uint8_t  num_of_list_to_search; /* 1 for P, 2 for B */
     uint8_t  num_of_ref_pic_to_search[SVTME_MAX_LISTS]; /* ref_list{0,1}_count_try */
-    uint8_t  me_type; /* SVTME_ME_OPEN_LOOP or SVTME_ME_MCTF */
-    uint8_t  reserved[2];
+    uint8_t  me_type; /* SVTME_ME_OPEN_LOOP, SVTME_ME_MCTF or SVTME_ME_FIRST_PASS */
+    uint8_t  bypass_zz_check; /* SVTME_ME_FIRST_PASS only */
+    uint8_t  reserved;
     uint64_t ref_key[SVTME_MAX_LISTS][SVTME_MAX_REFS]; /* store keys of pcs->ref_pa_pic_ptr_array */
     uint64_t ref_picture_number[SVTME_MAX_LISTS][SVTME_MAX_REFS];
     svtme_controls ctrl;

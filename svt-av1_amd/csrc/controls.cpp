@@ -97,6 +97,29 @@ extern "C" int svtme_derive_tf_controls(uint8_t hme_me_level, svtme_controls *c)
     return SVTME_OK;
 }
 
+extern "C" int svtme_derive_first_pass_controls(uint8_t input_resolution, uint32_t frame_rate, uint8_t reduce_me_search,
+                                                svtme_controls *c) {
+    if (!c || input_resolution > 6 || reduce_me_search > 1) return SVTME_ERR_BAD_ARG;
+    memset(c, 0, sizeof(*c));
+    // set_first_pass_me_hme_params_oq, firstpass.c:627-662
+    c->stat_factor  = 100;
+    c->num_hme_sa_w = c->num_hme_sa_h = 2;
+    c->me_sa     = reduce_me_search ? mk(8, 3, 8, 5) : mk(8, 8, 8, 8);
+    c->hme_l0_sa = input_resolution < RES_1080P ? mk(4, 4, 96, 96) : mk(8, 8, 96, 96);
+    c->hme_l1_sa = c->hme_l2_sa = svtme_sa{8, 8};
+    if ((frame_rate >> 16) < 50) { // low frame rate: minimum area x1.5
+        c->me_sa.sa_min.width  = (uint16_t)((c->me_sa.sa_min.width * 3) >> 1);
+        c->me_sa.sa_min.height = (uint16_t)((c->me_sa.sa_min.height * 3) >> 1);
+    }
+    // every HME level on (:488-491), level 2 off with the reduced search (:684-690); SUB_SAD_SEARCH; no pre-HME, no
+    // pruning, no search-range adjustment (:692-711)
+    c->enable_hme_flag = c->enable_hme_level0_flag = c->enable_hme_level1_flag = 1;
+    c->enable_hme_level2_flag = !reduce_me_search;
+    c->prune_ref_if_hme_sad_dev_bigger_than_th = 0xFFFF;
+    c->prune_ref_if_me_sad_dev_bigger_than_th  = 0xFFFF;
+    return SVTME_OK;
+}
+
 extern "C" int svtme_derive_controls(const svtme_preset_key *key, svtme_controls *c) {
     if (!key || !c) return SVTME_ERR_BAD_ARG;
     const int m = key->enc_mode, sc = key->sc_class1 != 0, res = key->input_resolution;

@@ -305,7 +305,9 @@ extern "C" int svtme_picture_submit(svtme_engine *e, const svtme_picture *pic, s
         return SVTME_ERR_BAD_ARG;
     // not implemented on the device: full-SAD integer search (nothing in the encoder selects it)
     if (k.me_search_method != 0) return SVTME_ERR_UNSUPPORTED;
-    if (pic->tail.enable > 2 || pic->me_type > SVTME_ME_MCTF) return SVTME_ERR_BAD_ARG;
+    if (pic->tail.enable > 2 || (pic->me_type != SVTME_ME_OPEN_LOOP && pic->me_type != SVTME_ME_MCTF && pic->me_type != SVTME_ME_FIRST_PASS) ||
+        pic->bypass_zz_check > 1)
+        return SVTME_ERR_BAD_ARG;
     // the temporal filter searches one neighbour frame at a time and has no host tail (EbTemporalFiltering.c:4844-4847,
     // EbMotionEstimation.c:2977)
     if (pic->me_type == SVTME_ME_MCTF &&
@@ -313,8 +315,11 @@ extern "C" int svtme_picture_submit(svtme_engine *e, const svtme_picture *pic, s
         return SVTME_ERR_BAD_ARG;
     if (pic->tail.enable &&
         (pic->tail.max_refs > SVTME_TAIL_MV_STRIDE || pic->tail.max_cand > SVTME_TAIL_CAND_STRIDE || pic->tail.max_cand < 1 ||
-         pic->tail.max_refs < pic->tail.max_l0 + (pic->num_of_list_to_search == 2 ? pic->num_of_ref_pic_to_search[1] : 0) ||
-         pic->tail.max_l0 < pic->num_of_ref_pic_to_search[0]))
+         // me_mv_array holds list 0 at [0, n_ref[0]) and list 1 at [max_l0, max_l0 + n_ref[1]) of every partition's max_refs
+         // entries (the first pass runs two list-0 references with max_l0 = 1 and no list 1, firstpass.c:1273-1276)
+         pic->tail.max_refs < pic->num_of_ref_pic_to_search[0] ||
+         (pic->num_of_list_to_search == 2 &&
+          (pic->tail.max_l0 < pic->num_of_ref_pic_to_search[0] || pic->tail.max_refs < pic->tail.max_l0 + pic->num_of_ref_pic_to_search[1]))))
         return SVTME_ERR_BAD_ARG;
 
     std::lock_guard<std::mutex> lock(e->mu);
@@ -357,6 +362,7 @@ extern "C" int svtme_picture_submit(svtme_engine *e, const svtme_picture *pic, s
     p.temporal_layer = pic->temporal_layer_index;
     p.is_ref = pic->is_used_as_reference_flag;
     p.me_type       = pic->me_type;
+    p.bypass_zz_check = pic->me_type == SVTME_ME_FIRST_PASS && pic->bypass_zz_check;
     p.tf_me_exit_th = pic->tf_me_exit_th;
     // a reference depends on an earlier one: pre-HME list-1 early exit (:1758-1768) and the HME level-0 area
     // rescaling from the first reference's vector (:1837-1851): those items run in a second launch

@@ -212,7 +212,8 @@ __global__ void __launch_bounds__(ME_THREADS) me_plan_kernel(PicParams p) {
     } else {
         u64 best_hme_sad = ~0ull;
         int accurate     = 1;
-        if ((cx != 0 || cy != 0) && p.is_ref) {
+        // the first pass may bypass the zero-vector check (:1363-1364)
+        if (!(p.me_type == SVTME_ME_FIRST_PASS && p.bypass_zz_check) && (cx != 0 || cy != 0) && p.is_ref) {
             // check_00_center :1170-1243
             const uint32_t zero_sad = wg_block_sad(cur, ref, b64x, b64y, 0, 0, block_w, block_h >> 1, 2, &S.red) << 1;
             if (b64x + cx < -63) cx = (int16_t)(-63 - b64x);

@@ -225,6 +225,8 @@ __global__ void __launch_bounds__(TAIL_THREADS) me_tail_kernel(PicParams p) {
             st[3] = (((d16 * sz) / pix) * f) / 100;
             st[4] = (((d8 * sz) / pix) * f) / 100;
             st[5] = (uint32_t)(ssq / 64);
+            if (p.me_type == SVTME_ME_FIRST_PASS) // the first pass does not call compute_distortion (:2990)
+                for (int i = 0; i < 6; ++i) st[i] = 0;
         }
     }
 

@@ -77,13 +77,13 @@ class Picture(C.Structure):
         ("cur_key", C.c_uint64), ("picture_number", C.c_uint64), ("width", C.c_uint32), ("height", C.c_uint32),
         ("temporal_layer_index", C.c_uint8), ("is_used_as_reference_flag", C.c_uint8),
         ("num_of_list_to_search", C.c_uint8), ("num_of_ref_pic_to_search", C.c_uint8 * 2), ("me_type", C.c_uint8),
-        ("reserved", C.c_uint8 * 2),
+        ("bypass_zz_check", C.c_uint8), ("reserved", C.c_uint8),
         ("ref_key", (C.c_uint64 * MAX_REFS) * MAX_LISTS), ("ref_picture_number", (C.c_uint64 * MAX_REFS) * MAX_LISTS),
         ("ctrl", Controls), ("tail", Tail), ("tf_me_exit_th", C.c_uint32),
     ]
 
 
-ME_OPEN_LOOP, ME_MCTF = 0, 1
+ME_OPEN_LOOP, ME_MCTF, ME_FIRST_PASS = 0, 1, 4
 
 
 class SearchResult(C.Structure):
@@ -106,7 +106,8 @@ class Results(C.Structure):
                 ("final_hme_sad", C.POINTER(C.c_uint64)), ("n_ref", C.c_uint32 * MAX_LISTS)]
 
 
-EXPORTS = ("svtme_version", "svtme_derive_controls", "svtme_derive_tf_controls", "svtme_input_resolution", "svtme_create", "svtme_destroy",
+EXPORTS = ("svtme_version", "svtme_derive_controls", "svtme_derive_tf_controls", "svtme_derive_first_pass_controls",
+           "svtme_input_resolution", "svtme_create", "svtme_destroy",
            "svtme_store_put", "svtme_store_release", "svtme_store_read", "svtme_picture_submit", "svtme_picture_wait",
            "svtme_picture_done", "svtme_picture_timing", "svtme_picture_ops", "svtme_unpack_b64")
 
@@ -124,6 +125,7 @@ def load_library():
     lib.svtme_version.restype = C.c_char_p
     lib.svtme_derive_controls.argtypes = [C.POINTER(PresetKey), C.POINTER(Controls)]
     lib.svtme_derive_tf_controls.argtypes = [C.c_uint8, C.POINTER(Controls)]
+    lib.svtme_derive_first_pass_controls.argtypes = [C.c_uint8, C.c_uint32, C.c_uint8, C.POINTER(Controls)]
     lib.svtme_input_resolution.argtypes = [C.c_uint32, C.c_uint32]
     lib.svtme_input_resolution.restype = C.c_uint8
     lib.svtme_create.argtypes = [C.POINTER(Config), C.POINTER(C.c_void_p)]
@@ -161,6 +163,15 @@ def derive_tf_controls(hme_me_level):
     rc = load_library().svtme_derive_tf_controls(hme_me_level, C.byref(c))
     if rc:
         raise SvtmeError(rc, "svtme_derive_tf_controls")
+    return c
+
+
+def derive_first_pass_controls(width, height, frame_rate=30 << 16, reduce_me_search=0):
+    """Controls of the first-pass ME of a two-pass encode."""
+    c = Controls()
+    rc = load_library().svtme_derive_first_pass_controls(input_resolution(width, height), frame_rate, reduce_me_search, C.byref(c))
+    if rc:
+        raise SvtmeError(rc, "svtme_derive_first_pass_controls")
     return c
 
 
@@ -211,9 +222,10 @@ class Engine:
         return buf[:rows * st.value].reshape(rows, st.value).copy()
 
     def make_picture(self, width, height, poc, temporal_layer, is_ref, refs, ctrl, key_of=lambda poc: poc, tail=None,
-                     tf_me_exit_th=None):
+                     tf_me_exit_th=None, first_pass_bypass_zz=None):
         """refs: [[pocs of list 0], [pocs of list 1]]; tail: a Tail to run the host tail on the device too;
-        tf_me_exit_th: not None makes it a temporal-filter search (ME_MCTF) of refs[0][0] with that exit threshold."""
+        tf_me_exit_th: not None makes it a temporal-filter search (ME_MCTF) of refs[0][0] with that exit threshold;
+        first_pass_bypass_zz: not None makes it a first-pass search (ME_FIRST_PASS) with that bypass_zz_check."""
         p = Picture()
         p.cur_key = key_of(poc)
         p.picture_number = poc
@@ -232,6 +244,9 @@ class Engine:
         if tf_me_exit_th is not None:
             p.me_type = ME_MCTF
             p.tf_me_exit_th = tf_me_exit_th
+        if first_pass_bypass_zz is not None:
+            p.me_type = ME_FIRST_PASS
+            p.bypass_zz_check = first_pass_bypass_zz
         return p
 
     def submit(self, pic):

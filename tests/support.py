@@ -139,6 +139,21 @@ def run_engine_tf_job(frames, pics, level, exit_th, engine=None, serial_hme=0):
             eng.close()
 
 
+def run_engine_first_pass_job(frames, pics, bypass_zz, reduce_me, frame_rate=30 << 16, tail=None):
+    """First-pass searches (ME_FIRST_PASS) of a make_first_pass_job sequence through the engine's C ABI."""
+    import svtme
+    n, h, w = frames.shape
+    eng = svtme.Engine(w, h, store_slots=n + 1, max_in_flight=2)
+    try:
+        for i in range(n):
+            eng.store_put(i, i, frames[i])
+        ctrl = svtme.derive_first_pass_controls(w, h, frame_rate, reduce_me)
+        return [eng.run_picture(eng.make_picture(w, h, p.poc, p.temporal_layer, p.is_ref, p.refs, ctrl, tail=tail,
+                                                 first_pass_bypass_zz=bypass_zz)) for p in pics]
+    finally:
+        eng.close()
+
+
 def tf_fields(out):
     """What a temporal-filter search hands back, in the shape of make_golden.tf_canonical."""
     sr = out["search_results"]

@@ -126,3 +126,25 @@ def test_derive_tf_controls_equals_reference_goldens_and_oracle():
         assert bytes(svtme.derive_tf_controls(lvl)) == bytes(b)
     with pytest.raises(svtme.SvtmeError):
         svtme.derive_tf_controls(3)
+
+
+def test_derive_first_pass_controls_equals_reference_goldens_and_oracle():
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("make_golden", os.path.join(HERE, "golden", "make_golden.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    for name, c in mod.FP_CASES.items():
+        g = np.load(os.path.join(HERE, "golden", name + ".npz"))
+        mine = _as_np(svtme.derive_first_pass_controls(c["width"], c["height"], c.get("frame_rate", 30 << 16), c["reduce_me"]))
+        for pd in g["pic"]:
+            assert mine.tobytes() == pd["ctrl"].tobytes(), (name, mine, pd["ctrl"])
+    orc = C.CDLL(os.path.join(ROOT, "oracle", "build", "libme_oracle.so"))
+    orc.orc_derive_first_pass_controls.argtypes = [C.c_uint8, C.c_uint32, C.c_uint8, C.POINTER(svtme.Controls)]
+    lib = svtme.load_library()
+    for res in range(7):
+        for fps in (24, 60):
+            for red in (0, 1):
+                a, b = svtme.Controls(), svtme.Controls()
+                assert lib.svtme_derive_first_pass_controls(res, fps << 16, red, C.byref(a)) == 0
+                assert orc.orc_derive_first_pass_controls(res, fps << 16, red, C.byref(b)) == 0
+                assert bytes(a) == bytes(b), (res, fps, red)

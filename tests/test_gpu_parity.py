@@ -286,6 +286,36 @@ def test_temporal_filter_search_argument_checks():
         eng.close()
 
 
+@pytest.mark.parametrize("name", sorted(MOD.FP_CASES))
+def test_first_pass_search_matches_reference_goldens(name):
+    """ME_FIRST_PASS: search results against the real reference's dump, and - with the device tail - the candidate
+    lists and MV arrays the first pass reads (me_results), with compute_distortion's statistics left untouched."""
+    c = MOD.FP_CASES[name]
+    g = np.load(os.path.join(GOLDEN, name + ".npz"))
+    frames, pics, _ = MOD.fp_job(c)
+    pd0 = g["pic"][0]
+    tail = svtme.Tail(enable=1, enable_me_8x8=int(pd0["enable_me_8x8"]), enable_me_16x16=int(pd0["enable_me_16x16"]),
+                      max_refs=int(pd0["max_refs"]), max_cand=int(pd0["max_cand"]), max_l0=int(pd0["max_l0"]),
+                      input_resolution=int(pd0["input_resolution"]), gm_enabled=0)
+    assert (tail.max_refs, tail.max_cand, tail.max_l0) == (2, 3, 1)
+    outs = support.run_engine_first_pass_job(frames, pics, c["bypass_zz"], c["reduce_me"], c.get("frame_rate", 30 << 16), tail=tail)
+    stat_names = ["rc_me_distortion", "me_64x64_distortion", "me_32x32_distortion", "me_16x16_distortion",
+                  "me_8x8_distortion", "me_8x8_cost_variance", "stationary_block_present_sb", "rc_me_allow_gm"]
+    for i, (p, out) in enumerate(zip(pics, outs)):
+        bd = g["b64"][i]
+        sr = out["search_results"]
+        for f in ("hme_sc_x", "hme_sc_y", "hme_sad", "do_ref"):
+            assert np.array_equal(sr[f], bd[f]), (name, p.poc, f)
+        nr = len(p.refs[0])
+        assert np.array_equal(out["best_sad"][:, 0, :nr], bd["best_sad"][:, 0, :nr]), (name, p.poc, "best_sad")
+        assert np.array_equal(out["best_mv"][:, 0, :nr], bd["best_mv"][:, 0, :nr]), (name, p.poc, "best_mv")
+        for f in ("total_me_candidate_index", "me_mv_array", "me_candidate_array", "me_distortion"):
+            assert np.array_equal(out[f], bd[f]), (name, p.poc, f)
+        for j, f in enumerate(stat_names):
+            assert np.array_equal(out["b64_stats"][:, j], bd[f].astype(np.uint32)), (name, p.poc, f)
+            assert not bd[f].any()
+
+
 def test_device_store_planes_match_oracle():
     frames, pics, rc = support.make_job(200, 136, 3, 8, seed=5)
     _, planes = refio.run_oracle(frames, [], 8, mode=refio.MODE_PLANES, ref_counts=rc)
