@@ -198,6 +198,7 @@ extern "C" int svtme_create(const svtme_config *cfg, svtme_engine **out) {
             hipMalloc((void **)&f.d_keys, n * SVTME_PU_COUNT * sizeof(unsigned long long)) != hipSuccess ||
             hipHostMalloc((void **)&f.h_res, f.res_bytes, hipHostMallocDefault) != hipSuccess)
             return fail(SVTME_ERR_NO_RESOURCES);
+        if (hipMemset(f.d_hme, 0, n * sizeof(HmeRefOut) + SVTME_OPS_BYTES) != hipSuccess) return fail(SVTME_ERR_DEVICE);
         for (auto &ev : f.ev)
             if (hipEventCreate(&ev) != hipSuccess) return fail(SVTME_ERR_NO_RESOURCES);
     }
@@ -404,7 +405,7 @@ extern "C" int svtme_picture_submit(svtme_engine *e, const svtme_picture *pic, s
             e->slots[si].ready_seen[mi] = true;
         }
     HIP_TRY(hipEventRecord(f->ev[0], sm));
-    HIP_TRY(hipMemsetAsync(f->d_hme, 0, hme_bytes + SVTME_OPS_BYTES, sm));
+    // (the HME records and the counters are zero: allocated so, and every picture's last search kernel clears them again)
     const bool  kt = e->cfg.kernel_timing != 0;
     hipEvent_t  hme_marks[2] = {kt ? f->ev[1] : nullptr, kt ? f->ev[2] : nullptr};
     hipEvent_t  me_marks[3]  = {kt ? f->ev[3] : nullptr, kt ? f->ev[4] : nullptr, f->ev[5]};

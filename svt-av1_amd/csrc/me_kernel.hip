@@ -541,8 +541,18 @@ __global__ void __launch_bounds__(256) me_finish_kernel(PicParams p) {
     const int n_b64 = p.b64_w * p.b64_h, per_plane = n_b64 * SVTME_PU_COUNT;
     const int n = (p.n_ref[0] + p.n_ref[1]) * per_plane;
     const int i = blockIdx.x * 256 + threadIdx.x;
+    // the last kernel that needs the HME records and the counters leaves both zeroed for the next picture that uses
+    // this buffer (they are zero when the engine is created), which saves every picture a memset
     if (blockIdx.x == 0)
-        for (int c = threadIdx.x; c < SVTME_OPS_SLOTS * 8; c += 256) p.ops_out[c] = p.ops[c];
+        for (int c = threadIdx.x; c < SVTME_OPS_SLOTS * 8; c += 256) {
+            p.ops_out[c] = p.ops[c];
+            p.ops[c]     = 0;
+        }
+    {
+        uint32_t *hz = reinterpret_cast<uint32_t *>(p.hme_out);
+        const int nz = n_b64 * SVTME_MAX_LISTS * SVTME_MAX_REFS * (int)(sizeof(HmeRefOut) / 4);
+        for (int z = i; z < nz; z += (int)gridDim.x * 256) hz[z] = 0;
+    }
     if (i >= n) return;
     // output plane q = reference (l, r), list-0 references first
     const int   q = i / per_plane, rest = i - q * per_plane, b64 = rest / SVTME_PU_COUNT, pu = rest - b64 * SVTME_PU_COUNT;

@@ -98,8 +98,8 @@ constexpr int SVTME_OPS_BYTES = SVTME_OPS_SLOTS * 8 * 8;
 // store kernels (store_kernels.hip)
 void launch_store_build(const uint8_t *luma, int luma_stride, const DevPicture &pic, int hme_level1, hipStream_t s);
 // search kernels
-// Each launcher records marks[i] (when not null) on the stream after its i-th kernel (timing only). The caller has
-// zeroed hme_out and the operation counters.
+// Each launcher records marks[i] (when not null) on the stream after its i-th kernel (timing only). The buffers hold
+// zeroed hme_out and operation counters on entry (me_finish_kernel leaves them so).
 void launch_hme(const PicParams &p, hipStream_t s, hipEvent_t marks[2]); // picks the serial or the itemised kernels
 void launch_hme_items(const PicParams &p, hipStream_t s, hipEvent_t marks[2]);
 void launch_me(const PicParams &p, hipStream_t s, hipEvent_t marks[3]);
