@@ -286,7 +286,7 @@ def main():
             "ops_by_stage": dict(zip(STAGES, [float(v) for v in ops])),
             "picture_ms_incl_d2h": float(ms[6]),
         }
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:  # the host-core baseline is measured at N = 1 only
             try:
                 out["cpu_baseline"] = cpu_baseline(wl, frames, pics)
             except Exception as ex:  # the baseline is a reported number, never a reason to lose the GPU line
