@@ -148,3 +148,34 @@ def test_derive_first_pass_controls_equals_reference_goldens_and_oracle():
                 assert lib.svtme_derive_first_pass_controls(res, fps << 16, red, C.byref(a)) == 0
                 assert orc.orc_derive_first_pass_controls(res, fps << 16, red, C.byref(b)) == 0
                 assert bytes(a) == bytes(b), (res, fps, red)
+
+
+def test_header_is_plain_c_and_matches_the_ctypes_mirror(tmp_path):
+    """include/svtme.h compiles as C99 (the reference is C) and its struct sizes / field offsets are the ones the
+    ctypes mirror uses."""
+    import subprocess
+    src = tmp_path / "abi.c"
+    src.write_text('''
+#include <stdio.h>
+#include <stddef.h>
+#include "svtme.h"
+int main(void) {
+    printf("%zu %zu %zu %zu %zu %zu %zu %zu\\n", sizeof(svtme_controls), sizeof(svtme_picture), sizeof(svtme_tail),
+           sizeof(svtme_search_result), sizeof(svtme_results), sizeof(svtme_config), sizeof(svtme_preset_key),
+           sizeof(svtme_sa_minmax));
+    printf("%zu %zu %zu %zu %zu %zu\\n", offsetof(svtme_picture, ref_key), offsetof(svtme_picture, ctrl),
+           offsetof(svtme_picture, tail), offsetof(svtme_picture, tf_me_exit_th), offsetof(svtme_results, n_ref),
+           offsetof(svtme_search_result, hme_sad));
+    return 0;
+}
+''')
+    exe = tmp_path / "abi"
+    subprocess.run(["gcc", "-std=c99", "-Wall", "-Wextra", "-Werror", "-pedantic", "-I", os.path.join(ROOT, "include"), str(src),
+                    "-o", str(exe)], check=True)
+    out = subprocess.run([str(exe)], check=True, capture_output=True, text=True).stdout.split()
+    got = [int(v) for v in out]
+    want = [C.sizeof(svtme.Controls), C.sizeof(svtme.Picture), C.sizeof(svtme.Tail), C.sizeof(svtme.SearchResult),
+            C.sizeof(svtme.Results), C.sizeof(svtme.Config), C.sizeof(svtme.PresetKey), C.sizeof(svtme.SaMinMax),
+            svtme.Picture.ref_key.offset, svtme.Picture.ctrl.offset, svtme.Picture.tail.offset,
+            svtme.Picture.tf_me_exit_th.offset, svtme.Results.n_ref.offset, svtme.SearchResult.hme_sad.offset]
+    assert got == want, (got, want)
