@@ -7,3 +7,7 @@ SRC="$HERE/csrc/engine.cpp $HERE/csrc/controls.cpp $HERE/csrc/store_kernels.hip 
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared -Wall -Wno-unused-function \
     ${SVTME_EXTRA_FLAGS} -o "$OUT" $SRC
 echo "built $OUT"
+# the plain-C example of the reference-side binding (links only against the C ABI)
+gcc -std=c99 -O2 -Wall -Wextra -I "$HERE/../include" "$HERE/examples/me_shim_demo.c" -o "$HERE/svtme/me_shim_demo" \
+    -L "$HERE/svtme" -lsvtme -Wl,-rpath,'$ORIGIN' -Wl,-rpath,/opt/rocm/lib
+echo "built $HERE/svtme/me_shim_demo"

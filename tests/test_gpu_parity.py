@@ -436,3 +436,59 @@ def test_operation_counts_match_oracle():
         outs = support.run_engine_job(frames, pics, mode)
         got = [sum(o["ops"][i] for o in outs) for i in range(6)]
         assert got == want, (mode, got, want)
+
+
+def test_plain_c_program_drives_the_engine_like_the_encoder_would():
+    """svt-av1_amd/examples/me_shim_demo.c (C99, links only against the C ABI): store_put, submit, wait, unpack per b64.
+    Its hashes of the unpacked MeContext-shaped arrays equal the ones of the same job run through the ctypes binding."""
+    import subprocess
+    w, h, preset, seed = 320, 192, 6, 12345
+    exe = os.path.join(os.path.dirname(svtme.LIB_PATH), "me_shim_demo")
+    assert os.path.exists(exe), "run svt-av1_amd/build.sh"
+    r = subprocess.run([exe, str(w), str(h), str(preset), str(seed)], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stderr
+    n_b64, h_sad, h_mv, h_sr = r.stdout.split()
+
+    state = [seed]
+
+    def lcg():
+        state[0] = (state[0] * 1664525 + 1013904223) & 0xFFFFFFFF
+        return state[0] >> 8
+
+    cw, ch = w // 16 + 8, h // 16 + 8
+    cells = [lcg() & 0xFF for _ in range(cw * ch)]
+    frames = np.zeros((3, h, w), np.uint8)
+    for k in range(3):
+        for y in range(h):
+            sy = y + 32 - 2 * k
+            for x in range(w):
+                sx = x + 32 + 3 * k
+                fine = ((sx * 7 + sy * 13) ^ (sx * sy)) & 15
+                frames[k, y, x] = (cells[(sy // 16) * cw + sx // 16] * 3 + fine * 4 + (lcg() & 3)) >> 2
+    eng = svtme.Engine(w, h, store_slots=4, max_in_flight=2)
+    try:
+        for k in range(3):
+            eng.store_put(100 + k, k, frames[k])
+        ctrl = svtme.derive_controls(preset, w, h)
+        out = eng.run_picture(eng.make_picture(w, h, 1, 1, 0, [[0], [2]], ctrl, key_of=lambda poc: 100 + poc))
+    finally:
+        eng.close()
+
+    def fnv(hh, b):
+        for v in b:
+            hh = ((hh ^ v) * 1099511628211) & 0xFFFFFFFFFFFFFFFF
+        return hh
+
+    a = b = c = 1469598103934665603
+    sr = out["search_results"]
+    for i in range(int(n_b64)):
+        a = fnv(a, out["best_sad"][i].tobytes())
+        b = fnv(b, out["best_mv"][i].tobytes())
+        for l in range(2):
+            for rr in range(4):
+                e_ = sr[i, l, rr]
+                c = fnv(c, e_["hme_sc_x"].tobytes() + e_["hme_sc_y"].tobytes() + e_["do_ref"].tobytes() + e_["hme_sad"].tobytes())
+        c = fnv(c, out["zz_sad"][i].tobytes() + out["sr_divisor"][i].tobytes())
+    assert int(n_b64) == out["best_sad"].shape[0] == 15
+    assert (h_sad, h_mv, h_sr) == ("%016x" % a, "%016x" % b, "%016x" % c)
+    assert out["best_mv"][:, 0, 0].any(), "the job should find motion"
