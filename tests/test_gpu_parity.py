@@ -492,3 +492,44 @@ def test_plain_c_program_drives_the_engine_like_the_encoder_would():
     assert int(n_b64) == out["best_sad"].shape[0] == 15
     assert (h_sad, h_mv, h_sr) == ("%016x" % a, "%016x" % b, "%016x" % c)
     assert out["best_mv"][:, 0, 0].any(), "the job should find motion"
+
+
+def test_concurrent_callers_get_the_same_results():
+    """The encoder's ME threads call the engine concurrently (up to one per segment): four threads submit / wait / unpack
+    different pictures of one sequence at the same time; every result equals the one of a single-threaded run."""
+    import threading
+    frames, pics, _ = support.make_job(320, 192, 17, 8, seed=77)
+    n, h, w = frames.shape
+    serial = support.run_engine_job(frames, pics, 8)
+    eng = svtme.Engine(w, h, store_slots=n + 1, max_in_flight=4)
+    got, errors = {}, []
+    try:
+        for i in range(n):
+            eng.store_put(i, i, frames[i])
+        ctrl = svtme.derive_controls(8, w, h)
+
+        def worker(k):
+            try:
+                for rep in range(3):
+                    for i in range(k, len(pics), 4):
+                        p = pics[i]
+                        t = eng.submit(eng.make_picture(w, h, p.poc, p.temporal_layer, p.is_ref, p.refs, ctrl))
+                        out = eng.wait(t)
+                        eng.done(t)
+                        got[(rep, i)] = out
+            except Exception as ex:  # noqa: BLE001 - reported below
+                errors.append(repr(ex))
+
+        threads = [threading.Thread(target=worker, args=(k,)) for k in range(4)]
+        for t in threads:
+            t.start()
+        for t in threads:
+            t.join(timeout=100)
+    finally:
+        eng.close()
+    assert not errors, errors
+    assert len(got) == 3 * len(pics)
+    for (rep, i), out in got.items():
+        for f in ("best_sad", "best_mv", "zz_sad", "sr_divisor"):
+            assert np.array_equal(out[f], serial[i][f]), (rep, i, f)
+        assert out["search_results"].tobytes() == serial[i]["search_results"].tobytes(), (rep, i)
