@@ -245,7 +245,7 @@ __device__ __forceinline__ u64 l0_search(L0Shared &S, uint32_t *win, const DevPl
             // rows the LDS budget holds: a band's search rows + the (NR - 1) STEP rows under the last one + the staggered
             // walk's overrun (rows that are addressed but never used)
             constexpr int under = (NR - 1) * STEP;
-            const int     cap   = HI_WIN_BYTES / (4 * pd);
+            const int     cap   = (int)magic_div(HI_WIN_BYTES / 4, (uint32_t)pd, div_magic((uint32_t)pd));
             int           band  = cap - under - 16;
             band           = band >= 16 ? band & ~15 : max(band, 1);
             for (int y0 = 0; y0 < sa_h; y0 += band) {

@@ -69,7 +69,19 @@ __device__ __forceinline__ uint32_t load_u32_any(const uint8_t *p) {
 
 // floor(i / d) = magic_div(i, d, div_magic(d)) for i * d < 2^32 (here: indices below 2^16, divisors below 2^8);
 // d == 1 has no 32-bit magic number
-__device__ __forceinline__ uint32_t div_magic(uint32_t d) { return (uint32_t)((0x100000000ull + d - 1) / d); }
+// (a 64-bit division costs about a hundred instructions on the device: the magic numbers of all divisors below 256
+// come from a table in constant memory instead, one scalar load)
+struct DivMagicTable {
+    uint32_t m[256];
+    constexpr DivMagicTable() : m() {
+        m[0] = 0;
+        for (uint32_t d = 1; d < 256; ++d) m[d] = (uint32_t)((0x100000000ull + d - 1) / d);
+    }
+};
+__constant__ const DivMagicTable kDivMagic{};
+__device__ __forceinline__ uint32_t div_magic(uint32_t d) {
+    return d < 256 ? kDivMagic.m[d] : (uint32_t)((0x100000000ull + d - 1) / d);
+}
 __device__ __forceinline__ uint32_t magic_div(uint32_t i, uint32_t d, uint32_t magic) { return d == 1 ? i : __umulhi(i, magic); }
 
 // Copies an (n_row x pd dwords) window from a plane (any byte alignment) into LDS rows of pd dwords, whole 64-lane wave,
