@@ -101,8 +101,8 @@ def cpu_baseline(wl, frames, pics, budget_s=20.0):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=60)
-    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--steps", type=int, default=120)
+    ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--workload", default="1080p_ra_m3", choices=sorted(WORKLOADS))
     ap.add_argument("--in-flight", type=int, default=6)
     ap.add_argument("--search-streams", type=int, default=3, choices=[1, 2, 3])
