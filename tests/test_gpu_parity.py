@@ -533,3 +533,44 @@ def test_concurrent_callers_get_the_same_results():
         for f in ("best_sad", "best_mv", "zz_sad", "sr_divisor"):
             assert np.array_equal(out[f], serial[i][f]), (rep, i, f)
         assert out["search_results"].tobytes() == serial[i]["search_results"].tobytes(), (rep, i)
+
+
+def test_error_codes_of_the_life_cycle_calls():
+    """Unknown tickets and keys, exhausted flights and store slots, a release while a picture is in flight."""
+    frames, pics, _ = support.make_job(128, 128, 5, 8, seed=2)
+    eng = svtme.Engine(128, 128, store_slots=3, max_in_flight=1)
+    try:
+        def code(fn, *a, **kw):
+            with pytest.raises(svtme.SvtmeError) as ei:
+                fn(*a, **kw)
+            return ei.value.code
+
+        ctrl = svtme.derive_controls(8, 128, 128)
+        assert code(eng.store_put, 1, 1, np.zeros((100, 128), np.uint8)) == svtme.ERR_BAD_ARG  # height not a multiple of 8
+        assert code(eng.store_put, 1, 1, np.zeros((256, 256), np.uint8)) == svtme.ERR_BAD_ARG  # larger than the engine
+        for k in range(3):
+            eng.store_put(k, k, frames[k])
+        assert code(eng.store_put, 9, 9, frames[3]) == svtme.ERR_NO_RESOURCES  # store full
+        eng.store_put(2, 2, frames[2])  # an existing key is overwritten in place
+        assert code(eng.store_release, 77) == svtme.ERR_NOT_FOUND
+        assert code(eng.wait, 12345) == svtme.ERR_NOT_FOUND
+        assert code(eng.done, 12345) == svtme.ERR_NOT_FOUND
+        pic = eng.make_picture(128, 128, 1, 1, 1, [[0], [2]], ctrl)
+        bad = eng.make_picture(128, 128, 1, 1, 1, [[0], [2]], ctrl)
+        bad.num_of_list_to_search = 3
+        assert code(eng.submit, bad) == svtme.ERR_BAD_ARG
+        t = eng.submit(pic)
+        assert code(eng.submit, pic) == svtme.ERR_NO_RESOURCES  # one picture in flight at most
+        assert code(eng.done, t) == svtme.ERR_BAD_ARG  # not waited for yet
+        eng.store_release(0)  # deferred: the picture in flight still reads it
+        first = eng.wait(t)
+        eng.done(t)
+        assert code(eng.done, t) == svtme.ERR_NOT_FOUND
+        assert code(eng.submit, pic) == svtme.ERR_NOT_FOUND  # reference 0 is gone now
+        eng.store_put(0, 0, frames[0])
+        t = eng.submit(pic)
+        again = eng.wait(t)
+        eng.done(t)
+        assert np.array_equal(first["best_mv"], again["best_mv"]) and np.array_equal(first["best_sad"], again["best_sad"])
+    finally:
+        eng.close()
