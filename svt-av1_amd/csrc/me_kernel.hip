@@ -215,12 +215,36 @@ __global__ void __launch_bounds__(ME_THREADS) me_plan_kernel(PicParams p) {
         // the first pass may bypass the zero-vector check (:1363-1364)
         if (!(p.me_type == SVTME_ME_FIRST_PASS && p.bypass_zz_check) && (cx != 0 || cy != 0) && p.is_ref) {
             // check_00_center :1170-1243
-            const uint32_t zero_sad = wg_block_sad(cur, ref, b64x, b64y, 0, 0, block_w, block_h >> 1, 2, &S.red) << 1;
             if (b64x + cx < -63) cx = (int16_t)(-63 - b64x);
             if (b64x + cx > ref.width - 1) cx = (int16_t)(cx - ((b64x + cx) - (ref.width - 1)));
             if (b64y + cy < -63) cy = (int16_t)(-63 - b64y);
             if (b64y + cy > ref.height - 1) cy = (int16_t)(cy - ((b64y + cy) - (ref.height - 1)));
-            const uint32_t hme_sad = wg_block_sad(cur, ref, b64x, b64y, cx, cy, block_w, block_h >> 1, 2, &S.red) << 1;
+            // both SADs (every other row) in one pass of this single wave: lane = one dword column of 8 sampled rows, all
+            // loads in flight together
+            uint32_t zero_sad = 0, hme_sad = 0;
+            {
+                const int d = tid & 15, bwd = block_w >> 2, rows = block_h >> 1;
+                uint32_t  sv[8], zv[8], hv[8];
+#pragma unroll
+                for (int kk = 0; kk < 8; ++kk) {
+                    const int  rr = (tid >> 4) + 4 * kk;
+                    const bool on = d < bwd && rr < rows;
+                    const int  rc = on ? rr : 0, dc = on ? d : 0; // idle lanes repeat a valid address
+                    const uint8_t *sp = cur.pix + (ptrdiff_t)(b64y + 2 * rc) * cur.stride + b64x + 4 * dc;
+                    const uint8_t *fp = ref.pix + (ptrdiff_t)(b64y + 2 * rc) * ref.stride + b64x + 4 * dc;
+                    sv[kk] = *reinterpret_cast<const uint32_t *>(sp);
+                    zv[kk] = *reinterpret_cast<const uint32_t *>(fp);
+                    __builtin_memcpy(&hv[kk], fp + (ptrdiff_t)cy * ref.stride + cx, 4);
+                }
+#pragma unroll
+                for (int kk = 0; kk < 8; ++kk) {
+                    const bool on = d < bwd && (tid >> 4) + 4 * kk < rows;
+                    zero_sad = __builtin_amdgcn_sad_u8(sv[kk], on ? zv[kk] : sv[kk], zero_sad);
+                    hme_sad  = __builtin_amdgcn_sad_u8(sv[kk], on ? hv[kk] : sv[kk], hme_sad);
+                }
+                zero_sad = wave_sum(zero_sad) << 1;
+                hme_sad  = wave_sum(hme_sad) << 1;
+            }
             best_hme_sad           = hme_sad;
             if (tid == 0) count_ops(p, 0, 2ull * (block_h >> 1) * block_w);
             // costs are SAD << COST_PRECISION; the temporal filter weights a poor centre by TF_HME_MV_COST_WEIGHT
