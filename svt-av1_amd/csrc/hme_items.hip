@@ -305,7 +305,7 @@ __global__ void __launch_bounds__(HI_THREADS, 3) hme_l0_kernel(PicParams p) {
     // zero-MV SAD (init_zz_sad :2318-2333); stays ~0 (init_me_hme_data :2921) when not computed
     uint32_t zz = ~0u;
     if (k.me_early_exit_th && searched)
-        zz = wg_block_sad(p.cur.lvl[2], p.ref[l][r].lvl[2], b64x, b64y, 0, 0, block_w, block_h >> 1, 2, &S.red) << 1;
+        zz = wave_block_sad_sub2(p.cur.lvl[2], p.ref[l][r].lvl[2], b64x, b64y, 0, 0, block_w, block_h >> 1) << 1;
     if (header && threadIdx.x == 0) {
         if (k.me_early_exit_th && searched) count_ops(p, 0, (unsigned long long)(block_h >> 1) * block_w);
         out->zz_sad = zz;

@@ -121,6 +121,30 @@ __device__ __forceinline__ u64 wave_min_u64(u64 v) {
     return v;
 }
 
+// The same for a single wave and a block of at most 64 x 32 sampled rows, every other plane row (the zero-MV and
+// search-centre checks of a 64x64 block): lane = one dword column of 8 sampled rows, all loads in flight together, no
+// LDS. Returns the sum in every lane.
+__device__ __forceinline__ uint32_t wave_block_sad_sub2(const DevPlane &cur, const DevPlane &ref, int ox, int oy, int dx, int dy,
+                                                        int bw, int rows) {
+    const int lane = threadIdx.x & 63, d = lane & 15, bwd = bw >> 2;
+    uint32_t  sv[8], fv[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        const int  r  = (lane >> 4) + 4 * k;
+        const bool on = d < bwd && r < rows;
+        const int  rc = on ? r : 0, dc = on ? d : 0; // idle lanes repeat a valid address
+        sv[k] = *reinterpret_cast<const uint32_t *>(cur.pix + (ptrdiff_t)(oy + 2 * rc) * cur.stride + ox + 4 * dc);
+        __builtin_memcpy(&fv[k], ref.pix + (ptrdiff_t)(oy + dy + 2 * rc) * ref.stride + ox + dx + 4 * dc, 4);
+    }
+    uint32_t acc = 0;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        const bool on = d < bwd && (lane >> 4) + 4 * k < rows;
+        acc = __builtin_amdgcn_sad_u8(sv[k], on ? fv[k] : sv[k], acc);
+    }
+    return wave_sum(acc);
+}
+
 // SAD of the (bw x rows) block of `cur` at (ox, oy) against `ref` at (ox + dx, oy + dy), every `step`-th row:
 // svt_nxm_sad_kernel as get_zz_sad (:1720-1742) and check_00_center (:1170-1243) call it (stride << 1, height >> 1).
 // Whole workgroup takes part; `red` is one LDS word; returns the same sum in every thread. bw is a multiple of 4.
