@@ -574,3 +574,31 @@ def test_error_codes_of_the_life_cycle_calls():
         assert np.array_equal(first["best_mv"], again["best_mv"]) and np.array_equal(first["best_sad"], again["best_sad"])
     finally:
         eng.close()
+
+
+def test_pictures_of_different_sizes_share_an_engine():
+    """Result buffers are reused by pictures of different sizes (the search kernels leave their scratch records zeroed
+    for the next user): alternating sizes on one in-flight buffer give the results of fresh engines."""
+    jobs = [support.make_job(320, 192, 5, 8, seed=5), support.make_job(128, 128, 5, 12, seed=6),
+            support.make_job(264, 136, 5, 3, seed=7)]
+    modes = [8, 12, 3]
+    fresh = [support.run_engine_job(fr, pics, m) for (fr, pics, _), m in zip(jobs, modes)]
+    eng = svtme.Engine(320, 192, store_slots=16, max_in_flight=1)
+    try:
+        for j, (fr, pics, _) in enumerate(jobs):
+            for i in range(len(fr)):
+                eng.store_put(100 * j + i, i, fr[i])
+        for rep in range(2):
+            for k in range(4):
+                for j, (fr, pics, _) in enumerate(jobs):
+                    n, h, w = fr.shape
+                    p = pics[k]
+                    ctrl = svtme.derive_controls(modes[j], w, h)
+                    out = eng.run_picture(eng.make_picture(w, h, p.poc, p.temporal_layer, p.is_ref, p.refs, ctrl,
+                                                           key_of=lambda poc, j=j: 100 * j + poc))
+                    for f in ("best_sad", "best_mv", "zz_sad", "sr_divisor"):
+                        assert np.array_equal(out[f], fresh[j][k][f]), (rep, k, j, f)
+                    assert out["search_results"].tobytes() == fresh[j][k]["search_results"].tobytes(), (rep, k, j)
+                    assert out["ops"] == fresh[j][k]["ops"], (rep, k, j, "operation counters")
+    finally:
+        eng.close()
