@@ -424,6 +424,8 @@ extern "C" int svtme_picture_submit(svtme_engine *e, const svtme_picture *pic, s
         p.t_cand_array = f->d_res + f->off_tcand;
         p.t_total_cand = f->d_res + f->off_ttot;
         p.t_do_ref     = f->d_res + f->off_tdo;
+        p.t_zero_begin = f->d_res + f->off_thme;
+        p.t_zero_bytes = f->tail_end - f->off_thme;
     }
     launch_me(p, sm, me_marks);
     if (f->tail) {

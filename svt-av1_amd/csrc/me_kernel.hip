@@ -572,6 +572,12 @@ __global__ void __launch_bounds__(256) me_finish_kernel(PicParams p) {
             p.ops_out[c] = p.ops[c];
             p.ops[c]     = 0;
         }
+    if (p.tail.enable) {
+        // the device tail fills its candidate lists, MV arrays and counts sparsely: they start from zero
+        uint32_t *tz = reinterpret_cast<uint32_t *>(p.t_zero_begin);
+        const int nt = (int)(p.t_zero_bytes >> 2);
+        for (int z = i; z < nt; z += (int)gridDim.x * 256) tz[z] = 0;
+    }
     {
         uint32_t *hz = reinterpret_cast<uint32_t *>(p.hme_out);
         const int nz = n_b64 * SVTME_MAX_LISTS * SVTME_MAX_REFS * (int)(sizeof(HmeRefOut) / 4);

@@ -90,6 +90,8 @@ struct PicParams {
     uint32_t           *t_stats; // [n_b64][8]
     uint8_t            *t_do_ref; // [n_b64][8]
     unsigned long long *t_hme_sad; // [n_b64][8]
+    uint8_t            *t_zero_begin; // the tail's output arrays as one block (a multiple of 64 bytes), cleared by
+    size_t              t_zero_bytes; // me_finish_kernel before the tail kernel runs
 };
 
 constexpr int SVTME_OPS_SLOTS = 64;

@@ -26,6 +26,7 @@ struct TailShared {
     uint32_t stationary;
     uint8_t  do_ref[8];
     uint8_t  first_cand[SVTME_PU_COUNT]; // candidate 0 of every partition
+    uint32_t sad[8][SVTME_PU_COUNT], mv[8][SVTME_PU_COUNT]; // this block's minima per reference slot l * 4 + r
 };
 
 // MeCandidate bit-field, EbMotionEstimationLcuResults.h:29-35: direction:2, ref_idx_l0:2, ref_idx_l1:2, ref0_list:1,
@@ -53,7 +54,9 @@ __global__ void __launch_bounds__(TAIL_THREADS) me_tail_kernel(PicParams p) {
     auto         at = [&](const uint32_t *a, int l, int r, int n) -> uint32_t {
         return a[(size_t)(l ? p.n_ref[0] + r : r) * plane + (size_t)b64 * SVTME_PU_COUNT + n];
     };
-    const uint32_t *bs = p.best_sad, *bm = p.best_mv;
+    // after the hand-over to LDS below the rest of the kernel reads the minima there
+    const int bs = 0, bm = 1;
+    auto      lds_at = [&](int which, int l, int r, int n) -> uint32_t { return which ? S.mv[l * 4 + r][n] : S.sad[l * 4 + r][n]; };
     const svtme_search_result *sr = p.search_results + (size_t)b64 * 8;
     uint8_t  *o_total = p.t_total_cand + (size_t)b64 * SVTME_PU_COUNT;
     uint32_t *o_mv    = p.t_mv_array + (size_t)b64 * SVTME_PU_COUNT * SVTME_TAIL_MV_STRIDE;
@@ -69,11 +72,33 @@ __global__ void __launch_bounds__(TAIL_THREADS) me_tail_kernel(PicParams p) {
     for (int i = lane; i < SVTME_PU_COUNT; i += TAIL_THREADS) {
         S.me_dist[i]    = 0;
         S.first_cand[i] = 0;
-        o_total[i]      = 0;
     }
-    // the per-b64 result buffers start from zero
-    for (int i = lane; i < SVTME_PU_COUNT * SVTME_TAIL_MV_STRIDE; i += TAIL_THREADS) o_mv[i] = 0;
-    for (int i = lane; i < SVTME_PU_COUNT * SVTME_TAIL_CAND_STRIDE; i += TAIL_THREADS) o_cand[i] = 0;
+    // (the per-b64 result buffers start from zero: me_finish_kernel cleared them)
+    // every reference's minima of this block -> LDS, all loads in flight together: slot j = l * 4 + r, partitions lane
+    // and lane + 64
+    {
+        uint32_t r_sad[2][8], r_mv[2][8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int  l = j >> 2, r = j & 3;
+            const bool have = l < p.n_list && r < p.n_ref[l];
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const int  n  = lane + 64 * h;
+                const bool on = have && n < SVTME_PU_COUNT;
+                r_sad[h][j] = on ? at(p.best_sad, l, r, n) : 0u;
+                r_mv[h][j]  = on ? at(p.best_mv, l, r, n) : 0u;
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < 8; ++j)
+#pragma unroll
+            for (int h = 0; h < 2; ++h)
+                if (lane + 64 * h < SVTME_PU_COUNT) {
+                    S.sad[j][lane + 64 * h] = r_sad[h][j];
+                    S.mv[j][lane + 64 * h]  = r_mv[h][j];
+                }
+    }
     __syncthreads();
 
     // ---- me_prune_ref :1576-1618: HME SAD := sum of the 64 best 8x8 SADs; prune on its deviation from the best
@@ -82,8 +107,7 @@ __global__ void __launch_bounds__(TAIL_THREADS) me_tail_kernel(PicParams p) {
             for (int r = 0; r < p.n_ref[l]; ++r) {
                 const int i = l * 4 + r;
                 u64       v = (u64)SVTME_MAX_SAD_VALUE * 64;
-                if (S.do_ref[i]) v = wave_sum(at(bs, l, r, 21 + lane));
-                __syncthreads();
+                if (S.do_ref[i]) v = wave_sum(S.sad[i][21 + lane]);
                 if (lane == 0) S.hme_sad[i] = v;
             }
         __syncthreads();
@@ -121,13 +145,13 @@ __global__ void __launch_bounds__(TAIL_THREADS) me_tail_kernel(PicParams p) {
             if (n_list < 2 || !S.do_ref[4]) n_list = 1;
             const uint32_t prune_th = (org[0] && org[1]) ? (uint32_t)k.prune_me_candidates_th : 0;
             uint8_t        dr[2] = {org[0], org[1]};
-            const uint32_t s0 = at(bs, 0, 0, n), s1 = at(bs, 1, 0, n);
+            const uint32_t s0 = lds_at(bs, 0, 0, n), s1 = lds_at(bs, 1, 0, n);
             const uint32_t best = prune_th > 0 ? min(s0, s1) : ~0u;
             int            min_list = -1;
             if (k.use_best_unipred_cand_only && dr[0] && dr[1]) min_list = s0 < s1 ? 0 : 1;
             for (uint32_t l = 0; l < n_list && (use || off == 0); ++l) {
                 if (!dr[l]) continue;
-                const uint32_t sad = l ? s1 : s0, mv = at(bm, (int)l, 0, n);
+                const uint32_t sad = l ? s1 : s0, mv = lds_at(bm, (int)l, 0, n);
                 if (prune_th > 0) {
                     const uint32_t d = (sad - best) * 100;
                     if (d > best * prune_th) {
@@ -160,12 +184,12 @@ __global__ void __launch_bounds__(TAIL_THREADS) me_tail_kernel(PicParams p) {
             if (prune_th > 0)
                 for (int l = 0; l < p.n_list; ++l)
                     for (int r = 0; r < p.n_ref[l]; ++r)
-                        if (S.do_ref[l * 4 + r]) best = min(best, at(bs, l, r, n));
+                        if (S.do_ref[l * 4 + r]) best = min(best, lds_at(bs, l, r, n));
             for (int l = 0; l < p.n_list && (use || off == 0); ++l)
                 for (int r = 0; r < p.n_ref[l] && (use || off == 0); ++r) {
                     dr[l][r] = S.do_ref[l * 4 + r];
                     if (!dr[l][r]) continue;
-                    const uint32_t sad = at(bs, l, r, n);
+                    const uint32_t sad = lds_at(bs, l, r, n);
                     if (prune_th > 0) {
                         const uint32_t d = (sad - best) * 100;
                         if (d > best * prune_th) {
@@ -177,7 +201,7 @@ __global__ void __launch_bounds__(TAIL_THREADS) me_tail_kernel(PicParams p) {
                     if (use) {
                         ca[off] = me_cand(l, r, r, 0, l == 1 ? 1 : 0);
                         if (off == 0) S.first_cand[pu] = ca[0];
-                        o_mv[pu * t.max_refs + (l ? t.max_l0 : 0) + r] = at(bm, l, r, n);
+                        o_mv[pu * t.max_refs + (l ? t.max_l0 : 0) + r] = lds_at(bm, l, r, n);
                     }
                     off++;
                 }
@@ -251,7 +275,7 @@ __global__ void __launch_bounds__(TAIL_THREADS) me_tail_kernel(PicParams p) {
             const int     dist = (int)(uint16_t)p.dist[l][r];
             const int     th = low_res ? (t.gm_use_distance_based_active_th ? max(dist >> 1, 4) : 4)
                                        : (t.gm_use_distance_based_active_th ? max(dist * 16, 32) : 32);
-            const uint32_t mv = at(bm, l, r, idx);
+            const uint32_t mv = lds_at(bm, l, r, idx);
             const int      mx = (int16_t)(mv & 0xFFFF), my = (int16_t)(mv >> 16);
             uint32_t      *c  = &S.cnt[(l * 4 + r) * 4];
             if (mx < -th) atomicAdd(&c[0], 1u);
