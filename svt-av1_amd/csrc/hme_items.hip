@@ -684,7 +684,7 @@ __global__ void __launch_bounds__(FS ? HI_THREADS_FS : HI_THREADS) hme_l12_kerne
     const int             nw = k.num_hme_sa_w, nh = k.num_hme_sa_h;
     const int             n_refs = p.n_ref[0] + (p.n_list == 2 ? p.n_ref[1] : 0);
     int                   b64, item;
-    if (!b64_major_item(blockIdx.x, p.b64_w * p.b64_h, n_refs * nw * nh, b64, item)) return;
+    if (!b64_band_item(blockIdx.x, p.b64_w * p.b64_h, n_refs * nw * nh, b64, item)) return;
     const int             b64x = (b64 % p.b64_w) * 64, b64y = (b64 / p.b64_w) * 64;
     const int             block_w = min(p.width - b64x, 64), block_h = min(p.height - b64y, 64);
     int                   l = 0, r = item / (nw * nh);

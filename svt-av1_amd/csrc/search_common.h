@@ -54,6 +54,18 @@ __device__ __forceinline__ bool b64_major_item(int wg, int n_b64, int items_per_
     return b64 < n_b64;
 }
 
+// Workgroup id -> (b64, item) with one band of ceil(n_b64 / 8) consecutive b64s per XCD (workgroups go to the XCDs round
+// robin, so id & 7 is the XCD): an XCD's L2 then only sees the rows of the reference planes its band needs, instead of
+// all of every plane. For kernels whose items all cost the same. The grid holds 8 * ceil(n_b64 / 8) * items_per_b64
+// workgroups; returns false for the padding ones.
+__device__ __forceinline__ bool b64_band_item(int wg, int n_b64, int items_per_b64, int &b64, int &item) {
+    const int band = (n_b64 + 7) >> 3, xcd = wg & 7, slot = wg >> 3;
+    const int bl = slot / items_per_b64;
+    item = slot - bl * items_per_b64;
+    b64  = xcd * band + bl;
+    return b64 < n_b64 && bl < band;
+}
+
 // Adds n to operation counter k of this workgroup's partial-sum slot.
 __device__ __forceinline__ void count_ops(const PicParams &p, int k, unsigned long long n) {
     atomicAdd(&p.ops[((blockIdx.x + 5 * blockIdx.y) & (SVTME_OPS_SLOTS - 1)) * 8 + k], n);
