@@ -602,3 +602,28 @@ def test_pictures_of_different_sizes_share_an_engine():
                     assert out["ops"] == fresh[j][k]["ops"], (rep, k, j, "operation counters")
     finally:
         eng.close()
+
+
+def test_two_ranks_share_a_sequence_without_any_exchange():
+    """The multi-GPU path on one card: two engines stand in for two ranks; each puts only the sources its own pictures
+    need and searches only its own pictures (svtme.scheduler, picture i to rank i mod 2); together they reproduce the
+    oracle's results for the whole sequence."""
+    from svtme import scheduler
+    frames, pics, rc = support.make_job(256, 128, 17, 8, seed=9)
+    recs = support.oracle_handover(frames, pics, 8, rc)
+    ctrl = svtme.derive_controls(8, 256, 128)
+    src = {i: frames[i] for i in range(len(frames))}
+    got = {}
+    for rank in range(2):
+        eng = svtme.Engine(256, 128, store_slots=10, max_in_flight=3)
+        try:
+            mine = scheduler.run_sharded(eng, src, pics, ctrl, rank, 2, in_flight=3)
+        finally:
+            eng.close()
+        assert sorted(mine) == [i for i in range(len(pics)) if i % 2 == rank]
+        got.update(mine)
+    assert sorted(got) == list(range(len(pics)))
+    msgs = []
+    for i, p in enumerate(pics):
+        msgs += support.compare_picture(got[i], recs[i], p, "poc %d" % p.poc)
+    assert not msgs, "\n".join(msgs[:10])
