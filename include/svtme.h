@@ -225,7 +225,11 @@ typedef struct svtme_picture {
     uint8_t  num_of_ref_pic_to_search[SVTME_MAX_LISTS]; /* ref_list{0,1}_count_try */
     uint8_t  me_type; /* SVTME_ME_OPEN_LOOP, SVTME_ME_MCTF or SVTME_ME_FIRST_PASS */
     uint8_t  bypass_zz_check; /* SVTME_ME_FIRST_PASS only */
-    uint8_t  reserved;
+    uint8_t  restricted_motion_vector; /* scs->static_config.restricted_motion_vector: the integer search window stays inside
+                                          the tile instead of the padded picture (EbMotionEstimation.c:1405-1430, :1465-1495).
+                                          The open-loop ME always sees one tile = the picture (EbPictureControlSet.c:1684-1688);
+                                          the engine uses the picture for every me_type, so temporal-filter / first-pass
+                                          searches of multi-tile sequences with this option stay on the CPU */
     uint64_t ref_key[SVTME_MAX_LISTS][SVTME_MAX_REFS]; /* store keys of pcs->ref_pa_pic_ptr_array */
     uint64_t ref_picture_number[SVTME_MAX_LISTS][SVTME_MAX_REFS];
     svtme_controls ctrl;

@@ -820,9 +820,11 @@ static void orc_integer_search(orc_ctx *c, const orc_pic *pic, int ox, int oy) {
                 }
             }
             int16_t org_x = (int16_t)(cx - (w >> 1)), org_y = (int16_t)(cy - (h >> 1));
-            orc_clip_axis(ox, &org_x, &w, -63, (int)pic->width);
+            /* restricted motion vectors: the tile (here: the picture) instead of the padded picture bounds the window */
+            const int lo = pic->restricted_motion_vector ? 0 : -63;
+            orc_clip_axis(ox, &org_x, &w, lo, (int)pic->width);
             w = (int16_t)(w < 8 ? w : (w & ~0x07));
-            orc_clip_axis(oy, &org_y, &h, -63, (int)pic->height);
+            orc_clip_axis(oy, &org_y, &h, lo, (int)pic->height);
 
             uint32_t *bs = c->best_sad[l][r], *bm = c->best_mv[l][r];
             for (int i = 0; i < 85; ++i) bs[i] = SVTME_MAX_SAD_VALUE; /* svt_initialize_buffer_32bits :1542 */

@@ -56,6 +56,8 @@ typedef struct orc_pic {
      * bypass_zz_check), and MeContext::tf_me_exit_th */
     uint8_t  me_type;
     uint8_t  bypass_zz_check; /* scs->ipp_pass_ctrls.bypass_zz_check, ME_FIRST_PASS only */
+    uint8_t  restricted_motion_vector; /* scs->static_config.restricted_motion_vector with one tile: the integer search
+                                          window stays inside the picture (EbMotionEstimation.c:1405-1430, :1465-1495) */
     uint16_t tf_me_exit_th;
 } orc_pic;
 

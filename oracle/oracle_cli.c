@@ -76,6 +76,7 @@ static void fill_pic(orc_pic *p, const ref_job_header *h, const ref_job_pic *jp,
     p->max_l0 = (uint8_t)l0;
     p->gm_enabled = jp->gm_enabled;
     p->gm_use_distance_based_active_th = jp->gm_dist_th;
+    p->restricted_motion_vector = jp->restricted_motion_vector;
     if (jp->me_type == 4) { /* firstpass.c:1273-1276 and set_gm_controls(pcs, 0), :702-703 */
         p->max_cand = 3;
         p->max_refs = 2;

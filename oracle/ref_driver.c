@@ -205,7 +205,7 @@ static void setup_pic(const Job *job, uint32_t pi, PicState *st) {
 
     derive_input_resolution(&scs->input_resolution, w * h);
     scs->static_config.frame_rate               = jp->frame_rate;
-    scs->static_config.restricted_motion_vector = 0;
+    scs->static_config.restricted_motion_vector = jp->restricted_motion_vector;
     scs->static_config.enc_mode                 = (int8_t)jp->enc_mode;
     scs->sb_sz                                  = 64;
     scs->ipp_pass_ctrls.bypass_zz_check         = 0;

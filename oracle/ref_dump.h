@@ -54,6 +54,8 @@ typedef struct ref_job_pic {
     uint8_t  me_type;
     uint8_t  tf_hme_me_level;
     uint16_t tf_me_exit_th;
+    uint8_t  restricted_motion_vector; /* scs->static_config.restricted_motion_vector (single tile) */
+    uint8_t  pad[3];
 } ref_job_pic;
 
 typedef struct ref_out_header {

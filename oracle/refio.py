@@ -55,12 +55,13 @@ B64_DUMP = np.dtype([
 ])
 
 _HDR = "<8sIIIIIIIIII"
-_PIC = "<IIQiBBBBBBBB8I8QBBH"
+_PIC = "<IIQiBBBBBBBB8I8QBBHB3x"
 _OUT = "<8sIIIIIIdQ"
 
 
 def write_job(path, frames, pics, enc_mode, *, mode=MODE_DUMP, threads=1, use_avx2=0, reps=1,
-              frame_rate=30 << 16, sc_class1=0, gm_enabled=0, gm_dist_th=0, ref_counts=(4, 3), tf=None, first_pass=None):
+              frame_rate=30 << 16, sc_class1=0, gm_enabled=0, gm_dist_th=0, ref_counts=(4, 3), tf=None, first_pass=None,
+              restricted_motion_vector=0):
     """frames: uint8 [n, h, w]; pics: list of svtme.gop.Picture (refs are POCs = frame indices).
     tf = (hme_me_level, me_exit_th) runs every picture as a temporal-filter search (ME_MCTF) of its first list-0
     reference: the controls then come from tf_signal_derivation_me_kernel_oq and enc_mode is not used.
@@ -80,7 +81,7 @@ def write_job(path, frames, pics, enc_mode, *, mode=MODE_DUMP, threads=1, use_av
             n_list = 2 if p.refs[1] else 1
             f.write(struct.pack(_PIC, p.poc, frame_rate, p.poc, enc_mode, p.temporal_layer, p.is_ref, n_list,
                                 len(p.refs[0]), len(p.refs[1]), sc_class1, gm_enabled, gm_dist_th,
-                                *rf[0], *rf[1], *rf[0], *rf[1], *variant))
+                                *rf[0], *rf[1], *rf[0], *rf[1], *variant, restricted_motion_vector))
 
 
 def read_dump(path):

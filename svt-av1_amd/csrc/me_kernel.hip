@@ -268,9 +268,11 @@ __global__ void __launch_bounds__(ME_THREADS) me_plan_kernel(PicParams p) {
         }
     }
     int16_t org_x = (int16_t)(cx - (w >> 1)), org_y = (int16_t)(cy - (h >> 1));
-    clip_axis(b64x, org_x, w, -63, p.width);
+    // restricted motion vectors: the tile (the picture) instead of the padded picture bounds the window (:1405-1495)
+    const int lo = p.restricted ? 0 : -63;
+    clip_axis(b64x, org_x, w, lo, p.width);
     w = (int16_t)(w < 8 ? w : (w & ~0x07));
-    clip_axis(b64y, org_y, h, -63, p.height);
+    clip_axis(b64y, org_y, h, lo, p.height);
 
     if (tid == 0) {
         *job = MeJob{org_x, org_y, w, h};

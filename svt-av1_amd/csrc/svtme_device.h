@@ -63,6 +63,7 @@ struct PicParams {
     int32_t        hme_phase; // 0: every level-0 / pre-HME item; 1: the items others depend on; 2: the dependent items
     int32_t        me_type; // SVTME_ME_OPEN_LOOP / SVTME_ME_MCTF / SVTME_ME_FIRST_PASS
     int32_t        bypass_zz_check; // first pass only
+    int32_t        restricted; // integer search windows stay inside the picture (restricted_motion_vector, one tile)
     uint32_t       tf_me_exit_th;
     int32_t        me_ref0; // first reference (list-0 references first, then list 1) the integer-search launch covers
     int32_t        me_max_items; // upper bound of search work items per (b64, ref) for this picture's controls

@@ -77,7 +77,7 @@ class Picture(C.Structure):
         ("cur_key", C.c_uint64), ("picture_number", C.c_uint64), ("width", C.c_uint32), ("height", C.c_uint32),
         ("temporal_layer_index", C.c_uint8), ("is_used_as_reference_flag", C.c_uint8),
         ("num_of_list_to_search", C.c_uint8), ("num_of_ref_pic_to_search", C.c_uint8 * 2), ("me_type", C.c_uint8),
-        ("bypass_zz_check", C.c_uint8), ("reserved", C.c_uint8),
+        ("bypass_zz_check", C.c_uint8), ("restricted_motion_vector", C.c_uint8),
         ("ref_key", (C.c_uint64 * MAX_REFS) * MAX_LISTS), ("ref_picture_number", (C.c_uint64 * MAX_REFS) * MAX_LISTS),
         ("ctrl", Controls), ("tail", Tail), ("tf_me_exit_th", C.c_uint32),
     ]
@@ -222,7 +222,7 @@ class Engine:
         return buf[:rows * st.value].reshape(rows, st.value).copy()
 
     def make_picture(self, width, height, poc, temporal_layer, is_ref, refs, ctrl, key_of=lambda poc: poc, tail=None,
-                     tf_me_exit_th=None, first_pass_bypass_zz=None):
+                     tf_me_exit_th=None, first_pass_bypass_zz=None, restricted_motion_vector=0):
         """refs: [[pocs of list 0], [pocs of list 1]]; tail: a Tail to run the host tail on the device too;
         tf_me_exit_th: not None makes it a temporal-filter search (ME_MCTF) of refs[0][0] with that exit threshold;
         first_pass_bypass_zz: not None makes it a first-pass search (ME_FIRST_PASS) with that bypass_zz_check."""
@@ -244,6 +244,7 @@ class Engine:
         if tf_me_exit_th is not None:
             p.me_type = ME_MCTF
             p.tf_me_exit_th = tf_me_exit_th
+        p.restricted_motion_vector = restricted_motion_vector
         if first_pass_bypass_zz is not None:
             p.me_type = ME_FIRST_PASS
             p.bypass_zz_check = first_pass_bypass_zz

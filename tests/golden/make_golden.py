@@ -34,6 +34,9 @@ CASES = {
     "m9_sc_192x128": dict(width=192, height=128, n_frames=9, enc_mode=9, seed=22, structure="ra", sc_class1=1),
     "m4_sc_128x128": dict(width=128, height=128, n_frames=5, enc_mode=4, seed=23, structure="ra", sc_class1=1),
     "m8_fps60_192x128": dict(width=192, height=128, n_frames=9, enc_mode=8, seed=24, structure="ra", frame_rate=60 << 16),
+    # scs->static_config.restricted_motion_vector: integer search windows stay inside the picture
+    "m8_rmv_192x128": dict(width=192, height=128, n_frames=9, enc_mode=8, seed=71, structure="ra", restricted=1, motion=(6, -5)),
+    "m3_rmv_128x128": dict(width=128, height=128, n_frames=5, enc_mode=3, seed=72, structure="ra", restricted=1, motion=(-7, 4)),
 }
 # larger jobs: only sha256 digests of every dumped field are stored
 DIGEST_CASES = {
@@ -97,9 +100,9 @@ def tf_canonical(bd):
 
 def run_case(c, threads=1):
     frames, pics, rc = support.make_job(c["width"], c["height"], c["n_frames"], c["enc_mode"], c["seed"],
-                                        c.get("structure", "ra"), c.get("kind", "synth"))
+                                        c.get("structure", "ra"), c.get("kind", "synth"), c.get("motion", (3, -2)))
     kw = dict(ref_counts=rc, sc_class1=c.get("sc_class1", 0), frame_rate=c.get("frame_rate", 30 << 16),
-              gm_enabled=1, gm_dist_th=1)
+              gm_enabled=1, gm_dist_th=1, restricted_motion_vector=c.get("restricted", 0))
     hdr, recs = refio.run_reference(frames, pics, c["enc_mode"], threads=threads, use_avx2=0, **kw)
     return frames, pics, recs
 

@@ -98,7 +98,8 @@ def compare_picture(out, bd, pic, where=""):
     return msgs
 
 
-def run_engine_job(frames, pics, enc_mode, sc_class1=0, frame_rate=30 << 16, engine=None, tail=None, serial_hme=0):
+def run_engine_job(frames, pics, enc_mode, sc_class1=0, frame_rate=30 << 16, engine=None, tail=None, serial_hme=0,
+                   restricted=0):
     """Runs every picture of the job through the engine's C ABI; returns the list of output dicts. tail: an
     svtme.Tail to run the host tail on the device as well."""
     import svtme
@@ -111,7 +112,8 @@ def run_engine_job(frames, pics, enc_mode, sc_class1=0, frame_rate=30 << 16, eng
         ctrl = svtme.derive_controls(enc_mode, w, h, sc_class1, frame_rate)
         outs = []
         for p in pics:
-            pic = eng.make_picture(w, h, p.poc, p.temporal_layer, p.is_ref, p.refs, ctrl, tail=tail)
+            pic = eng.make_picture(w, h, p.poc, p.temporal_layer, p.is_ref, p.refs, ctrl, tail=tail,
+                                   restricted_motion_vector=restricted)
             outs.append(eng.run_picture(pic))
         return outs
     finally:

@@ -34,8 +34,9 @@ def test_engine_matches_reference_goldens(name):
     c = MOD.CASES[name]
     g = np.load(os.path.join(GOLDEN, name + ".npz"))
     frames, pics, _ = support.make_job(c["width"], c["height"], c["n_frames"], c["enc_mode"], c["seed"],
-                                       c.get("structure", "ra"), c.get("kind", "synth"))
-    outs = support.run_engine_job(frames, pics, c["enc_mode"], c.get("sc_class1", 0), c.get("frame_rate", 30 << 16))
+                                       c.get("structure", "ra"), c.get("kind", "synth"), c.get("motion", (3, -2)))
+    outs = support.run_engine_job(frames, pics, c["enc_mode"], c.get("sc_class1", 0), c.get("frame_rate", 30 << 16),
+                                  restricted=c.get("restricted", 0))
     for i, (p, out) in enumerate(zip(pics, outs)):
         bd = g["b64"][i]
         pruning = bool(g["pic"][i]["ctrl"]["enable_me_hme_ref_pruning"])
@@ -129,9 +130,11 @@ def test_engine_results_through_the_host_tail_give_the_reference_final_state(nam
     c = MOD.CASES[name]
     g = np.load(os.path.join(GOLDEN, name + ".npz"))
     frames, pics, rc = support.make_job(c["width"], c["height"], c["n_frames"], c["enc_mode"], c["seed"],
-                                        c.get("structure", "ra"), c.get("kind", "synth"))
-    kw = dict(ref_counts=rc, sc_class1=c.get("sc_class1", 0), frame_rate=c.get("frame_rate", 30 << 16), gm_enabled=1, gm_dist_th=1)
-    outs = support.run_engine_job(frames, pics, c["enc_mode"], c.get("sc_class1", 0), c.get("frame_rate", 30 << 16))
+                                        c.get("structure", "ra"), c.get("kind", "synth"), c.get("motion", (3, -2)))
+    kw = dict(ref_counts=rc, sc_class1=c.get("sc_class1", 0), frame_rate=c.get("frame_rate", 30 << 16), gm_enabled=1, gm_dist_th=1,
+              restricted_motion_vector=c.get("restricted", 0))
+    outs = support.run_engine_job(frames, pics, c["enc_mode"], c.get("sc_class1", 0), c.get("frame_rate", 30 << 16),
+                                  restricted=c.get("restricted", 0))
     n_b64 = g["b64"].shape[1]
     hand = [support.handover_records(o, n_b64) for o in outs]
     _, tail = refio.run_oracle_tail(frames, pics, c["enc_mode"], hand, **kw)
@@ -146,12 +149,13 @@ def test_device_side_host_tail_matches_reference_final_state(name):
     c = MOD.CASES[name]
     g = np.load(os.path.join(GOLDEN, name + ".npz"))
     frames, pics, _ = support.make_job(c["width"], c["height"], c["n_frames"], c["enc_mode"], c["seed"],
-                                       c.get("structure", "ra"), c.get("kind", "synth"))
+                                       c.get("structure", "ra"), c.get("kind", "synth"), c.get("motion", (3, -2)))
     pd0 = g["pic"][0]
     tail = svtme.Tail(enable=1, enable_me_8x8=int(pd0["enable_me_8x8"]), enable_me_16x16=int(pd0["enable_me_16x16"]),
                       max_refs=int(pd0["max_refs"]), max_cand=int(pd0["max_cand"]), max_l0=int(pd0["max_l0"]),
                       input_resolution=int(pd0["input_resolution"]), gm_enabled=1, gm_use_distance_based_active_th=1)
-    outs = support.run_engine_job(frames, pics, c["enc_mode"], c.get("sc_class1", 0), c.get("frame_rate", 30 << 16), tail=tail)
+    outs = support.run_engine_job(frames, pics, c["enc_mode"], c.get("sc_class1", 0), c.get("frame_rate", 30 << 16), tail=tail,
+                                  restricted=c.get("restricted", 0))
     stat_names = ["rc_me_distortion", "me_64x64_distortion", "me_32x32_distortion", "me_16x16_distortion",
                   "me_8x8_distortion", "me_8x8_cost_variance", "stationary_block_present_sb", "rc_me_allow_gm"]
     for i, (p, out) in enumerate(zip(pics, outs)):
