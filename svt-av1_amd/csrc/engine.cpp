@@ -104,6 +104,7 @@ struct svtme_engine {
     std::vector<Flight> flights;
     svtme_ticket        next_ticket = 1;
     size_t              slot_bytes = 0, max_b64 = 0;
+    uint8_t            *d_upload = nullptr; // un-padded luma of the picture being put (the store stream orders its reuse)
 };
 
 namespace {
@@ -178,6 +179,7 @@ extern "C" int svtme_create(const svtme_config *cfg, svtme_engine **out) {
     DevPicture tmp;
     layout_planes(nullptr, cfg->max_width, cfg->max_height, &tmp, &e->slot_bytes);
     e->max_b64 = (size_t)((cfg->max_width + 63) / 64) * ((cfg->max_height + 63) / 64);
+    if (hipMalloc((void **)&e->d_upload, (size_t)cfg->max_width * cfg->max_height) != hipSuccess) return fail(SVTME_ERR_NO_RESOURCES);
     e->slots.resize(cfg->store_slots);
     for (auto &s : e->slots) {
         if (hipMalloc((void **)&s.mem, e->slot_bytes) != hipSuccess ||
@@ -220,6 +222,7 @@ extern "C" void svtme_destroy(svtme_engine *e) {
         for (auto ev : s.last_read)
             if (ev) (void)hipEventDestroy(ev);
     }
+    if (e->d_upload) (void)hipFree(e->d_upload);
     for (auto &f : e->flights) free_flight(f);
     for (auto sm : e->s_me)
         if (sm) (void)hipStreamDestroy(sm);
@@ -256,10 +259,13 @@ extern "C" int svtme_store_put(svtme_engine *e, uint64_t key, uint64_t picture_n
     s.height = height;
     size_t bytes;
     layout_planes(s.mem, width, height, &s.pic, &bytes);
-    for (uint32_t y = 0; y < height; ++y) memcpy(s.host_stage + (size_t)y * width, luma + (size_t)y * stride, width);
-    const DevPlane &f = s.pic.lvl[2];
-    HIP_TRY(hipMemcpy2DAsync(f.pix, f.stride, s.host_stage, width, width, height, hipMemcpyHostToDevice, e->s_store));
-    launch_store_build(f.pix, f.stride, s.pic, 1, e->s_store);
+    if (stride == width) memcpy(s.host_stage, luma, (size_t)width * height); // one large copy: streaming stores
+    else
+        for (uint32_t y = 0; y < height; ++y) memcpy(s.host_stage + (size_t)y * width, luma + (size_t)y * stride, width);
+    // one linear DMA (a pitched copy into the padded plane runs at a quarter of the link's rate), then the store kernels
+    // place the rows into the padded plane while they decimate
+    HIP_TRY(hipMemcpyAsync(e->d_upload, s.host_stage, (size_t)width * height, hipMemcpyHostToDevice, e->s_store));
+    launch_store_build(e->d_upload, (int)width, s.pic, 1, e->s_store);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipEventRecord(s.ready, e->s_store));
     s.ready_seen[0] = s.ready_seen[1] = s.ready_seen[2] = s.ready_seen[3] = false;
