@@ -9,7 +9,6 @@
 
 #include <algorithm>
 
-#include <chrono>
 #include <mutex>
 #include <new>
 #include <stdio.h>
@@ -479,18 +478,7 @@ extern "C" int svtme_picture_wait(svtme_engine *e, svtme_ticket ticket, svtme_re
         if (!f) return SVTME_ERR_NOT_FOUND;
     }
     HIP_TRY(hipSetDevice(e->cfg.device));
-    {
-        // A picture takes tens to hundreds of microseconds: poll first (a blocking wait can cost a sleep / wake-up of
-        // that order, depending on how the process set up the device), block only when it takes longer.
-        const auto t0 = std::chrono::steady_clock::now();
-        hipError_t q;
-        while ((q = hipEventQuery(f->ev[6])) == hipErrorNotReady) {
-            if (std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(2)) break;
-            __builtin_ia32_pause();
-        }
-        if (q == hipErrorNotReady) HIP_TRY(hipEventSynchronize(f->ev[6]));
-        else if (q != hipSuccess) return SVTME_ERR_DEVICE;
-    }
+    HIP_TRY(hipEventSynchronize(f->ev[6]));
     std::lock_guard<std::mutex> lock(e->mu);
     if (!f->waited) {
         f->waited = true;
