@@ -3,8 +3,9 @@
 // HIP streams: `s_store` carries the uploads and the store-building kernels, the `s_me` streams the search kernels
 // (pictures take turns on up to three of them, so one picture's kernel tails overlap the others' kernels), `s_copy`
 // the result copies when fewer than three search streams are in use (with three, a picture's copy follows its kernels
-// on its own stream: four hardware queues in all). A picture waits (on the device, through events) for the store slots it reads; a slot that is
-// rewritten waits for the last picture that read it. Nothing here blocks the host except svtme_picture_wait.
+// on its own stream: four hardware queues in all). A picture waits (on the device, through events) for the store slots
+// it reads; a slot that is rewritten waits for the last picture that read it. Nothing here blocks the host except
+// svtme_picture_wait (and svtme_store_put when it reuses a slot whose previous upload is still in flight).
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
@@ -56,7 +57,7 @@ struct Flight {
     HmeRefOut           *d_hme = nullptr;
     MeJob               *d_jobs = nullptr;
     unsigned long long  *d_keys = nullptr;
-    uint8_t             *d_res = nullptr; // best_sad | best_mv | search_results | zz | div
+    uint8_t             *d_res = nullptr; // the result block, see layout()
     // pinned host mirror of d_res
     uint8_t             *h_res = nullptr;
     size_t               off_sad = 0, off_mv = 0, off_sr = 0, off_zz = 0, off_div = 0, off_ops = 0, res_bytes = 0;
@@ -397,7 +398,7 @@ extern "C" int svtme_picture_submit(svtme_engine *e, const svtme_picture *pic, s
     p.search_results = reinterpret_cast<svtme_search_result *>(f->d_res + f->off_sr);
     p.zz_sad         = reinterpret_cast<uint32_t *>(f->d_res + f->off_zz);
     p.sr_divisor     = reinterpret_cast<uint32_t *>(f->d_res + f->off_div);
-    // the counters sit right behind this picture's HME records, so that one memset clears both
+    // the counters sit right behind this picture's HME records
     const size_t hme_bytes = n_b64 * SVTME_MAX_LISTS * SVTME_MAX_REFS * sizeof(HmeRefOut);
     p.ops            = reinterpret_cast<unsigned long long *>(reinterpret_cast<uint8_t *>(f->d_hme) + hme_bytes);
     p.ops_out        = reinterpret_cast<unsigned long long *>(f->d_res + f->off_ops);
@@ -449,7 +450,7 @@ extern "C" int svtme_picture_submit(svtme_engine *e, const svtme_picture *pic, s
     // the process stays within four hardware queues)
     const hipStream_t sc = n_sm >= 3 ? sm : e->s_copy;
     if (sc != sm) HIP_TRY(hipStreamWaitEvent(sc, f->ev[5], 0));
-    // tail.enable == 2: the host wants finished results only, the best SAD / MV arrays (the first two blocks) stay on the device
+    // tail.enable == 2: the host wants finished results only, the best SAD / MV planes (the end of the block) stay on the device
     f->skip_search_arrays = f->tail && pic->tail.enable == 2;
     const size_t c1 = f->skip_search_arrays ? f->tail_end : f->res_bytes;
     HIP_TRY(hipMemcpyAsync(f->h_res, f->d_res, c1, hipMemcpyDeviceToHost, sc));
