@@ -164,16 +164,27 @@ def tf_fields(out):
 
 
 def engine_vs_oracle(width, height, n_frames, enc_mode, seed=1, structure="ra", kind="synth", sc_class1=0,
-                     frame_rate=30 << 16, max_msgs=12, serial_hme=0):
-    frames, pics, rc = make_job(width, height, n_frames, enc_mode, seed, structure, kind)
-    recs = oracle_handover(frames, pics, enc_mode, rc, sc_class1=sc_class1, frame_rate=frame_rate)
-    outs = run_engine_job(frames, pics, enc_mode, sc_class1, frame_rate, serial_hme=serial_hme)
+                     frame_rate=30 << 16, max_msgs=12, serial_hme=0, motion=(3, -2), restricted=0):
+    frames, pics, rc = make_job(width, height, n_frames, enc_mode, seed, structure, kind, motion)
+    recs = oracle_handover(frames, pics, enc_mode, rc, sc_class1=sc_class1, frame_rate=frame_rate,
+                           restricted_motion_vector=restricted)
+    outs = run_engine_job(frames, pics, enc_mode, sc_class1, frame_rate, serial_hme=serial_hme, restricted=restricted)
     msgs = []
     for p, out, bd in zip(pics, outs, recs):
         msgs += compare_picture(out, bd, p, "poc %d (layer %d, refs %s)" % (p.poc, p.temporal_layer, p.refs))
         if len(msgs) >= max_msgs:
             break
     return msgs
+
+
+def random_case(seed):
+    """A seeded random open-loop job description (keyword arguments of engine_vs_oracle)."""
+    rng = np.random.default_rng(seed)
+    kind = str(rng.choice(["synth", "synth", "synth", "synth", "half_static", "noise", "flat", "max"]))
+    return dict(width=int(rng.integers(8, 57)) * 8, height=int(rng.integers(8, 41)) * 8, n_frames=int(rng.integers(3, 10)),
+                enc_mode=int(rng.integers(-2, 14)), seed=int(seed), structure=str(rng.choice(["ra", "ra", "ldb", "ldp"])),
+                kind=kind, sc_class1=int(rng.random() < 0.25), frame_rate=int(rng.choice([24, 30, 50, 60])) << 16,
+                motion=(int(rng.integers(-14, 15)), int(rng.integers(-9, 10))), restricted=int(rng.random() < 0.2))
 
 
 MAX_SAD_VALUE = 128 * 128 * 255

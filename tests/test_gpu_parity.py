@@ -72,6 +72,15 @@ def test_engine_matches_oracle_on_extreme_inputs(kind):
     assert not msgs, "\n".join(msgs)
 
 
+@pytest.mark.parametrize("seed", range(1000, 1000 + int(os.environ.get("SVTME_FUZZ_N", "16"))))
+def test_engine_matches_oracle_on_random_jobs(seed):
+    """Seeded random sizes (down to one 64x64 block), presets, prediction structures, contents, frame rates, motions,
+    screen-content and restricted-vector flags; SVTME_FUZZ_N widens the sweep."""
+    case = support.random_case(seed)
+    msgs = support.engine_vs_oracle(**case)
+    assert not msgs, repr(case) + "\n" + "\n".join(msgs)
+
+
 def test_engine_matches_oracle_screen_content_fast_presets():
     msgs = support.engine_vs_oracle(256, 192, 9, 9, seed=9, sc_class1=1)
     assert not msgs, "\n".join(msgs)
