@@ -187,6 +187,51 @@ def random_case(seed):
                 motion=(int(rng.integers(-14, 15)), int(rng.integers(-9, 10))), restricted=int(rng.random() < 0.2))
 
 
+def random_tf_case(seed):
+    rng = np.random.default_rng(seed)
+    return dict(width=int(rng.integers(8, 57)) * 8, height=int(rng.integers(8, 41)) * 8, n_frames=int(rng.integers(2, 6)),
+                seed=int(seed), kind=str(rng.choice(["synth", "synth", "synth", "half_static", "noise", "flat"])),
+                motion=(int(rng.integers(-14, 15)), int(rng.integers(-9, 10))), level=int(rng.integers(0, 3)),
+                exit_th=int(rng.choice([0, 0, 256, 4096])))
+
+
+def random_first_pass_case(seed):
+    rng = np.random.default_rng(seed)
+    return dict(width=int(rng.integers(8, 57)) * 8, height=int(rng.integers(8, 41)) * 8, n_frames=int(rng.integers(2, 6)),
+                seed=int(seed), kind=str(rng.choice(["synth", "synth", "synth", "half_static", "noise", "flat"])),
+                motion=(int(rng.integers(-14, 15)), int(rng.integers(-9, 10))), bypass_zz=int(rng.integers(0, 2)),
+                reduce_me=int(rng.integers(0, 2)), frame_rate=int(rng.choice([24, 30, 60])) << 16)
+
+
+STAT_FIELDS = ["rc_me_distortion", "me_64x64_distortion", "me_32x32_distortion", "me_16x16_distortion",
+               "me_8x8_distortion", "me_8x8_cost_variance", "stationary_block_present_sb", "rc_me_allow_gm"]
+
+
+def tail_of(pd0, gm_enabled=1):
+    """The svtme.Tail matching a dump's picture record."""
+    import svtme
+    return svtme.Tail(enable=1, enable_me_8x8=int(pd0["enable_me_8x8"]), enable_me_16x16=int(pd0["enable_me_16x16"]),
+                      max_refs=int(pd0["max_refs"]), max_cand=int(pd0["max_cand"]), max_l0=int(pd0["max_l0"]),
+                      input_resolution=int(pd0["input_resolution"]), gm_enabled=gm_enabled,
+                      gm_use_distance_based_active_th=gm_enabled)
+
+
+def device_tail_mismatches(out, bd, where):
+    """Device-side host tail of one picture against a final dump's records."""
+    msgs = []
+    for f in ("total_me_candidate_index", "me_mv_array", "me_candidate_array", "me_distortion"):
+        if not np.array_equal(out[f], bd[f]):
+            msgs.append("%s %s" % (where, f))
+    for j, f in enumerate(STAT_FIELDS):
+        if not np.array_equal(out["b64_stats"][:, j], bd[f].astype(np.uint32)):
+            msgs.append("%s %s" % (where, f))
+    if not np.array_equal(out["final_do_ref"], bd["do_ref"]):
+        msgs.append("%s do_ref" % where)
+    if not np.array_equal(out["final_hme_sad"], bd["hme_sad"]):
+        msgs.append("%s hme_sad" % where)
+    return msgs
+
+
 MAX_SAD_VALUE = 128 * 128 * 255
 
 

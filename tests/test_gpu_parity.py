@@ -81,6 +81,54 @@ def test_engine_matches_oracle_on_random_jobs(seed):
     assert not msgs, repr(case) + "\n" + "\n".join(msgs)
 
 
+@pytest.mark.parametrize("seed", range(3000, 3000 + int(os.environ.get("SVTME_FUZZ_N", "8"))))
+def test_device_side_host_tail_matches_oracle_on_random_jobs(seed):
+    c = support.random_case(seed)
+    frames, pics, rc = support.make_job(c["width"], c["height"], c["n_frames"], c["enc_mode"], c["seed"], c["structure"],
+                                        c["kind"], c["motion"])
+    _, recs = refio.run_oracle(frames, pics, c["enc_mode"], mode=refio.MODE_DUMP, threads=8, ref_counts=rc,
+                               sc_class1=c["sc_class1"], frame_rate=c["frame_rate"], gm_enabled=1, gm_dist_th=1,
+                               restricted_motion_vector=c["restricted"])
+    outs = support.run_engine_job(frames, pics, c["enc_mode"], c["sc_class1"], c["frame_rate"],
+                                  tail=support.tail_of(recs[0][0]), restricted=c["restricted"])
+    msgs = []
+    for p, out, (_, bd) in zip(pics, outs, recs):
+        msgs += support.device_tail_mismatches(out, bd, "poc %d" % p.poc)
+    assert not msgs, repr(c) + "\n" + "\n".join(msgs[:12])
+
+
+@pytest.mark.parametrize("seed", range(5000, 5000 + int(os.environ.get("SVTME_FUZZ_N", "8"))))
+def test_temporal_filter_search_matches_oracle_on_random_jobs(seed):
+    c = support.random_tf_case(seed)
+    frames, pics = support.make_tf_job(c["width"], c["height"], c["n_frames"], seed=c["seed"], kind=c["kind"], motion=c["motion"])
+    _, recs = refio.run_oracle(frames, pics, 0, mode=refio.MODE_DUMP_NOTAIL, threads=8, tf=(c["level"], c["exit_th"]))
+    outs = support.run_engine_tf_job(frames, pics, c["level"], c["exit_th"])
+    for (pd, bd), out, p in zip(recs, outs, pics):
+        want = MOD.tf_canonical(bd)
+        for f, v in support.tf_fields(out).items():
+            assert np.array_equal(v, want[f]), (c, "neighbour %d" % p.refs[0][0], f)
+
+
+@pytest.mark.parametrize("seed", range(7000, 7000 + int(os.environ.get("SVTME_FUZZ_N", "8"))))
+def test_first_pass_search_matches_oracle_on_random_jobs(seed):
+    c = support.random_first_pass_case(seed)
+    frames, pics = support.make_first_pass_job(c["width"], c["height"], c["n_frames"], seed=c["seed"], kind=c["kind"],
+                                               motion=c["motion"])
+    _, recs = refio.run_oracle(frames, pics, 0, mode=refio.MODE_DUMP, threads=8,
+                               first_pass=(c["bypass_zz"], c["reduce_me"]), frame_rate=c["frame_rate"], ref_counts=(2, 0))
+    outs = support.run_engine_first_pass_job(frames, pics, c["bypass_zz"], c["reduce_me"], c["frame_rate"],
+                                             tail=support.tail_of(recs[0][0], gm_enabled=0))
+    for p, out, (_, bd) in zip(pics, outs, recs):
+        sr = out["search_results"]
+        nr = len(p.refs[0])
+        for f in ("hme_sc_x", "hme_sc_y"):
+            assert np.array_equal(sr[f], bd[f]), (c, p.poc, f)
+        assert np.array_equal(out["best_sad"][:, 0, :nr], bd["best_sad"][:, 0, :nr]), (c, p.poc, "best_sad")
+        assert np.array_equal(out["best_mv"][:, 0, :nr], bd["best_mv"][:, 0, :nr]), (c, p.poc, "best_mv")
+        msgs = support.device_tail_mismatches(out, bd, "poc %d" % p.poc)
+        assert not msgs, repr(c) + "\n" + "\n".join(msgs)
+
+
 def test_engine_matches_oracle_screen_content_fast_presets():
     msgs = support.engine_vs_oracle(256, 192, 9, 9, seed=9, sc_class1=1)
     assert not msgs, "\n".join(msgs)
