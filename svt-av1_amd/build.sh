@@ -11,3 +11,7 @@ echo "built $OUT"
 gcc -std=c99 -O2 -Wall -Wextra -I "$HERE/../include" "$HERE/examples/me_shim_demo.c" -o "$HERE/svtme/me_shim_demo" \
     -L "$HERE/svtme" -lsvtme -Wl,-rpath,'$ORIGIN' -Wl,-rpath,/opt/rocm/lib
 echo "built $HERE/svtme/me_shim_demo"
+# the plain-C life-cycle / error-path driver (also the program tools/run_sanitized.sh runs against a host-sanitized build)
+gcc -std=gnu99 -O2 -Wall -Wextra -I "$HERE/../include" "$HERE/../tools/san_driver.c" -o "$HERE/svtme/abi_stress" \
+    -L "$HERE/svtme" -lsvtme -Wl,-rpath,'$ORIGIN' -Wl,-rpath,/opt/rocm/lib
+echo "built $HERE/svtme/abi_stress"

@@ -555,6 +555,19 @@ def test_plain_c_program_drives_the_engine_like_the_encoder_would():
     assert out["best_mv"][:, 0, 0].any(), "the job should find motion"
 
 
+def test_plain_c_life_cycle_and_error_path_driver():
+    """tools/san_driver.c: full store, pictures in flight, slot overwrite / release under readers, every me_type, both tail
+    forms, the documented error codes, destroy with work outstanding. Deterministic, so two runs agree on its checksum
+    (tools/run_sanitized.sh runs the same program against a host-sanitized build of the library)."""
+    import subprocess
+    exe = os.path.join(os.path.dirname(svtme.LIB_PATH), "abi_stress")
+    assert os.path.exists(exe), "run svt-av1_amd/build.sh"
+    runs = [subprocess.run([exe], capture_output=True, text=True, timeout=120) for _ in range(2)]
+    for r in runs:
+        assert r.returncode == 0 and r.stdout.startswith("ok "), r.stdout + r.stderr
+    assert runs[0].stdout == runs[1].stdout
+
+
 def test_concurrent_callers_get_the_same_results():
     """The encoder's ME threads call the engine concurrently (up to one per segment): four threads submit / wait / unpack
     different pictures of one sequence at the same time; every result equals the one of a single-threaded run."""

@@ -1,0 +1,232 @@
+/*
+ * san_driver.c - drives the C ABI through its host-side paths so that a host-sanitized build of the library
+ * (tools/run_sanitized.sh: AddressSanitizer + UndefinedBehaviorSanitizer on the host code only) sees them: engines of
+ * several sizes, pictures in flight on a small store, slot overwrite and release with readers in flight, every
+ * me_type, the device tail in both forms, argument errors, and destroy with work outstanding.
+ * Prints "ok <checksum>"; the sanitizers abort on their own findings.
+ */
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <unistd.h>
+
+#include "svtme.h"
+
+static uint32_t lcg(uint32_t *s) {
+    *s = *s * 1664525u + 1013904223u;
+    return *s >> 8;
+}
+
+static uint64_t fnv(uint64_t h, const void *p, size_t n) {
+    const uint8_t *b = (const uint8_t *)p;
+    for (size_t i = 0; i < n; ++i) h = (h ^ b[i]) * 1099511628211ull;
+    return h;
+}
+
+#define CHECK(call)                                                                      \
+    do {                                                                                 \
+        int rc_ = (call);                                                                \
+        if (rc_ != SVTME_OK) {                                                           \
+            fprintf(stderr, "%s:%d %s failed with status %d\n", __FILE__, __LINE__, #call, rc_); \
+            exit(1);                                                                     \
+        }                                                                                \
+    } while (0)
+#define EXPECT(call, want)                                                               \
+    do {                                                                                 \
+        int rc_ = (call);                                                                \
+        if (rc_ != (want)) {                                                             \
+            fprintf(stderr, "%s:%d %s gave %d, expected %d\n", __FILE__, __LINE__, #call, rc_, (int)(want)); \
+            exit(1);                                                                     \
+        }                                                                                \
+    } while (0)
+
+static uint8_t *make_luma(uint32_t h, uint32_t stride, int k, uint32_t *seed) {
+    uint8_t *p = (uint8_t *)malloc((size_t)stride * h); /* exactly the bytes the ABI may read */
+    for (uint32_t y = 0; y < h; ++y)
+        for (uint32_t x = 0; x < stride; ++x) {
+            const uint32_t sx = x + 40 + 3 * (uint32_t)k, sy = y + 40 - 2 * (uint32_t)k;
+            p[(size_t)y * stride + x] = (uint8_t)((((sx >> 3) * 37 + (sy >> 3) * 91) & 0xFF) / 2 + ((sx * 5 + sy * 3) & 31) + (lcg(seed) & 3));
+        }
+    return p;
+}
+
+/* reads every byte a result hands out */
+static uint64_t hash_results(const svtme_results *r, const svtme_picture *pic, uint64_t h) {
+    const size_t n = r->n_b64, planes = (size_t)r->n_ref[0] + r->n_ref[1];
+    if (r->p_sb_best_sad) h = fnv(h, r->p_sb_best_sad, planes * n * SVTME_PU_COUNT * 4);
+    if (r->p_sb_best_mv) h = fnv(h, r->p_sb_best_mv, planes * n * SVTME_PU_COUNT * 4);
+    h = fnv(h, r->search_results, n * 8 * sizeof(svtme_search_result));
+    h = fnv(h, r->zz_sad, n * 8 * 4);
+    h = fnv(h, r->reduce_me_sr_divisor, n * 8 * 4);
+    if (pic->tail.enable) {
+        h = fnv(h, r->total_me_candidate_index, n * SVTME_PU_COUNT);
+        h = fnv(h, r->me_mv_array, n * SVTME_PU_COUNT * SVTME_TAIL_MV_STRIDE * 4);
+        h = fnv(h, r->me_candidate_array, n * SVTME_PU_COUNT * SVTME_TAIL_CAND_STRIDE);
+        h = fnv(h, r->me_distortion, n * SVTME_PU_COUNT * 4);
+        h = fnv(h, r->b64_stats, n * 8 * 4);
+        h = fnv(h, r->final_do_ref, n * 8);
+        h = fnv(h, r->final_hme_sad, n * 8 * 8);
+    }
+    if (r->p_sb_best_sad) {
+        static uint32_t            sad[2][4][85], mv[2][4][85], zz[2][4], dv[2][4];
+        static svtme_search_result sr[2][4];
+        for (uint32_t b = 0; b < r->n_b64; ++b) {
+            CHECK(svtme_unpack_b64(r, b, &sad[0][0][0], &mv[0][0][0], &sr[0][0], &zz[0][0], &dv[0][0]));
+            h = fnv(h, sad, sizeof(sad));
+            h = fnv(h, mv, sizeof(mv));
+        }
+        EXPECT(svtme_unpack_b64(r, r->n_b64, &sad[0][0][0], &mv[0][0][0], &sr[0][0], &zz[0][0], &dv[0][0]), SVTME_ERR_BAD_ARG);
+    }
+    return h;
+}
+
+static void base_picture(svtme_picture *pic, uint32_t w, uint32_t h, uint64_t cur, uint64_t poc) {
+    memset(pic, 0, sizeof(*pic));
+    pic->cur_key = cur;
+    pic->picture_number = poc;
+    pic->width = w;
+    pic->height = h;
+}
+
+static void add_ref(svtme_picture *pic, int list, uint64_t key, uint64_t poc) {
+    const int r = pic->num_of_ref_pic_to_search[list]++;
+    pic->ref_key[list][r] = key;
+    pic->ref_picture_number[list][r] = poc;
+    if (pic->num_of_list_to_search < list + 1) pic->num_of_list_to_search = (uint8_t)(list + 1);
+}
+
+static uint64_t run_size(uint32_t w, uint32_t h, uint32_t max_w, uint32_t max_h, int preset, uint32_t seed, uint64_t hsh) {
+    enum { N = 6 };
+    svtme_config cfg;
+    memset(&cfg, 0, sizeof(cfg));
+    cfg.max_width = max_w;
+    cfg.max_height = max_h;
+    cfg.store_slots = N; /* + one overwrite below: the store is full while pictures are in flight */
+    cfg.max_in_flight = 3;
+    cfg.kernel_timing = 1;
+    svtme_engine *eng = NULL;
+    CHECK(svtme_create(&cfg, &eng));
+    uint8_t *luma[N];
+    for (int k = 0; k < N; ++k) {
+        const uint32_t stride = (k & 1) ? w + 24 : w; /* both upload paths */
+        luma[k] = make_luma(h, stride, k, &seed);
+        CHECK(svtme_store_put(eng, 10 + (uint64_t)k, (uint64_t)k, luma[k], stride, w, h));
+    }
+    EXPECT(svtme_store_put(eng, 99, 9, luma[0], w, w, h), SVTME_ERR_NO_RESOURCES); /* store full */
+    EXPECT(svtme_store_put(eng, 10, 0, luma[0], w - 8, w, h), SVTME_ERR_BAD_ARG); /* stride < width */
+    EXPECT(svtme_store_release(eng, 12345), SVTME_ERR_NOT_FOUND);
+
+    svtme_preset_key key;
+    memset(&key, 0, sizeof(key));
+    key.enc_mode = (int8_t)preset;
+    key.input_resolution = svtme_input_resolution(w, h);
+    key.frame_rate = 30u << 16;
+    svtme_picture pic[4];
+    /* a B picture with 2 + 2 references, no tail */
+    base_picture(&pic[0], w, h, 12, 2);
+    pic[0].temporal_layer_index = 1;
+    add_ref(&pic[0], 0, 11, 1), add_ref(&pic[0], 0, 10, 0), add_ref(&pic[0], 1, 13, 3), add_ref(&pic[0], 1, 14, 4);
+    CHECK(svtme_derive_controls(&key, &pic[0].ctrl));
+    /* a base-layer picture with the device tail */
+    base_picture(&pic[1], w, h, 14, 4);
+    pic[1].is_used_as_reference_flag = 1;
+    add_ref(&pic[1], 0, 10, 0), add_ref(&pic[1], 0, 11, 1), add_ref(&pic[1], 1, 10, 0);
+    CHECK(svtme_derive_controls(&key, &pic[1].ctrl));
+    pic[1].tail.enable = 1;
+    pic[1].tail.enable_me_8x8 = pic[1].tail.enable_me_16x16 = 1;
+    pic[1].tail.max_refs = 7, pic[1].tail.max_cand = 23, pic[1].tail.max_l0 = 4;
+    pic[1].tail.input_resolution = key.input_resolution;
+    pic[1].tail.gm_enabled = pic[1].tail.gm_use_distance_based_active_th = 1;
+    /* tail results only */
+    pic[2] = pic[1];
+    pic[2].cur_key = 13, pic[2].picture_number = 3, pic[2].tail.enable = 2;
+    /* a P picture */
+    base_picture(&pic[3], w, h, 15, 5);
+    add_ref(&pic[3], 0, 14, 4);
+    CHECK(svtme_derive_controls(&key, &pic[3].ctrl));
+
+    svtme_ticket  t[4];
+    svtme_results res;
+    for (int i = 0; i < 3; ++i) CHECK(svtme_picture_submit(eng, &pic[i], &t[i]));
+    EXPECT(svtme_picture_submit(eng, &pic[3], &t[3]), SVTME_ERR_NO_RESOURCES); /* max_in_flight */
+    /* overwrite and release slots the pictures in flight still read */
+    CHECK(svtme_store_put(eng, 10, 0, luma[1], w + 24, w, h));
+    CHECK(svtme_store_release(eng, 11));
+    for (int i = 0; i < 3; ++i) {
+        float    ms[8];
+        uint64_t ops[6];
+        CHECK(svtme_picture_wait(eng, t[i], &res));
+        hsh = hash_results(&res, &pic[i], hsh);
+        CHECK(svtme_picture_timing(eng, t[i], ms));
+        CHECK(svtme_picture_ops(eng, t[i], ops));
+        hsh = fnv(hsh, ops, sizeof(ops));
+        CHECK(svtme_picture_done(eng, t[i]));
+        EXPECT(svtme_picture_done(eng, t[i]), SVTME_ERR_NOT_FOUND);
+    }
+    EXPECT(svtme_picture_submit(eng, &pic[0], &t[0]), SVTME_ERR_NOT_FOUND); /* reference 11 was released */
+    CHECK(svtme_picture_submit(eng, &pic[3], &t[3]));
+    CHECK(svtme_picture_wait(eng, t[3], &res));
+    hsh = hash_results(&res, &pic[3], hsh);
+    CHECK(svtme_picture_done(eng, t[3]));
+
+    /* temporal filter pair and first-pass picture */
+    svtme_picture tf;
+    base_picture(&tf, w, h, 12, 2);
+    tf.me_type = SVTME_ME_MCTF;
+    tf.is_used_as_reference_flag = 1;
+    add_ref(&tf, 0, 13, 3);
+    tf.tf_me_exit_th = 256;
+    for (uint8_t level = 0; level < 3; ++level) {
+        CHECK(svtme_derive_tf_controls(level, &tf.ctrl));
+        CHECK(svtme_picture_submit(eng, &tf, &t[0]));
+        CHECK(svtme_picture_wait(eng, t[0], &res));
+        hsh = hash_results(&res, &tf, hsh);
+        CHECK(svtme_picture_done(eng, t[0]));
+    }
+    EXPECT(svtme_derive_tf_controls(3, &tf.ctrl), SVTME_ERR_BAD_ARG);
+    svtme_picture fp;
+    base_picture(&fp, w, h, 15, 5);
+    fp.me_type = SVTME_ME_FIRST_PASS;
+    fp.is_used_as_reference_flag = 1;
+    fp.bypass_zz_check = 1;
+    add_ref(&fp, 0, 14, 4), add_ref(&fp, 0, 10, 0);
+    CHECK(svtme_derive_first_pass_controls(key.input_resolution, key.frame_rate, 0, &fp.ctrl));
+    fp.tail.enable = 1;
+    fp.tail.enable_me_8x8 = fp.tail.enable_me_16x16 = 1;
+    fp.tail.max_refs = 2, fp.tail.max_cand = 3, fp.tail.max_l0 = 1;
+    CHECK(svtme_picture_submit(eng, &fp, &t[0]));
+    CHECK(svtme_picture_wait(eng, t[0], &res));
+    hsh = hash_results(&res, &fp, hsh);
+    CHECK(svtme_picture_done(eng, t[0]));
+
+    /* read back a plane, then leave with a picture still in flight */
+    {
+        uint32_t stride = 0, pw = 0, ph = 0, pad = 0;
+        EXPECT(svtme_store_read(eng, 14, 2, NULL, 0, &stride, &pw, &ph, &pad), SVTME_ERR_BAD_ARG);
+        const size_t bytes = (size_t)(w + 2 * 72) * (h + 2 * 72);
+        uint8_t     *dst = (uint8_t *)malloc(bytes);
+        CHECK(svtme_store_read(eng, 14, 2, dst, bytes, &stride, &pw, &ph, &pad));
+        hsh = fnv(hsh, dst, (size_t)stride * (ph + 2 * pad));
+        EXPECT(svtme_store_read(eng, 14, 2, dst, bytes - 1, &stride, &pw, &ph, &pad), SVTME_ERR_BAD_ARG);
+        free(dst);
+    }
+    CHECK(svtme_picture_submit(eng, &pic[3], &t[3]));
+    svtme_destroy(eng);
+    for (int k = 0; k < N; ++k) free(luma[k]);
+    return hsh;
+}
+
+int main(void) {
+    uint64_t h = 1469598103934665603ull;
+    EXPECT(svtme_create(NULL, NULL), SVTME_ERR_BAD_ARG);
+    h = run_size(192, 136, 192, 136, 8, 1, h);
+    h = run_size(128, 64, 256, 192, 3, 2, h); /* smaller pictures than the engine was sized for */
+    h = run_size(328, 200, 328, 200, 12, 3, h);
+    h = run_size(64, 64, 64, 64, 0, 4, h);
+    printf("ok %016llx\n", (unsigned long long)h);
+    fflush(stdout);
+    /* leave without running the HIP runtime's exit handlers: under the sanitizer's allocator they fail a check of the
+       sanitizer runtime itself (memory freed after its device hooks were torn down), which is not the library's doing */
+    _exit(0);
+}
