@@ -61,12 +61,13 @@ _OUT = "<8sIIIIIIdQ"
 
 def write_job(path, frames, pics, enc_mode, *, mode=MODE_DUMP, threads=1, use_avx2=0, reps=1,
               frame_rate=30 << 16, sc_class1=0, gm_enabled=0, gm_dist_th=0, ref_counts=(4, 3), tf=None, first_pass=None,
-              restricted_motion_vector=0):
+              restricted_motion_vector=0, number_scale=1):
     """frames: uint8 [n, h, w]; pics: list of svtme.gop.Picture (refs are POCs = frame indices).
     tf = (hme_me_level, me_exit_th) runs every picture as a temporal-filter search (ME_MCTF) of its first list-0
     reference: the controls then come from tf_signal_derivation_me_kernel_oq and enc_mode is not used.
     first_pass = (bypass_zz_check, reduce_me_search) runs every picture as first-pass ME (ME_FIRST_PASS): controls from
-    first_pass_signal_derivation_me_kernel; enc_mode only selects the HME level flags."""
+    first_pass_signal_derivation_me_kernel; enc_mode only selects the HME level flags.
+    number_scale: picture numbers are poc * number_scale (frames stay indexed by poc): stretches the picture distances."""
     variant = (1, tf[0], tf[1]) if tf else ((4, (first_pass[0] & 1) | ((first_pass[1] & 1) << 1), 0) if first_pass else (0, 0, 0))
     n, h, w = frames.shape
     with open(path, "wb") as f:
@@ -79,9 +80,9 @@ def write_job(path, frames, pics, enc_mode, *, mode=MODE_DUMP, threads=1, use_av
                 for i, r in enumerate(p.refs[l][:4]):
                     rf[l][i] = r
             n_list = 2 if p.refs[1] else 1
-            f.write(struct.pack(_PIC, p.poc, frame_rate, p.poc, enc_mode, p.temporal_layer, p.is_ref, n_list,
+            f.write(struct.pack(_PIC, p.poc, frame_rate, p.poc * number_scale, enc_mode, p.temporal_layer, p.is_ref, n_list,
                                 len(p.refs[0]), len(p.refs[1]), sc_class1, gm_enabled, gm_dist_th,
-                                *rf[0], *rf[1], *rf[0], *rf[1], *variant, restricted_motion_vector))
+                                *rf[0], *rf[1], *[r * number_scale for r in rf[0] + rf[1]], *variant, restricted_motion_vector))
 
 
 def read_dump(path):

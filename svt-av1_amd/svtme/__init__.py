@@ -222,13 +222,14 @@ class Engine:
         return buf[:rows * st.value].reshape(rows, st.value).copy()
 
     def make_picture(self, width, height, poc, temporal_layer, is_ref, refs, ctrl, key_of=lambda poc: poc, tail=None,
-                     tf_me_exit_th=None, first_pass_bypass_zz=None, restricted_motion_vector=0):
-        """refs: [[pocs of list 0], [pocs of list 1]]; tail: a Tail to run the host tail on the device too;
+                     tf_me_exit_th=None, first_pass_bypass_zz=None, restricted_motion_vector=0, number_of=lambda poc: poc):
+        """refs: [[pocs of list 0], [pocs of list 1]]; number_of: poc -> picture_number (the search areas grow with the
+        picture-number distance); tail: a Tail to run the host tail on the device too;
         tf_me_exit_th: not None makes it a temporal-filter search (ME_MCTF) of refs[0][0] with that exit threshold;
         first_pass_bypass_zz: not None makes it a first-pass search (ME_FIRST_PASS) with that bypass_zz_check."""
         p = Picture()
         p.cur_key = key_of(poc)
-        p.picture_number = poc
+        p.picture_number = number_of(poc)
         p.width, p.height = width, height
         p.temporal_layer_index = temporal_layer
         p.is_used_as_reference_flag = is_ref
@@ -237,7 +238,7 @@ class Engine:
             p.num_of_ref_pic_to_search[l] = len(refs[l])
             for i, r in enumerate(refs[l]):
                 p.ref_key[l][i] = key_of(r)
-                p.ref_picture_number[l][i] = r
+                p.ref_picture_number[l][i] = number_of(r)
         p.ctrl = ctrl
         if tail is not None:
             p.tail = tail

@@ -99,7 +99,7 @@ def compare_picture(out, bd, pic, where=""):
 
 
 def run_engine_job(frames, pics, enc_mode, sc_class1=0, frame_rate=30 << 16, engine=None, tail=None, serial_hme=0,
-                   restricted=0):
+                   restricted=0, number_scale=1):
     """Runs every picture of the job through the engine's C ABI; returns the list of output dicts. tail: an
     svtme.Tail to run the host tail on the device as well."""
     import svtme
@@ -113,7 +113,7 @@ def run_engine_job(frames, pics, enc_mode, sc_class1=0, frame_rate=30 << 16, eng
         outs = []
         for p in pics:
             pic = eng.make_picture(w, h, p.poc, p.temporal_layer, p.is_ref, p.refs, ctrl, tail=tail,
-                                   restricted_motion_vector=restricted)
+                                   restricted_motion_vector=restricted, number_of=lambda poc: poc * number_scale)
             outs.append(eng.run_picture(pic))
         return outs
     finally:
@@ -164,11 +164,12 @@ def tf_fields(out):
 
 
 def engine_vs_oracle(width, height, n_frames, enc_mode, seed=1, structure="ra", kind="synth", sc_class1=0,
-                     frame_rate=30 << 16, max_msgs=12, serial_hme=0, motion=(3, -2), restricted=0):
+                     frame_rate=30 << 16, max_msgs=12, serial_hme=0, motion=(3, -2), restricted=0, number_scale=1):
     frames, pics, rc = make_job(width, height, n_frames, enc_mode, seed, structure, kind, motion)
     recs = oracle_handover(frames, pics, enc_mode, rc, sc_class1=sc_class1, frame_rate=frame_rate,
-                           restricted_motion_vector=restricted)
-    outs = run_engine_job(frames, pics, enc_mode, sc_class1, frame_rate, serial_hme=serial_hme, restricted=restricted)
+                           restricted_motion_vector=restricted, number_scale=number_scale)
+    outs = run_engine_job(frames, pics, enc_mode, sc_class1, frame_rate, serial_hme=serial_hme, restricted=restricted,
+                          number_scale=number_scale)
     msgs = []
     for p, out, bd in zip(pics, outs, recs):
         msgs += compare_picture(out, bd, p, "poc %d (layer %d, refs %s)" % (p.poc, p.temporal_layer, p.refs))

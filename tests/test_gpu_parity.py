@@ -129,6 +129,16 @@ def test_first_pass_search_matches_oracle_on_random_jobs(seed):
         assert not msgs, repr(c) + "\n" + "\n".join(msgs)
 
 
+@pytest.mark.parametrize("scale", [5, 13, 40, 300, 5000, 9000])
+def test_engine_matches_oracle_at_large_picture_distances(scale):
+    """Picture numbers stretched by `scale` (long-term references, and the 16-bit wrap of the reference's distance,
+    EbMotionEstimation.c:1269-1271): the search areas hit their caps; the oracle is byte-exact with the real reference
+    on the same jobs."""
+    for seed, mode, structure in ((1, 8, "ra"), (2, 3, "ra"), (3, 12, "ldb"), (4, 0, "ra"), (5, 10, "ldp")):
+        msgs = support.engine_vs_oracle(200, 136, 6, mode, seed=seed, structure=structure, motion=(5, -3), number_scale=scale)
+        assert not msgs, "preset %d\n" % mode + "\n".join(msgs)
+
+
 def test_engine_matches_oracle_screen_content_fast_presets():
     msgs = support.engine_vs_oracle(256, 192, 9, 9, seed=9, sc_class1=1)
     assert not msgs, "\n".join(msgs)
