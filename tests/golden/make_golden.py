@@ -44,6 +44,11 @@ DIGEST_CASES = {
     "m12_ldp_1280x720": dict(width=1280, height=720, n_frames=5, enc_mode=12, seed=32, structure="ldp"),
     "m3_ra_640x360": dict(width=640, height=360, n_frames=17, enc_mode=3, seed=33, structure="ra"),
 }
+# the benchmark's largest picture sizes: digests only, checked by the GPU tests (the CPU restatement is not run on them)
+BIG_DIGEST_CASES = {
+    "m8_ra_3840x2160": dict(width=3840, height=2160, n_frames=5, enc_mode=8, seed=34, structure="ra", motion=(7, -4)),
+    "m2_ra_7680x4320": dict(width=7680, height=4320, n_frames=5, enc_mode=2, seed=35, structure="ra", motion=(9, -6)),
+}
 
 
 # temporal-filter searches (ME_MCTF): level = tf_ctrls.hme_me_level, exit_th = tf_ctrls.me_exit_th
@@ -107,9 +112,33 @@ def run_case(c, threads=1):
     return frames, pics, recs
 
 
+def digest_case(c, threads=8):
+    frames, pics, recs = run_case(c, threads=threads)
+    d = {"frames_sha256": hashlib.sha256(frames.tobytes()).hexdigest(), "pictures": []}
+    for (pd, bd) in recs:
+        canon = support.canonical(bd, pics[len(d["pictures"])], bool(pd["ctrl"]["enable_me_hme_ref_pruning"]))
+        d["pictures"].append({f: hashlib.sha256(v.tobytes()).hexdigest() for f, v in canon.items()})
+    return d
+
+
+def main_big():
+    """`make_golden.py --big`: only the BIG_DIGEST_CASES (minutes of reference time each), merged into digests.json."""
+    path = os.path.join(HERE, "digests.json")
+    with open(path) as f:
+        doc = json.load(f)
+    for name, c in BIG_DIGEST_CASES.items():
+        doc["digests"][name] = digest_case(c)
+        doc["cases"][name] = dict(c)
+        print(name, "digested", len(doc["digests"][name]["pictures"]), "pictures")
+    with open(path, "w") as f:
+        json.dump(doc, f, indent=1)
+
+
 def main():
     if not refio.have_reference():
         sys.exit("oracle/_ref/ref_me missing: run `make -C oracle ref` where /root/reference exists")
+    if "--big" in sys.argv:
+        return main_big()
     for name, c in CASES.items():
         frames, pics, recs = run_case(c)
         pd = np.stack([r[0] for r in recs])
@@ -141,17 +170,12 @@ def main():
             d["pictures"].append({f: hashlib.sha256(v.tobytes()).hexdigest() for f, v in tf_canonical(bd).items()})
         digests[name] = d
         print(name, "digested", len(recs), "pairs")
-    for name, c in DIGEST_CASES.items():
-        frames, pics, recs = run_case(c, threads=8)
-        d = {"frames_sha256": hashlib.sha256(frames.tobytes()).hexdigest(), "pictures": []}
-        for (pd, bd) in recs:
-            canon = support.canonical(bd, pics[len(d["pictures"])], bool(pd["ctrl"]["enable_me_hme_ref_pruning"]))
-            d["pictures"].append({f: hashlib.sha256(v.tobytes()).hexdigest() for f, v in canon.items()})
-        digests[name] = d
-        print(name, "digested", len(recs), "pictures")
+    for name, c in list(DIGEST_CASES.items()) + list(BIG_DIGEST_CASES.items()):
+        digests[name] = digest_case(c)
+        print(name, "digested", len(digests[name]["pictures"]), "pictures")
     with open(os.path.join(HERE, "digests.json"), "w") as f:
-        json.dump({"cases": {k: dict(v) for k, v in list(DIGEST_CASES.items()) + list(TF_DIGEST_CASES.items())},
-                   "digests": digests}, f, indent=1)
+        json.dump({"cases": {k: dict(v) for k, v in list(DIGEST_CASES.items()) + list(BIG_DIGEST_CASES.items()) +
+                             list(TF_DIGEST_CASES.items())}, "digests": digests}, f, indent=1)
 
 
 if __name__ == "__main__":
