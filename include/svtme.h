@@ -145,7 +145,9 @@ typedef struct svtme_config {
                             independent work items; same results, slower; kept as a cross-check */
 } svtme_config;
 
-/* Replaces nothing in the reference (the reference has no device): engine life cycle. */
+/* Replaces nothing in the reference (the reference has no device): engine life cycle. Every call of this library makes
+ * the engine's device current while it runs and leaves the calling thread's current HIP device as it found it. Calls
+ * on one engine may come from several threads (an internal mutex orders them). */
 int  svtme_create(const svtme_config *cfg, svtme_engine **out);
 void svtme_destroy(svtme_engine *e);
 

@@ -111,6 +111,26 @@ namespace {
 
 size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
+// Makes the engine's device current for the calling thread and puts the thread's previous device back on the way out,
+// so that a caller that works on several devices (or a framework that tracks its own current device) is not disturbed.
+struct DeviceGuard {
+    int  prev = -1;
+    bool ok   = false;
+    explicit DeviceGuard(int device) {
+        if (hipGetDevice(&prev) != hipSuccess) prev = -1;
+        ok = prev == device || hipSetDevice(device) == hipSuccess;
+        if (prev == device) prev = -1; // nothing to put back
+    }
+    ~DeviceGuard() {
+        if (prev >= 0) (void)hipSetDevice(prev);
+    }
+    DeviceGuard(const DeviceGuard &)            = delete;
+    DeviceGuard &operator=(const DeviceGuard &) = delete;
+};
+#define DEVICE_OR_FAIL(device)                  \
+    DeviceGuard device_guard__(device);         \
+    if (!device_guard__.ok) return SVTME_ERR_DEVICE
+
 // Lays the three planes of a picture of w x h into one slot allocation.
 void layout_planes(uint8_t *mem, uint32_t w, uint32_t h, DevPicture *pic, size_t *bytes) {
     size_t off = 0;
@@ -161,7 +181,7 @@ extern "C" int svtme_create(const svtme_config *cfg, svtme_engine **out) {
         fprintf(stderr, "svtme: no HIP device %d (found %d)\n", cfg->device, n_dev);
         return SVTME_ERR_DEVICE;
     }
-    HIP_TRY(hipSetDevice(cfg->device));
+    DEVICE_OR_FAIL(cfg->device);
     svtme_engine *e = new (std::nothrow) svtme_engine();
     if (!e) return SVTME_ERR_NO_RESOURCES;
     e->cfg = *cfg;
@@ -210,7 +230,7 @@ extern "C" int svtme_create(const svtme_config *cfg, svtme_engine **out) {
 
 extern "C" void svtme_destroy(svtme_engine *e) {
     if (!e) return;
-    (void)hipSetDevice(e->cfg.device);
+    DeviceGuard guard(e->cfg.device);
     for (auto sm : e->s_me)
         if (sm) (void)hipStreamSynchronize(sm);
     if (e->s_copy) (void)hipStreamSynchronize(e->s_copy);
@@ -237,7 +257,7 @@ extern "C" int svtme_store_put(svtme_engine *e, uint64_t key, uint64_t picture_n
         height > e->cfg.max_height || stride < width)
         return SVTME_ERR_BAD_ARG;
     std::lock_guard<std::mutex> lock(e->mu);
-    HIP_TRY(hipSetDevice(e->cfg.device));
+    DEVICE_OR_FAIL(e->cfg.device);
     int si = find_slot(e, key);
     if (si < 0) {
         for (size_t i = 0; i < e->slots.size(); ++i)
@@ -287,7 +307,7 @@ extern "C" int svtme_store_read(svtme_engine *e, uint64_t key, int level, uint8_
                                 uint32_t *width, uint32_t *height, uint32_t *pad) {
     if (!e || level < 0 || level > 2 || !dst) return SVTME_ERR_BAD_ARG;
     std::lock_guard<std::mutex> lock(e->mu);
-    HIP_TRY(hipSetDevice(e->cfg.device));
+    DEVICE_OR_FAIL(e->cfg.device);
     const int si = find_slot(e, key);
     if (si < 0) return SVTME_ERR_NOT_FOUND;
     const DevPlane &p  = e->slots[si].pic.lvl[level];
@@ -330,7 +350,7 @@ extern "C" int svtme_picture_submit(svtme_engine *e, const svtme_picture *pic, s
         return SVTME_ERR_BAD_ARG;
 
     std::lock_guard<std::mutex> lock(e->mu);
-    HIP_TRY(hipSetDevice(e->cfg.device));
+    DEVICE_OR_FAIL(e->cfg.device);
     Flight *f = nullptr;
     for (auto &c : e->flights)
         if (!c.busy) {
@@ -478,7 +498,7 @@ extern "C" int svtme_picture_wait(svtme_engine *e, svtme_ticket ticket, svtme_re
         f = find_flight(e, ticket);
         if (!f) return SVTME_ERR_NOT_FOUND;
     }
-    HIP_TRY(hipSetDevice(e->cfg.device));
+    DEVICE_OR_FAIL(e->cfg.device);
     HIP_TRY(hipEventSynchronize(f->ev[6]));
     std::lock_guard<std::mutex> lock(e->mu);
     if (!f->waited) {
@@ -579,7 +599,7 @@ extern "C" int svtme_unpack_b64(const svtme_results *res, uint32_t b64_index, ui
 
 // Diagnostic, not part of the public header: resident workgroups per CU of {hme_l0, hme_l12, me_search}.
 extern "C" int svtme_debug_occupancy(int device, int out[3]) {
-    HIP_TRY(hipSetDevice(device));
+    DEVICE_OR_FAIL(device);
     occupancy_hme_items(out);
     out[2] = occupancy_me_search();
     return SVTME_OK;
