@@ -10,7 +10,7 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libsvtme.so")
+LIB_PATH = os.environ.get("SVTME_LIB") or os.path.join(_HERE, "libsvtme.so")  # SVTME_LIB: a diagnostic build of the same library
 
 MAX_LISTS, MAX_REFS, PU_COUNT = 2, 4, 85
 OK, ERR_BAD_ARG, ERR_NO_RESOURCES, ERR_NOT_FOUND, ERR_DEVICE, ERR_UNSUPPORTED = 0, -1, -2, -3, -4, -5
