@@ -7,7 +7,9 @@
 A step = the ME of one mini-GOP (all its pictures x all their references) over synthetic pictures that are already
 resident in the device picture store when the timed region starts; results (best SAD / MV per partition, search
 centres) are copied back to pinned host memory inside the timed region. Pictures are independent, so every rank
-runs its own mini-GOPs (weak scaling, no data-path collective); rank 0 prints one JSON line.
+runs its own mini-GOPs (weak scaling, no data-path collective); rank 0 prints one JSON line. The K timed steps run
+back to back with at most --in-flight pictures outstanding (mini-GOPs follow each other without a pause, as in the
+encoder); all of them have been waited for when the clock stops.
 
 `value` comes from the timed region, in which the engine rotates pictures over three HIP streams (one picture's
 kernel tails overlap the other pictures' kernels). Kernel durations measured there include that sharing, so the
@@ -170,13 +172,16 @@ def main():
     new_stats = lambda: {"ms": np.zeros(8, np.float64), "launches": 0, "ops": np.zeros(6, np.float64)}  # noqa: E731
     stats = new_stats()
 
-    def step(collect, e=None, ds=None):
+    def run_steps(k, collect, e=None, ds=None):
+        """k steps back to back: at most --in-flight pictures outstanding, also across step boundaries (mini-GOPs follow
+        each other without a pause, as they do in the encoder); everything has been waited for on return."""
         e, ds = e or eng, ds or descs
         tickets = []
-        for d in ds:
-            if len(tickets) == args.in_flight:
-                finish(e, tickets.pop(0), collect)
-            tickets.append(e.submit(d))
+        for _ in range(k):
+            for d in ds:
+                if len(tickets) == args.in_flight:
+                    finish(e, tickets.pop(0), collect)
+                tickets.append(e.submit(d))
         while tickets:
             finish(e, tickets.pop(0), collect)
 
@@ -193,12 +198,10 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        step(None)
+    run_steps(args.warmup, None)
     barrier()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step(None)  # nothing but submit / wait / done per picture inside the timed region
+    run_steps(args.steps, None)  # nothing but submit / wait / done per picture inside the timed region
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
     barrier()
@@ -206,8 +209,7 @@ def main():
         tt = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if rehearsal else "cuda")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
-    for _ in range(min(args.steps, 4)):  # kernel spans while the streams share the GPU (reported beside the solo timings)
-        step(stats)
+    run_steps(min(args.steps, 4), stats)  # kernel spans while the streams share the GPU (reported beside the solo timings)
     # host -> device: what putting one new source picture into the store costs (pinned staging copy, H2D, the pad /
     # decimate kernels); every picture is put once and then read by its own search and by up to 7 later ones
     upload_pps = None
@@ -225,9 +227,8 @@ def main():
         eng.close()
         eng, descs = make_engine(1, 1)
         solo = new_stats()
-        step(None)
-        for _ in range(args.kernel_steps):
-            step(solo)
+        run_steps(1, None)
+        run_steps(args.kernel_steps, solo)
         torch.cuda.synchronize()
     if rank == 0:
         pictures = len(descs) * args.steps * world
