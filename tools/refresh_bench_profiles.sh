@@ -1,0 +1,22 @@
+#!/bin/bash
+# Re-runs bench.py for every workload and writes the JSON lines under profiles/ (run on the GPU box from the repository root).
+set -e
+R=${1:-r01}
+run() { # name, args...
+    local name=$1; shift
+    timeout -k 10 600 python3 bench.py "$@" > "profiles/${R}_bench_${name}.json.tmp" 2> "gpurun_out/refresh_${name}.err"
+    tail -1 "profiles/${R}_bench_${name}.json.tmp" > "profiles/${R}_bench_${name}.json"
+    rm "profiles/${R}_bench_${name}.json.tmp"
+    python3 -c "import json,sys; d=json.load(open(sys.argv[1])); print(sys.argv[2], round(d['value']), round(d['roofline']['frac'],3), (d.get('cpu_baseline') or {}).get('value'))" "profiles/${R}_bench_${name}.json" "$name"
+}
+mkdir -p gpurun_out
+run 1080p_ra_m3
+run 1080p_ra_m3_tail1 --device-tail
+run 1080p_ra_m3_tail2 --device-tail-only
+run 1080p_ra_m8 --workload 1080p_ra_m8
+run 720p_ld_m12 --workload 720p_ld_m12
+run 4k_ra_m8 --workload 4k_ra_m8
+run 1080p_tf_l0 --workload 1080p_tf_l0
+run 1080p_tf_l2 --workload 1080p_tf_l2
+run 8k_ra_m2 --workload 8k_ra_m2 --steps 10 --warmup 2 --kernel-steps 2
+mkdir -p gpurun_out/profiles && cp profiles/${R}_bench_*.json gpurun_out/profiles/
