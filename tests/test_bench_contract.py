@@ -1,0 +1,58 @@
+"""The one-line JSON contract of bench.py: checked on the committed runs under profiles/ (CPU) and on a short live run (GPU)."""
+import glob
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+TOP = {"metric": str, "value": float, "unit": str, "n_gpus": int, "steps": int, "warmup": int, "ms_per_step": float,
+       "higher_is_better": bool, "scaling": str, "dtype": str, "data": str, "config": dict, "roofline": dict}
+ROOFLINE = {"bound": str, "achieved": float, "peak": float, "unit": str, "frac": float}
+CPU_BASELINE = {"value": float, "unit": str, "cores": int, "kind": str, "sample": str}
+
+
+def check_line(d, expect_cpu_baseline):
+    for k, t in TOP.items():
+        assert k in d and isinstance(d[k], t), k
+    assert "vs_baseline" in d and d["vs_baseline"] is None  # no published number exists for this metric
+    assert d["metric"] == "open-loop ME pictures/s" and d["unit"] == "pictures/s"
+    assert d["higher_is_better"] is True and d["scaling"] == "weak" and d["dtype"] == "u8" and d["data"] == "synthetic"
+    assert isinstance(d["config"].get("workload"), str) and "model" not in d["config"]
+    assert d["value"] > 0 and d["ms_per_step"] > 0
+    r = d["roofline"]
+    for k, t in ROOFLINE.items():
+        assert k in r and isinstance(r[k], t), k
+    assert "traffic" in r and (r["traffic"] is None or r["traffic"] > 0)
+    assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9 and 0 < r["frac"] < 1
+    if expect_cpu_baseline:
+        c = d["cpu_baseline"]
+        for k, t in CPU_BASELINE.items():
+            assert k in c and isinstance(c[k], t), k
+        assert c["kind"] in ("reference", "port") and c["cores"] >= 1 and c["value"] > 0
+
+
+@pytest.mark.parametrize("path", sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]_bench_*.json"))))
+def test_committed_bench_lines_keep_the_contract(path):
+    with open(path) as f:
+        check_line(json.loads(f.read().strip().splitlines()[-1]), expect_cpu_baseline=True)
+
+
+def test_bench_help_needs_no_gpu():
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--help"], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0 and "--gpus" in r.stdout and "--steps" in r.stdout and "--warmup" in r.stdout
+
+
+@pytest.mark.gpu
+def test_live_bench_line_keeps_the_contract():
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "6", "--warmup", "2", "--kernel-steps", "2",
+                        "--workload", "1080p_ra_m8"], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    d = json.loads(lines[0])
+    check_line(d, expect_cpu_baseline=True)
+    assert d["n_gpus"] == 1 and d["steps"] == 6 and d["warmup"] == 2 and d["config"]["workload"] == "1080p_ra_m8"
