@@ -43,7 +43,9 @@ struct Slot {
     uint8_t   *mem = nullptr; // device
     uint8_t   *host_stage = nullptr; // pinned
     hipEvent_t ready = nullptr; // planes built (recorded on s_store)
-    hipEvent_t last_read[4] = {nullptr, nullptr, nullptr, nullptr}; // last search kernels that read the planes, per search stream
+    // per search stream: the end-of-kernels event of the last picture that read the planes (the event belongs to that
+    // picture's Flight; read_recorded is cleared again once that picture has been waited for)
+    hipEvent_t last_read[4] = {nullptr, nullptr, nullptr, nullptr};
     bool       read_recorded[4] = {false, false, false, false};
     bool       ready_seen[4] = {false, false, false, false}; // this search stream already waits behind `ready`
 };
@@ -88,6 +90,7 @@ struct Flight {
     }
     size_t off_thme = 0, off_tmv = 0, off_tdist = 0, off_tstat = 0, off_tcand = 0, off_ttot = 0, off_tdo = 0, tail_end = 0;
     uint32_t n_ref[2] = {0, 0};
+    unsigned stream_index = 0; // search stream the picture runs on
     bool   tail = false, skip_search_arrays = false;
     // start, after each of the 2 HME and 3 ME kernels, after D2H
     hipEvent_t           ev[7] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
@@ -204,11 +207,7 @@ extern "C" int svtme_create(const svtme_config *cfg, svtme_engine **out) {
     for (auto &s : e->slots) {
         if (hipMalloc((void **)&s.mem, e->slot_bytes) != hipSuccess ||
             hipHostMalloc((void **)&s.host_stage, (size_t)cfg->max_width * cfg->max_height, hipHostMallocDefault) != hipSuccess ||
-            hipEventCreateWithFlags(&s.ready, hipEventDisableTiming) != hipSuccess ||
-            hipEventCreateWithFlags(&s.last_read[0], hipEventDisableTiming) != hipSuccess ||
-            hipEventCreateWithFlags(&s.last_read[1], hipEventDisableTiming) != hipSuccess ||
-            hipEventCreateWithFlags(&s.last_read[2], hipEventDisableTiming) != hipSuccess ||
-            hipEventCreateWithFlags(&s.last_read[3], hipEventDisableTiming) != hipSuccess)
+            hipEventCreateWithFlags(&s.ready, hipEventDisableTiming) != hipSuccess)
             return fail(SVTME_ERR_NO_RESOURCES);
     }
     e->flights.resize(cfg->max_in_flight);
@@ -239,8 +238,6 @@ extern "C" void svtme_destroy(svtme_engine *e) {
         if (s.mem) (void)hipFree(s.mem);
         if (s.host_stage) (void)hipHostFree(s.host_stage);
         if (s.ready) (void)hipEventDestroy(s.ready);
-        for (auto ev : s.last_read)
-            if (ev) (void)hipEventDestroy(ev);
     }
     if (e->d_upload) (void)hipFree(e->d_upload);
     for (auto &f : e->flights) free_flight(f);
@@ -460,11 +457,12 @@ extern "C" int svtme_picture_submit(svtme_engine *e, const svtme_picture *pic, s
         HIP_TRY(hipEventRecord(last_mark, sm));
     }
     HIP_TRY(hipGetLastError());
-    for (int si : used) {
-        HIP_TRY(hipEventRecord(e->slots[si].last_read[mi], sm));
+    for (int si : used) { // ev[5] was recorded behind the picture's last kernel
+        e->slots[si].last_read[mi]     = f->ev[5];
         e->slots[si].read_recorded[mi] = true;
         e->slots[si].readers++;
     }
+    f->stream_index = mi;
     // results back to pinned host memory on the copy stream, so that the next picture's kernels do not wait for PCIe
     // (with three search streams the copy stays on the picture's own stream: the other two keep the GPU busy, and
     // the process stays within four hardware queues)
@@ -505,6 +503,7 @@ extern "C" int svtme_picture_wait(svtme_engine *e, svtme_ticket ticket, svtme_re
         f->waited = true;
         for (int si : f->slots) {
             Slot &s = e->slots[si];
+            if (s.last_read[f->stream_index] == f->ev[5]) s.read_recorded[f->stream_index] = false; // that read is over
             if (--s.readers == 0 && s.release_pending) {
                 s.used = false;
                 s.release_pending = false;
