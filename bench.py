@@ -43,6 +43,9 @@ WORKLOADS = {
     # up to M5 use, level 2 with the 16x16 exit threshold what the fast presets use (EbEncHandle.c:2556-2876).
     "1080p_tf_l0": dict(width=1920, height=1080, enc_mode=0, structure="tf", n_frames=7, bit_depth=8, tf=(0, 0)),
     "1080p_tf_l2": dict(width=1920, height=1080, enc_mode=8, structure="tf", n_frames=7, bit_depth=8, tf=(2, 256)),
+    # first-pass ME of a two-pass encode (ME_FIRST_PASS): every frame searches the previous and the first frame;
+    # fp = (ipp_pass_ctrls.bypass_zz_check, ipp_pass_ctrls.reduce_me_search)
+    "1080p_first_pass": dict(width=1920, height=1080, enc_mode=8, structure="fp", n_frames=17, bit_depth=8, fp=(0, 0)),
 }
 STAGES = ["zz_centre", "prehme", "hme_l0", "hme_l1", "hme_l2", "integer_search"]
 # Packed-SAD peak of gfx950: 256 CUs x 4 SIMDs x 16 lanes/clk (v_sad_u8 / v_qsad_pk_u16_u8 issue at a quarter of the
@@ -57,6 +60,9 @@ def make_pictures(wl, seed):
     if wl["structure"] == "tf":
         c = wl["n_frames"] // 2
         pics = [gop.Picture(poc=c, temporal_layer=0, is_ref=1, refs=[[j], []]) for j in range(wl["n_frames"]) if j != c]
+    elif wl["structure"] == "fp":  # firstpass.c:1166-1186: one list, base layer, used as reference
+        pics = [gop.Picture(poc=i, temporal_layer=0, is_ref=1, refs=[[i - 1] + ([0] if i >= 2 else []), []])
+                for i in range(1, wl["n_frames"])]
     elif wl["structure"] == "ra":
         pics = gop.random_access(wl["n_frames"], wl["enc_mode"])
     else:
@@ -71,7 +77,7 @@ def cpu_baseline(wl, frames, pics, budget_s=20.0):
     from svtme import gop
     threads = max(1, min(16, os.cpu_count() or 1))
     b0, b1, n0, n1 = gop.mrp_counts(wl["enc_mode"])
-    rc = (max(b0, n0), max(b1, n1))
+    rc = (2, 0) if wl.get("fp") else (max(b0, n0), max(b1, n1))
     kind, binary, avx2 = ("reference", refio.REF_BIN, 1) if os.path.exists(refio.REF_BIN) else ("port", refio.ORACLE_BIN, 0)
     sample = pics[:4] if kind == "port" else pics
     with tempfile.TemporaryDirectory(prefix="svtme_bench_") as td:
@@ -79,7 +85,7 @@ def cpu_baseline(wl, frames, pics, budget_s=20.0):
 
         def run(reps):
             refio.write_job(job, frames, sample, wl["enc_mode"], mode=refio.MODE_BENCH, threads=threads, use_avx2=avx2,
-                            reps=reps, ref_counts=rc, tf=wl.get("tf"))
+                            reps=reps, ref_counts=rc, tf=wl.get("tf"), first_pass=wl.get("fp"))
             r = subprocess.run([binary, job, out], capture_output=True, text=True, timeout=600)
             if r.returncode != 0:
                 raise RuntimeError(r.stderr[-500:])
@@ -140,14 +146,18 @@ def main():
     wl = dict(WORKLOADS[args.workload], name=args.workload)
     frames, pics = make_pictures(wl, seed=1000 + rank)
     n, h, w = frames.shape
-    tf = wl.get("tf")
-    ctrl = svtme.derive_tf_controls(tf[0]) if tf else svtme.derive_controls(wl["enc_mode"], w, h)
+    tf, fp = wl.get("tf"), wl.get("fp")
+    ctrl = (svtme.derive_tf_controls(tf[0]) if tf else
+            svtme.derive_first_pass_controls(w, h, reduce_me_search=fp[1]) if fp else svtme.derive_controls(wl["enc_mode"], w, h))
     n_refs = sum(len(p.refs[0]) + len(p.refs[1]) for p in pics)
 
     tail = None
     if tf and (args.device_tail or args.device_tail_only):
         sys.exit("temporal-filter searches have no host tail")
-    if args.device_tail or args.device_tail_only:
+    if fp and (args.device_tail or args.device_tail_only):
+        tail = svtme.Tail(enable=2 if args.device_tail_only else 1, enable_me_8x8=1, enable_me_16x16=1, max_refs=2, max_cand=3,
+                          max_l0=1, input_resolution=svtme.input_resolution(w, h), gm_enabled=0)
+    elif args.device_tail or args.device_tail_only:
         from svtme import gop
         b0, b1, n0, n1 = gop.mrp_counts(wl["enc_mode"])
         l0, l1 = max(b0, n0), max(b1, n1)
@@ -165,7 +175,8 @@ def main():
         for i in range(n):
             e.store_put(i, i, frames[i])  # inputs resident in HBM before the timed region
         return e, [e.make_picture(w, h, p.poc, p.temporal_layer, p.is_ref, p.refs, ctrl, tail=tail,
-                                  tf_me_exit_th=tf[1] if tf else None) for p in pics]
+                                  tf_me_exit_th=tf[1] if tf else None,
+                                  first_pass_bypass_zz=fp[0] if fp else None) for p in pics]
 
     # per-kernel events only where they are needed: with one search stream they are the roofline timings
     eng, descs = make_engine(args.search_streams, 1 if args.search_streams == 1 else 0)
@@ -266,7 +277,8 @@ def main():
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u8", "data": "synthetic",
             "config": {"workload": args.workload, "width": w, "height": h,
-                       "preset": "tf hme_me_level %d, me_exit_th %d" % tf if tf else wl["enc_mode"],
+                       "preset": ("tf hme_me_level %d, me_exit_th %d" % tf if tf else
+                                  "first pass, bypass_zz_check %d, reduce_me_search %d" % fp if fp else wl["enc_mode"]),
                        "pred_structure": wl["structure"], "pictures_per_step": len(descs),
                        "refs_per_picture": round(refs_per_pic, 2), "bit_depth": wl["bit_depth"],
                        "parallelism": "pictures sharded over %d GPU(s), no data-path collective" % world},

@@ -18,5 +18,6 @@ run 720p_ld_m12 --workload 720p_ld_m12
 run 4k_ra_m8 --workload 4k_ra_m8
 run 1080p_tf_l0 --workload 1080p_tf_l0
 run 1080p_tf_l2 --workload 1080p_tf_l2
+run 1080p_first_pass --workload 1080p_first_pass
 run 8k_ra_m2 --workload 8k_ra_m2 --steps 10 --warmup 2 --kernel-steps 2
 mkdir -p gpurun_out/profiles && cp profiles/${R}_bench_*.json gpurun_out/profiles/
