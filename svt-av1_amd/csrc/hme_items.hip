@@ -608,14 +608,15 @@ __device__ u64 strip_search_fs(L12Shared<true> &S, const uint32_t *src, uint32_t
     return best;
 }
 
-// small_search for the shape every preset uses at these levels - 8 x (1..3) positions, full-width block of BWD dwords
-// (8: the 32-pixel quarter-resolution block, 16: the 64-pixel full-resolution block) - with everything unrolled:
-// lane = (position quad 0..5) x (8 chunks of BWD / 4 sampled block rows); window staged in one memory round trip.
-template <int BWD>
+// small_search for the shapes the presets use at these levels - 8 x (1..MAXH) positions (3 rows in the pre-analysis ME, 8 in
+// the first pass), full-width block of BWD dwords (8: the 32-pixel quarter-resolution block, 16: the 64-pixel
+// full-resolution block) - with everything unrolled: lane = (position quad: 2 per row x 4 rows) x (8 chunks of BWD / 4
+// sampled block rows), 4 search rows per trip; window staged in one memory round trip.
+template <int BWD, int MAXH>
 __device__ u64 quick_search(L12Shared<false> &S, const uint32_t *src, uint32_t *win, const DevPlane &ref, int rows, int wx, int wy, int sa_h) {
     constexpr int PD  = BWD + 2; // dwords per staged row: 8 positions + the block width - 1 more pixels, rounded up
     constexpr int RPC = BWD / 4; // sampled block rows per lane (rows <= 8 RPC); RPC x 4 BWD x 255 fits the 16-bit sums
-    constexpr int NB  = ((3 + 2 * (8 * RPC - 1)) * PD + 63) / 64;
+    constexpr int NB  = ((MAXH + 2 * (8 * RPC - 1)) * PD + 63) / 64;
     const int     lane = threadIdx.x;
     const int     n = (sa_h + 2 * (rows - 1)) * PD;
     __syncthreads();
@@ -633,45 +634,50 @@ __device__ u64 quick_search(L12Shared<false> &S, const uint32_t *src, uint32_t *
         for (int k = 0; k < NB; ++k) win[min(lane + 64 * k, n - 1)] = v[k];
     }
     __syncthreads();
-    const int  chunk = lane & 7, q = lane >> 3, xg = q & 1, yl = q >> 1;
-    const bool active = yl < sa_h;
-    u64        a16 = 0;
-    if (active) {
+    const int chunk = lane & 7, q = lane >> 3, xg = q & 1;
+    u64       best = ~0ull;
 #pragma unroll
-        for (int jj = 0; jj < RPC; ++jj) {
-            const int j = chunk * RPC + jj;
-            if (j < rows) {
-                const uint32_t *rr = win + (yl + 2 * j) * PD + xg;
-                const uint32_t *ss = src + j * 16;
-                uint32_t        rv[BWD + 1], sv[BWD];
+    for (int y0 = 0; y0 < MAXH; y0 += 4) {
+        if (y0 >= sa_h) break; // wave-uniform
+        const int  yl     = y0 + (q >> 1);
+        const bool active = yl < sa_h;
+        u64        a16 = 0;
+        if (active) {
 #pragma unroll
-                for (int d = 0; d <= BWD; ++d) rv[d] = rr[d];
+            for (int jj = 0; jj < RPC; ++jj) {
+                const int j = chunk * RPC + jj;
+                if (j < rows) {
+                    const uint32_t *rr = win + (yl + 2 * j) * PD + xg;
+                    const uint32_t *ss = src + j * 16;
+                    uint32_t        rv[BWD + 1], sv[BWD];
 #pragma unroll
-                for (int d = 0; d < BWD; ++d) sv[d] = ss[d];
+                    for (int d = 0; d <= BWD; ++d) rv[d] = rr[d];
 #pragma unroll
-                for (int d = 0; d < BWD; ++d) a16 = __builtin_amdgcn_qsad_pk_u16_u8(((u64)rv[d + 1] << 32) | rv[d], sv[d], a16);
+                    for (int d = 0; d < BWD; ++d) sv[d] = ss[d];
+#pragma unroll
+                    for (int d = 0; d < BWD; ++d) a16 = __builtin_amdgcn_qsad_pk_u16_u8(((u64)rv[d + 1] << 32) | rv[d], sv[d], a16);
+                }
+            }
+        }
+        uint32_t a32[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            a32[i] = (uint32_t)(a16 >> (16 * i)) & 0xFFFFu;
+            a32[i] += quad_xor1(a32[i]);
+            a32[i] += quad_xor2(a32[i]);
+            a32[i] += __shfl_xor(a32[i], 4);
+        }
+        if (active && chunk == 0) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const u64 kk = ((u64)a32[i] << 32) | (uint32_t)(yl * 8 + xg * 4 + i);
+                best         = kk < best ? kk : best;
             }
         }
     }
-    uint32_t a32[4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        a32[i] = (uint32_t)(a16 >> (16 * i)) & 0xFFFFu;
-        a32[i] += quad_xor1(a32[i]);
-        a32[i] += quad_xor2(a32[i]);
-        a32[i] += __shfl_xor(a32[i], 4);
-    }
-    if (active && chunk == 0) {
-        u64 best = ~0ull;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const u64 kk = ((u64)a32[i] << 32) | (uint32_t)(yl * 8 + xg * 4 + i);
-            best         = kk < best ? kk : best;
-        }
-        atomicMin(&S.key, best);
-    }
+    if (best != ~0ull) atomicMin(&S.key, best);
     __syncthreads();
-    const u64 best = S.key;
+    best = S.key;
     __syncthreads();
     return best;
 }
@@ -762,8 +768,11 @@ __global__ void __launch_bounds__(FS ? HI_THREADS_FS : HI_THREADS) hme_l12_kerne
         u64 key;
         if constexpr (!FS) {
             if (block_w == 64 && w == 8 && h >= 1 && h <= 3)
-                key = level == 1 ? quick_search<8>(S, S.src1, win, ref, rows, ox + org_x, oy + org_y, h)
-                                 : quick_search<16>(S, S.src2, win, ref, rows, ox + org_x, oy + org_y, h);
+                key = level == 1 ? quick_search<8, 3>(S, S.src1, win, ref, rows, ox + org_x, oy + org_y, h)
+                                 : quick_search<16, 3>(S, S.src2, win, ref, rows, ox + org_x, oy + org_y, h);
+            else if (block_w == 64 && w == 8 && h >= 4 && h <= 8) // the first pass's 8 x 8 windows
+                key = level == 1 ? quick_search<8, 8>(S, S.src1, win, ref, rows, ox + org_x, oy + org_y, h)
+                                 : quick_search<16, 8>(S, S.src2, win, ref, rows, ox + org_x, oy + org_y, h);
             else
                 key = small_search<FS>(S, level == 1 ? S.src1 : S.src2, win, ref, bw, rows, ox + org_x, oy + org_y, w, h);
         } else {
