@@ -277,6 +277,29 @@ __device__ __forceinline__ u64 l0_search(L0Shared &S, uint32_t *win, const DevPl
     return best;
 }
 
+// Zero-MV SAD of every (b64, reference) for the controls with me_early_exit_th (init_zz_sad :2318-2333, get_zz_sad
+// :1720-1742: the 64x64 block on every other row, x2), once instead of in each of the six level-0 / pre-HME items that
+// test it; also the per-reference header fields. One wave per (b64, reference).
+__global__ void __launch_bounds__(HI_THREADS) hme_zz_kernel(PicParams p) {
+    const int b64 = blockIdx.x;
+    const int b64x = (b64 % p.b64_w) * 64, b64y = (b64 / p.b64_w) * 64;
+    const int block_w = min(p.width - b64x, 64), block_h = min(p.height - b64y, 64);
+    int       l = 0, r = (int)blockIdx.y;
+    if (r >= p.n_ref[0]) {
+        r -= p.n_ref[0];
+        l = 1;
+    }
+    const bool searched = ref_searched(p, l);
+    uint32_t   zz = ~0u;
+    if (searched) zz = wave_block_sad_sub2(p.cur.lvl[2], p.ref[l][r].lvl[2], b64x, b64y, 0, 0, block_w, block_h >> 1) << 1;
+    if (threadIdx.x == 0) {
+        HmeRefOut *out = &p.hme_out[(b64 * SVTME_MAX_LISTS + l) * SVTME_MAX_REFS + r];
+        if (searched) count_ops(p, 0, (unsigned long long)(block_h >> 1) * block_w);
+        out->zz_sad = zz;
+        out->valid  = searched ? 1u : 0u;
+    }
+}
+
 template <bool FS>
 __global__ void __launch_bounds__(HI_THREADS, 3) hme_l0_kernel(PicParams p) {
     __shared__ L0Shared               S;
@@ -302,12 +325,12 @@ __global__ void __launch_bounds__(HI_THREADS, 3) hme_l0_kernel(PicParams p) {
     HmeRefOut *out      = &p.hme_out[(b64 * SVTME_MAX_LISTS + l) * SVTME_MAX_REFS + r];
     const bool header   = sub == 2; // this item also writes the per-reference fields
 
-    // zero-MV SAD (init_zz_sad :2318-2333); stays ~0 (init_me_hme_data :2921) when not computed
+    // zero-MV SAD (init_zz_sad :2318-2333); stays ~0 (init_me_hme_data :2921) when not computed. With the early exit on,
+    // hme_zz_kernel has computed it once for the six items of this (b64, reference) and has written the header fields.
     uint32_t zz = ~0u;
-    if (k.me_early_exit_th && searched)
-        zz = wave_block_sad_sub2(p.cur.lvl[2], p.ref[l][r].lvl[2], b64x, b64y, 0, 0, block_w, block_h >> 1) << 1;
-    if (header && threadIdx.x == 0) {
-        if (k.me_early_exit_th && searched) count_ops(p, 0, (unsigned long long)(block_h >> 1) * block_w);
+    if (k.me_early_exit_th) {
+        if (searched) zz = out->zz_sad;
+    } else if (header && threadIdx.x == 0) {
         out->zz_sad = zz;
         out->valid  = searched ? 1u : 0u;
     }
@@ -800,6 +823,7 @@ void launch_hme_items(const PicParams &p, hipStream_t s, hipEvent_t marks[2]) {
     const dim3 g0(n_b64, 2 + max(n_reg, 1), n_refs), g12((n_b64 + 7) / 8 * 8 * n_refs * n_reg);
     PicParams  q = p;
     const int  n_phase = (p.dep_pre || p.dep_l0) ? 2 : 1;
+    if (p.ctrl.me_early_exit_th) hipLaunchKernelGGL(hme_zz_kernel, dim3(n_b64, n_refs), dim3(HI_THREADS), 0, s, p);
     for (int phase = 1; phase <= n_phase; ++phase) {
         q.hme_phase = n_phase == 1 ? 0 : phase;
         if (fs) hipLaunchKernelGGL(hme_l0_kernel<true>, g0, dim3(HI_THREADS), 0, s, q);
