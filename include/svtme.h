@@ -192,8 +192,10 @@ typedef struct svtme_tail {
 #define SVTME_TAIL_MV_STRIDE 7 /* MAX_PA_ME_MV, EbMotionEstimationLcuResults.h:23 */
 #define SVTME_TAIL_CAND_STRIDE 23 /* MAX_PA_ME_CAND, :24 */
 
-/* MeContext::me_type (EbMotionEstimationContext.h:44-50). */
-#define SVTME_ME_OPEN_LOOP 0 /* ME_OPEN_LOOP: the pre-analysis search of motion_estimation_kernel() */
+/* MeContext::me_type with the values of EbMeType (EbMotionEstimationContext.h:44-50), so that a shim can pass
+ * context->me_type through. 0 (ME_CLOSE_LOOP, which never reaches motion_estimation_b64) is read as SVTME_ME_OPEN_LOOP, so
+ * that a zero-initialised svtme_picture is an open-loop job. */
+#define SVTME_ME_OPEN_LOOP 3 /* ME_OPEN_LOOP: the pre-analysis search of motion_estimation_kernel() */
 #define SVTME_ME_MCTF 1 /* ME_MCTF: the temporal filter's search of one neighbour frame */
 #define SVTME_ME_FIRST_PASS 4 /* ME_FIRST_PASS: the first pass of a two-pass encode (firstpass.c:1237-1300) */
 
@@ -225,7 +227,7 @@ typedef struct svtme_picture {
     uint8_t  is_used_as_reference_flag;
     uint8_t  num_of_list_to_search; /* 1 for P, 2 for B */
     uint8_t  num_of_ref_pic_to_search[SVTME_MAX_LISTS]; /* ref_list{0,1}_count_try */
-    uint8_t  me_type; /* SVTME_ME_OPEN_LOOP, SVTME_ME_MCTF or SVTME_ME_FIRST_PASS */
+    uint8_t  me_type; /* SVTME_ME_OPEN_LOOP (or 0), SVTME_ME_MCTF or SVTME_ME_FIRST_PASS */
     uint8_t  bypass_zz_check; /* SVTME_ME_FIRST_PASS only */
     uint8_t  restricted_motion_vector; /* scs->static_config.restricted_motion_vector: the integer search window stays inside
                                           the tile instead of the padded picture (EbMotionEstimation.c:1405-1430, :1465-1495).
@@ -239,15 +241,19 @@ typedef struct svtme_picture {
     uint32_t       tf_me_exit_th; /* MeContext::tf_me_exit_th = pcs->tf_ctrls.me_exit_th; SVTME_ME_MCTF only */
 } svtme_picture;
 
-/* SearchResults, EbMotionEstimationContext.h:330-337, as left by hme_prune_ref_and_adjust_sr. */
+/* SearchResults, EbMotionEstimationContext.h:330-337, as left by hme_prune_ref_and_adjust_sr: the same six fields at the
+ * same offsets (0, 1, 2, 4, 8, 16) in the same 24 bytes on the LP64 / Win64 ABIs the encoder builds for, so an array of
+ * these can be copied byte for byte into MeContext::search_results[2][4] (:399). The engine's one extra field lives in
+ * the reference struct's tail padding, which nothing in the encoder reads. */
 typedef struct svtme_search_result {
-    int16_t  hme_sc_x;
-    int16_t  hme_sc_y;
-    uint8_t  do_ref;
     uint8_t  list_i;
     uint8_t  ref_i;
-    uint8_t  tf_me_exit; /* SVTME_ME_MCTF, entry [0][0] only: 1 = the block left at the tf_me_exit_th test */
+    int16_t  hme_sc_x;
+    int16_t  hme_sc_y;
     uint64_t hme_sad;
+    uint8_t  do_ref;
+    uint8_t  tf_me_exit; /* SVTME_ME_MCTF, entry [0][0] only: 1 = the block left at the tf_me_exit_th test */
+    uint8_t  reserved[6];
 } svtme_search_result;
 
 /* Per-b64 outputs. Pointers are engine-owned pinned host memory, valid until svtme_picture_done().

@@ -15,9 +15,14 @@
  * (Source/Lib/Encoder/Codec/EbMotionEstimationProcess.c:698-846): signal derivation, pointing MeContext at
  * the source block and at the reference planes, then motion_estimation_b64 per 64x64 block.
  *
- * Usage: ref_me <job file> <output file>
+ * Mode REF_MODE_SHIM is the reference-side binding of the GPU engine (include/svtme.h) end to end: the engine's results
+ * are unpacked into a real MeContext per 64x64 block and the reference's own host tail runs on them (run_pic_shim).
+ *
+ * Usage: ref_me <job file> <output file> [libsvtme.so, REF_MODE_SHIM only]
  */
+#include <dlfcn.h>
 #include <pthread.h>
+#include <stddef.h>
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
@@ -48,6 +53,14 @@ uint8_t get_enable_me_16x16(EbEncMode enc_mode);
 EbErrorType tf_signal_derivation_me_kernel_oq(PictureParentControlSet *pcs_ptr, MotionEstimationContext_t *context_ptr);
 EbErrorType first_pass_signal_derivation_me_kernel(SequenceControlSet *scs_ptr, PictureParentControlSet *pcs_ptr,
                                                    MotionEstimationContext_t *context_ptr);
+/* the host tail of motion_estimation_b64 (EbMotionEstimation.c:1576, :2430, :2544, :2688, :2814) */
+void me_prune_ref(MeContext *context_ptr);
+void construct_me_candidate_array_mrp_off(PictureParentControlSet *pcs_ptr, MeContext *context_ptr,
+                                          uint32_t num_of_list_to_search, uint32_t sb_index);
+void construct_me_candidate_array(PictureParentControlSet *pcs_ptr, MeContext *context_ptr,
+                                  uint32_t num_of_list_to_search, uint32_t sb_index);
+void perform_gm_detection(PictureParentControlSet *pcs_ptr, uint32_t sb_index, MeContext *context_ptr);
+void compute_distortion(PictureParentControlSet *pcs_ptr, uint32_t sb_index, MeContext *context_ptr);
 void    get_max_allocated_me_refs(uint8_t ref_count_used_list0, uint8_t ref_count_used_list1,
                                   uint8_t *max_ref_to_alloc, uint8_t *max_cand_to_alloc);
 
@@ -462,6 +475,188 @@ static void *worker_main(void *arg) {
     return NULL;
 }
 
+/* ---------------------------------------------------------------------------------------------------------------
+ * REF_MODE_SHIM: what the patch to motion_estimation_kernel() does (EbMotionEstimationProcess.c:750-846 with the call at
+ * :841 replaced): per picture store_put / submit / wait through the engine's C ABI, per 64x64 block svtme_unpack_b64
+ * straight into the thread's MeContext, then the rest of motion_estimation_b64 (EbMotionEstimation.c:2972-3000) with the
+ * reference's own functions. The library is loaded at run time so that the other modes need no GPU runtime. */
+
+/* svtme_search_result is copied byte for byte into MeContext::search_results */
+_Static_assert(sizeof(svtme_search_result) == sizeof(SearchResults), "svtme_search_result / SearchResults size");
+_Static_assert(offsetof(svtme_search_result, list_i) == offsetof(SearchResults, list_i), "list_i");
+_Static_assert(offsetof(svtme_search_result, ref_i) == offsetof(SearchResults, ref_i), "ref_i");
+_Static_assert(offsetof(svtme_search_result, hme_sc_x) == offsetof(SearchResults, hme_sc_x), "hme_sc_x");
+_Static_assert(offsetof(svtme_search_result, hme_sc_y) == offsetof(SearchResults, hme_sc_y), "hme_sc_y");
+_Static_assert(offsetof(svtme_search_result, hme_sad) == offsetof(SearchResults, hme_sad), "hme_sad");
+_Static_assert(offsetof(svtme_search_result, do_ref) == offsetof(SearchResults, do_ref), "do_ref");
+_Static_assert(sizeof(((MeContext *)0)->search_results) == SVTME_MAX_LISTS * SVTME_MAX_REFS * sizeof(svtme_search_result),
+               "MeContext::search_results shape");
+_Static_assert(sizeof(((MeContext *)0)->p_sb_best_sad) == SVTME_MAX_LISTS * SVTME_MAX_REFS * SVTME_PU_COUNT * 4,
+               "MeContext::p_sb_best_sad shape");
+_Static_assert(sizeof(((MeContext *)0)->p_sb_best_mv) == SVTME_MAX_LISTS * SVTME_MAX_REFS * SVTME_PU_COUNT * 4,
+               "MeContext::p_sb_best_mv shape");
+_Static_assert(sizeof(((MeContext *)0)->zz_sad) == SVTME_MAX_LISTS * SVTME_MAX_REFS * 4, "MeContext::zz_sad shape");
+_Static_assert(sizeof(((MeContext *)0)->reduce_me_sr_divisor) == SVTME_MAX_LISTS * SVTME_MAX_REFS * 4,
+               "MeContext::reduce_me_sr_divisor shape");
+
+typedef struct Shim {
+    void         *dl;
+    svtme_engine *engine;
+    int (*create)(const svtme_config *, svtme_engine **);
+    void (*destroy)(svtme_engine *);
+    int (*store_put)(svtme_engine *, uint64_t, uint64_t, const uint8_t *, uint32_t, uint32_t, uint32_t);
+    int (*submit)(svtme_engine *, const svtme_picture *, svtme_ticket *);
+    int (*wait)(svtme_engine *, svtme_ticket, svtme_results *);
+    int (*done)(svtme_engine *, svtme_ticket);
+    int (*unpack)(const svtme_results *, uint32_t, uint32_t *, uint32_t *, svtme_search_result *, uint32_t *, uint32_t *);
+} Shim;
+
+static void *shim_sym(Shim *s, const char *name) {
+    void *f = dlsym(s->dl, name);
+    if (!f) {
+        fprintf(stderr, "ref_me: %s: %s\n", name, dlerror());
+        exit(2);
+    }
+    return f;
+}
+
+static void shim_open(Shim *s, const char *lib, const Job *job) {
+    memset(s, 0, sizeof(*s));
+    s->dl = dlopen(lib, RTLD_NOW | RTLD_LOCAL);
+    if (!s->dl) {
+        fprintf(stderr, "ref_me: cannot load %s: %s\n", lib, dlerror());
+        exit(2);
+    }
+    *(void **)&s->create    = shim_sym(s, "svtme_create");
+    *(void **)&s->destroy   = shim_sym(s, "svtme_destroy");
+    *(void **)&s->store_put = shim_sym(s, "svtme_store_put");
+    *(void **)&s->submit    = shim_sym(s, "svtme_picture_submit");
+    *(void **)&s->wait      = shim_sym(s, "svtme_picture_wait");
+    *(void **)&s->done      = shim_sym(s, "svtme_picture_done");
+    *(void **)&s->unpack    = shim_sym(s, "svtme_unpack_b64");
+    svtme_config cfg;
+    memset(&cfg, 0, sizeof(cfg));
+    cfg.max_width     = job->hdr.width;
+    cfg.max_height    = job->hdr.height;
+    cfg.store_slots   = job->hdr.n_frames + 1;
+    cfg.max_in_flight = 2;
+    if (s->create(&cfg, &s->engine) != SVTME_OK) die("svtme_create failed");
+    /* the device picture store: one put per source picture, keyed like the EbPaReferenceObject it mirrors */
+    for (uint32_t i = 0; i < job->hdr.n_frames; ++i)
+        if (s->store_put(s->engine, (uint64_t)(uintptr_t)&job->planes[i], i, job->frames + (size_t)job->hdr.width * job->hdr.height * i,
+                         job->hdr.width, job->hdr.width, job->hdr.height) != SVTME_OK)
+            die("svtme_store_put failed");
+}
+
+static void run_pic_shim(Shim *s, const Job *job, uint32_t pi, PicState *st) {
+    const ref_job_pic        *jp  = &job->pics[pi];
+    PictureParentControlSet  *pcs = st->pcs;
+    SequenceControlSet       *scs = st->scs;
+    MotionEstimationContext_t mectx;
+    memset(&mectx, 0, sizeof(mectx));
+    MeContext *m = (MeContext *)calloc(1, sizeof(MeContext));
+    if (!m) die("out of memory");
+    me_context_ctor(m);
+    mectx.me_context_ptr = m;
+    if (jp->me_type == ME_MCTF) {
+        m->me_type = ME_MCTF;
+        tf_signal_derivation_me_kernel_oq(pcs, &mectx);
+        m->hme_search_method = FULL_SAD_SEARCH;
+    } else if (jp->me_type == ME_FIRST_PASS) {
+        m->me_type = ME_FIRST_PASS;
+        first_pass_signal_derivation_me_kernel(scs, pcs, &mectx);
+    } else {
+        m->me_type = ME_OPEN_LOOP;
+        signal_derivation_me_kernel_oq(scs, pcs, &mectx);
+    }
+    /* ---- once per picture: the job description from the pcs and from the controls the reference just derived */
+    svtme_picture d;
+    memset(&d, 0, sizeof(d));
+    d.cur_key        = (uint64_t)(uintptr_t)&job->planes[jp->cur_frame];
+    d.picture_number = pcs->picture_number;
+    d.width          = pcs->aligned_width;
+    d.height         = pcs->aligned_height;
+    d.temporal_layer_index      = pcs->temporal_layer_index;
+    d.is_used_as_reference_flag = pcs->is_used_as_reference_flag;
+    d.num_of_list_to_search       = jp->n_list;
+    d.num_of_ref_pic_to_search[0] = jp->n_ref[0];
+    d.num_of_ref_pic_to_search[1] = jp->n_list == 2 ? jp->n_ref[1] : 0;
+    d.me_type = (uint8_t)m->me_type;
+    d.bypass_zz_check          = m->me_type == ME_FIRST_PASS ? scs->ipp_pass_ctrls.bypass_zz_check : 0;
+    d.restricted_motion_vector = scs->static_config.restricted_motion_vector;
+    d.tf_me_exit_th            = m->me_type == ME_MCTF ? jp->tf_me_exit_th : 0;
+    for (int l = 0; l < jp->n_list; ++l)
+        for (int r = 0; r < jp->n_ref[l]; ++r) {
+            d.ref_key[l][r]            = (uint64_t)(uintptr_t)&job->planes[jp->ref_frame[l][r]];
+            d.ref_picture_number[l][r] = jp->ref_poc[l][r];
+        }
+    fill_controls(&d.ctrl, m);
+    svtme_ticket  ticket;
+    svtme_results res;
+    if (s->submit(s->engine, &d, &ticket) != SVTME_OK) die("svtme_picture_submit failed");
+    if (s->wait(s->engine, ticket, &res) != SVTME_OK) die("svtme_picture_wait failed");
+
+    ref_pic_dump *pd = (ref_pic_dump *)st->out;
+    pd->ctrl            = d.ctrl;
+    pd->enable_me_8x8   = pcs->enable_me_8x8;
+    pd->enable_me_16x16 = pcs->enable_me_16x16;
+    pd->max_cand = pcs->pa_me_data->max_cand;
+    pd->max_refs = pcs->pa_me_data->max_refs;
+    pd->max_l0   = pcs->pa_me_data->max_l0;
+    pd->input_resolution = (uint8_t)scs->input_resolution;
+    pd->n_b64 = st->n_b64;
+
+    /* ---- per 64x64 block, where motion_estimation_kernel calls motion_estimation_b64 */
+    Planes *cur = &job->planes[jp->cur_frame];
+    for (uint32_t b64 = 0; b64 < st->n_b64; ++b64) {
+        const uint32_t ox = (b64 % st->b64_w) * 64, oy = (b64 / st->b64_w) * 64;
+        m->me_type = (EbMeType)d.me_type;
+        m->tf_me_exit_th             = jp->tf_me_exit_th;
+        m->tf_use_pred_64x64_only_th = 0;
+        m->num_of_list_to_search       = jp->n_list;
+        m->num_of_ref_pic_to_search[0] = jp->n_ref[0];
+        if (jp->n_list == 2) m->num_of_ref_pic_to_search[1] = jp->n_ref[1];
+        m->temporal_layer_index      = jp->temporal_layer;
+        m->is_used_as_reference_flag = jp->is_ref;
+        for (int l = 0; l < jp->n_list; ++l)
+            for (int r = 0; r < jp->n_ref[l]; ++r) {
+                Planes *rp = &job->planes[jp->ref_frame[l][r]];
+                m->me_ds_ref_array[l][r].picture_ptr           = &rp->full;
+                m->me_ds_ref_array[l][r].quarter_picture_ptr   = &rp->quarter;
+                m->me_ds_ref_array[l][r].sixteenth_picture_ptr = &rp->sixteenth;
+                m->me_ds_ref_array[l][r].picture_number        = jp->ref_poc[l][r];
+            }
+        m->block_width  = (cur->full.width - ox) < BLOCK_SIZE_64 ? cur->full.width - ox : BLOCK_SIZE_64; /* :2944-2949 */
+        m->block_height = (cur->full.height - oy) < BLOCK_SIZE_64 ? cur->full.height - oy : BLOCK_SIZE_64;
+        /* in place of init_me_hme_data, hme_b64, hme_prune_ref_and_adjust_sr and integer_search_b64 (:2954-2970) */
+        if (s->unpack(&res, b64, &m->p_sb_best_sad[0][0][0], &m->p_sb_best_mv[0][0][0],
+                      (svtme_search_result *)&m->search_results[0][0], &m->zz_sad[0][0],
+                      &m->reduce_me_sr_divisor[0][0]) != SVTME_OK)
+            die("svtme_unpack_b64 failed");
+        const uint8_t prune_ref = m->enable_hme_flag && m->me_type != ME_MCTF;
+        if (m->me_type == ME_MCTF && ((const svtme_search_result *)&m->search_results[0][0])->tf_me_exit) {
+            m->tf_use_pred_64x64_only_th = (uint8_t)~0; /* :2958-2962 */
+        } else {
+            /* the rest of motion_estimation_b64, :2972-3000 */
+            if (prune_ref && m->me_hme_prune_ctrls.enable_me_hme_ref_pruning) me_prune_ref(m);
+            if (m->me_type != ME_MCTF) {
+                if (m->num_of_ref_pic_to_search[REF_LIST_0] == 1 && m->num_of_ref_pic_to_search[REF_LIST_1] == 1)
+                    construct_me_candidate_array_mrp_off(pcs, m, m->num_of_list_to_search, b64);
+                else
+                    construct_me_candidate_array(pcs, m, m->num_of_list_to_search, b64);
+                if (m->me_type != ME_FIRST_PASS) compute_distortion(pcs, b64, m);
+                pcs->stationary_block_present_sb[b64] = 0;
+                pcs->rc_me_allow_gm[b64]              = 0;
+                if (pcs->gm_ctrls.enabled) perform_gm_detection(pcs, b64, m);
+            }
+        }
+        dump_b64((ref_b64_dump *)(st->out + sizeof(ref_pic_dump)) + b64, m, st, b64);
+    }
+    if (s->done(s->engine, ticket) != SVTME_OK) die("svtme_picture_done failed");
+    free(m->p_eight_pos_sad16x16);
+    free(m);
+}
+
 static double now_s(void) {
     struct timespec ts;
     clock_gettime(CLOCK_MONOTONIC, &ts);
@@ -543,6 +738,20 @@ int main(int argc, char **argv) {
                 fwrite(d[k]->buffer_y, 1, d[k]->luma_size, o);
             }
         }
+    } else if (job.hdr.mode == REF_MODE_SHIM) {
+        if (argc < 4) die("REF_MODE_SHIM needs the path of libsvtme.so as third argument");
+        Shim shim;
+        shim_open(&shim, argv[3], &job);
+        fwrite(&oh, sizeof(oh), 1, o);
+        for (uint32_t pi = 0; pi < job.hdr.n_pics; ++pi) {
+            PicState st;
+            memset(&st, 0, sizeof(st));
+            setup_pic(&job, pi, &st);
+            run_pic_shim(&shim, &job, pi, &st);
+            fwrite(st.out, 1, sizeof(ref_pic_dump) + (size_t)st.n_b64 * sizeof(ref_b64_dump), o);
+            free_pic(&st);
+        }
+        shim.destroy(shim.engine);
     } else if (job.hdr.mode == REF_MODE_DUMP) {
         fwrite(&oh, sizeof(oh), 1, o);
         for (uint32_t pi = 0; pi < job.hdr.n_pics; ++pi) {

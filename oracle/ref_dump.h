@@ -16,6 +16,9 @@
 #define REF_MODE_DUMP_NOTAIL 3 /* restatement only: state right after integer_search_b64 (what the GPU engine hands over) */
 #define REF_MODE_TAIL 4 /* restatement only: the host tail (me_prune_ref .. perform_gm_detection) run on handed-over
                            search results: a third argument names a file of n_pics * n_b64 ref_b64_dump records */
+#define REF_MODE_SHIM 5 /* ref_me only: the reference-side binding end to end. The searches run on the GPU engine through
+                           its C ABI (a third argument names libsvtme.so), every block's results are unpacked into a real
+                           MeContext, and the reference's own me_prune_ref .. perform_gm_detection run on it */
 #define REF_DUMP_MAX_REFS 7 /* MAX_PA_ME_MV, EbMotionEstimationLcuResults.h:23 */
 #define REF_DUMP_MAX_CAND 23 /* MAX_PA_ME_CAND, :24 */
 

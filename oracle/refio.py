@@ -12,7 +12,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 REF_BIN = os.path.join(HERE, "_ref", "ref_me")
 ORACLE_BIN = os.path.join(HERE, "build", "oracle_me")
 
-MODE_DUMP, MODE_BENCH, MODE_PLANES, MODE_DUMP_NOTAIL, MODE_TAIL = 0, 1, 2, 3, 4
+MODE_DUMP, MODE_BENCH, MODE_PLANES, MODE_DUMP_NOTAIL, MODE_TAIL, MODE_SHIM = 0, 1, 2, 3, 4, 5
 
 SA = np.dtype([("width", "<u2"), ("height", "<u2")])
 SAMM = np.dtype([("sa_min", SA), ("sa_max", SA)])
@@ -94,7 +94,7 @@ def read_dump(path):
     assert magic == b"SVTMEO01", magic
     hdr = dict(n_pics=n_pics, n_b64=n_b64, used_avx2=avx2, mode=mode, bench_seconds=secs, bench_pictures=npic)
     out = []
-    if mode in (MODE_DUMP, MODE_DUMP_NOTAIL, MODE_TAIL):
+    if mode in (MODE_DUMP, MODE_DUMP_NOTAIL, MODE_TAIL, MODE_SHIM):
         assert pds == PIC_DUMP.itemsize and bds == B64_DUMP.itemsize, (pds, PIC_DUMP.itemsize, bds, B64_DUMP.itemsize)
         off = hs
         for _ in range(n_pics):
@@ -117,13 +117,13 @@ def read_dump(path):
     return hdr, out
 
 
-def run_binary(binary, frames, pics, enc_mode, **kw):
+def run_binary(binary, frames, pics, enc_mode, extra_args=(), **kw):
     if not os.path.exists(binary):
         raise FileNotFoundError(binary)
     with tempfile.TemporaryDirectory(prefix="svtme_") as td:
         job, out = os.path.join(td, "job.bin"), os.path.join(td, "out.bin")
         write_job(job, frames, pics, enc_mode, **kw)
-        r = subprocess.run([binary, job, out], capture_output=True, text=True)
+        r = subprocess.run([binary, job, out, *extra_args], capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError("%s failed (%d): %s" % (binary, r.returncode, r.stderr[-2000:]))
         hdr, recs = read_dump(out)
@@ -149,6 +149,13 @@ def run_oracle_tail(frames, pics, enc_mode, handover, **kw):
 
 def run_reference(frames, pics, enc_mode, **kw):
     return run_binary(REF_BIN, frames, pics, enc_mode, **kw)
+
+
+def run_reference_shim(frames, pics, enc_mode, library, **kw):
+    """The reference-side binding end to end (ref_me's REF_MODE_SHIM): the searches run on the GPU engine in `library`
+    (libsvtme.so) through its C ABI, each block's results are unpacked into a real MeContext and the reference's own
+    me_prune_ref .. perform_gm_detection finish the block. Returns what run_reference returns."""
+    return run_binary(REF_BIN, frames, pics, enc_mode, extra_args=(library,), mode=MODE_SHIM, **kw)
 
 
 def run_oracle(frames, pics, enc_mode, **kw):

@@ -329,7 +329,8 @@ extern "C" int svtme_picture_submit(svtme_engine *e, const svtme_picture *pic, s
         return SVTME_ERR_BAD_ARG;
     // not implemented on the device: full-SAD integer search (nothing in the encoder selects it)
     if (k.me_search_method != 0) return SVTME_ERR_UNSUPPORTED;
-    if (pic->tail.enable > 2 || (pic->me_type != SVTME_ME_OPEN_LOOP && pic->me_type != SVTME_ME_MCTF && pic->me_type != SVTME_ME_FIRST_PASS) ||
+    if (pic->tail.enable > 2 ||
+        (pic->me_type != 0 && pic->me_type != SVTME_ME_OPEN_LOOP && pic->me_type != SVTME_ME_MCTF && pic->me_type != SVTME_ME_FIRST_PASS) ||
         pic->bypass_zz_check > 1 || pic->restricted_motion_vector > 1)
         return SVTME_ERR_BAD_ARG;
     // the temporal filter searches one neighbour frame at a time and has no host tail (EbTemporalFiltering.c:4844-4847,
@@ -385,7 +386,7 @@ extern "C" int svtme_picture_submit(svtme_engine *e, const svtme_picture *pic, s
     p.b64_h  = (int32_t)((pic->height + 63) / 64);
     p.temporal_layer = pic->temporal_layer_index;
     p.is_ref = pic->is_used_as_reference_flag;
-    p.me_type       = pic->me_type;
+    p.me_type       = pic->me_type ? pic->me_type : SVTME_ME_OPEN_LOOP;
     p.bypass_zz_check = pic->me_type == SVTME_ME_FIRST_PASS && pic->bypass_zz_check;
     p.restricted      = pic->restricted_motion_vector;
     p.tf_me_exit_th = pic->tf_me_exit_th;

@@ -174,15 +174,19 @@ __global__ void __launch_bounds__(ME_THREADS) me_plan_kernel(PicParams p) {
     // the workgroup of the first reference publishes the per-b64 tables
     if (my_idx == 0 && tid < 8) {
         const int            l = tid >> 2, r = tid & 3;
-        svtme_search_result &o = p.search_results[b64 * 8 + tid];
-        o.hme_sc_x = S.sc_x[tid];
-        o.hme_sc_y = S.sc_y[tid];
-        o.do_ref   = S.do_ref[tid];
-        o.list_i   = (uint8_t)l;
-        o.ref_i    = (uint8_t)r;
+        // one SearchResults record (EbMotionEstimationContext.h:330-337) as three whole 8-byte words, so that the padding
+        // bytes of the record are defined (zero) as well
+        static_assert(sizeof(svtme_search_result) == 24 && offsetof(svtme_search_result, list_i) == 0 &&
+                          offsetof(svtme_search_result, ref_i) == 1 && offsetof(svtme_search_result, hme_sc_x) == 2 &&
+                          offsetof(svtme_search_result, hme_sc_y) == 4 && offsetof(svtme_search_result, hme_sad) == 8 &&
+                          offsetof(svtme_search_result, do_ref) == 16 && offsetof(svtme_search_result, tf_me_exit) == 17,
+                      "svtme_search_result must keep the layout of the encoder's SearchResults");
         // temporal filter: a block that is already well predicted is not searched (:2958-2962)
-        o.tf_me_exit = p.me_type == SVTME_ME_MCTF && tid == 0 && S.hsad[0] < p.tf_me_exit_th;
-        o.hme_sad  = S.hsad[tid];
+        const u64 tf_me_exit = p.me_type == SVTME_ME_MCTF && tid == 0 && S.hsad[0] < p.tf_me_exit_th;
+        u64      *o = reinterpret_cast<u64 *>(&p.search_results[b64 * 8 + tid]);
+        o[0] = (u64)l | ((u64)r << 8) | ((u64)(uint16_t)S.sc_x[tid] << 16) | ((u64)(uint16_t)S.sc_y[tid] << 32);
+        o[1] = S.hsad[tid];
+        o[2] = (u64)S.do_ref[tid] | (tf_me_exit << 8);
         p.sr_divisor[b64 * 8 + tid] = S.div[tid];
         const bool have = l < p.n_list && r < p.n_ref[l];
         p.zz_sad[b64 * 8 + tid] = have ? hme[tid].zz_sad : ~0u;

@@ -83,17 +83,22 @@ class Picture(C.Structure):
     ]
 
 
-ME_OPEN_LOOP, ME_MCTF, ME_FIRST_PASS = 0, 1, 4
+ME_OPEN_LOOP, ME_MCTF, ME_FIRST_PASS = 3, 1, 4  # EbMeType; 0 also reads as open loop
 
 
 class SearchResult(C.Structure):
-    _fields_ = [("hme_sc_x", C.c_int16), ("hme_sc_y", C.c_int16), ("do_ref", C.c_uint8), ("list_i", C.c_uint8),
-                ("ref_i", C.c_uint8), ("tf_me_exit", C.c_uint8), ("hme_sad", C.c_uint64)]
+    """Field for field the reference's SearchResults (EbMotionEstimationContext.h:330-337), 24 bytes; tf_me_exit sits in
+    that struct's tail padding."""
+    _fields_ = [("list_i", C.c_uint8), ("ref_i", C.c_uint8), ("hme_sc_x", C.c_int16), ("hme_sc_y", C.c_int16),
+                ("hme_sad", C.c_uint64), ("do_ref", C.c_uint8), ("tf_me_exit", C.c_uint8), ("reserved", C.c_uint8 * 6)]
 
 
-SEARCH_RESULT_DTYPE = np.dtype([("hme_sc_x", "<i2"), ("hme_sc_y", "<i2"), ("do_ref", "u1"), ("list_i", "u1"),
-                                ("ref_i", "u1"), ("tf_me_exit", "u1"), ("hme_sad", "<u8")])
-assert SEARCH_RESULT_DTYPE.itemsize == C.sizeof(SearchResult) == 16
+SEARCH_RESULT_DTYPE = np.dtype({"names": ["list_i", "ref_i", "hme_sc_x", "hme_sc_y", "hme_sad", "do_ref", "tf_me_exit"],
+                                "formats": ["u1", "u1", "<i2", "<i2", "<u8", "u1", "u1"],
+                                "offsets": [0, 1, 2, 4, 8, 16, 17], "itemsize": 24})
+SEARCH_RESULT_FIELDS = np.dtype([(f, SEARCH_RESULT_DTYPE.fields[f][0]) for f in SEARCH_RESULT_DTYPE.names])
+assert SEARCH_RESULT_DTYPE.itemsize == C.sizeof(SearchResult) == 24
+assert [getattr(SearchResult, f).offset for f in SEARCH_RESULT_DTYPE.names] == [0, 1, 2, 4, 8, 16, 17]
 
 
 class Results(C.Structure):
@@ -280,7 +285,10 @@ class Engine:
             "zz_sad": np.ctypeslib.as_array(r.zz_sad, (n, 2, 4)),
             "sr_divisor": np.ctypeslib.as_array(r.reduce_me_sr_divisor, (n, 2, 4)),
         })
-        sr = np.frombuffer(C.string_at(r.search_results, n * 8 * 16), SEARCH_RESULT_DTYPE).reshape(n, 2, 4)
+        raw = np.frombuffer(C.string_at(r.search_results, n * 8 * C.sizeof(SearchResult)), SEARCH_RESULT_DTYPE).reshape(n, 2, 4)
+        sr = np.zeros(raw.shape, SEARCH_RESULT_FIELDS)  # the named fields only, without the C struct's padding bytes
+        for f in SEARCH_RESULT_FIELDS.names:
+            sr[f] = raw[f]
         out["search_results"] = sr
         if r.me_mv_array:  # the picture ran the host tail on the device
             out["total_me_candidate_index"] = np.ctypeslib.as_array(r.total_me_candidate_index, (n, 85))

@@ -29,7 +29,7 @@ def test_library_exports_every_declared_symbol():
 
 def test_struct_sizes_match_the_header():
     assert C.sizeof(svtme.Controls) == 84 == refio.CONTROLS.itemsize
-    assert C.sizeof(svtme.SearchResult) == 16
+    assert C.sizeof(svtme.SearchResult) == 24
     assert C.sizeof(svtme.Tail) == 16
     # keys/poc/geometry, ref keys, ref pocs, controls, device-tail parameters, tf_me_exit_th
     assert C.sizeof(svtme.Picture) == 32 + 64 + 64 + 84 + 16 + 4  # tf_me_exit_th closes the struct
