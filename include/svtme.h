@@ -294,6 +294,29 @@ int svtme_picture_wait(svtme_engine *e, svtme_ticket ticket, svtme_results *out)
 /* Returns the result buffers of a waited picture to the engine. */
 int svtme_picture_done(svtme_engine *e, svtme_ticket ticket);
 
+/*
+ * svtme_picture_submit + svtme_picture_wait in one synchronous call that allocates nothing. It has no counterpart in the
+ * reference; it is for callers that cannot allocate device memory while they run: code under HIP graph capture, tight
+ * serving loops, harnesses that forbid hipMalloc. Same kernels and same results as svtme_picture_submit, but
+ *  - the kernels' intermediates (HME records, search windows, running minima, counters) live in a file-scope device array
+ *    of the library, 13.1 MiB, which every GPU the library runs on holds until the process ends, instead of the buffers
+ *    svtme_create allocated per picture in flight;
+ *  - the results go into `result_block`, memory the caller owns and the device can write: device memory or pinned host
+ *    memory, 64-byte aligned, at least SVTME_STATIC_RESULT_BYTES(n_b64, references of the picture) bytes; `out` receives
+ *    pointers into it (the five arrays of a picture without device tail, laid out as svtme_picture_wait returns them);
+ *  - the picture's source planes are store slots as usual (svtme_store_put before the call; it allocates nothing either).
+ * Limits: at most SVTME_STATIC_MAX_B64 64x64 blocks (3840x2160; larger pictures get SVTME_ERR_BAD_ARG and a message on
+ * stderr), tail.enable = 0 and serial_hme = 0 (SVTME_ERR_UNSUPPORTED otherwise). The call returns when the results are in
+ * `result_block`. All calls on one GPU share that GPU's array: within a process they take turns (a lock), calls from
+ * different processes each have their own copy; the call clears what has to start from zero, whatever the last call left.
+ * No hipMalloc / hipFree / hipHostMalloc, stream or event creation happens inside.
+ */
+#define SVTME_STATIC_MAX_B64 2040
+#define SVTME_STATIC_RESULT_BYTES(n_b64, n_refs) \
+    ((size_t)(n_b64) * 256 + 4096 + (size_t)(n_refs) * (size_t)(n_b64) * SVTME_PU_COUNT * 8)
+int svtme_picture_search_static(svtme_engine *e, const svtme_picture *pic, void *result_block, size_t result_bytes,
+                                svtme_results *out);
+
 /* Device time of a waited picture's kernels in milliseconds (HIP events on the stream the kernels run on):
  * [0] HME pre-HME + level-0 kernel (or the serial HME kernel), [1] HME level-1/2 kernel, [2] integer-search plan,
  * [3] integer-search kernel, [4] integer-search finish, [5] first kernel start to last kernel end,

@@ -98,7 +98,41 @@ struct Flight {
 
 } // namespace
 
+// ---- scratch of svtme_picture_search_static(): the search kernels' intermediates (HME records, operation counters,
+// integer-search windows, running minima) for one picture of at most SVTME_STATIC_MAX_B64 blocks, in device memory that
+// belongs to the loaded library instead of an allocation. Every GPU the library runs on holds its own copy until the
+// process ends. In host code the array's name is only a handle for hipGetSymbolAddress: the device address is taken once
+// per device (static_scratch_of) and that pointer is what kernels, memsets and copies get.
+constexpr size_t kStaticHmeBytes  = (size_t)SVTME_STATIC_MAX_B64 * SVTME_MAX_LISTS * SVTME_MAX_REFS * sizeof(HmeRefOut);
+constexpr size_t kStaticOpsOff    = (kStaticHmeBytes + 255) / 256 * 256;
+constexpr size_t kStaticJobsOff   = kStaticOpsOff + SVTME_OPS_BYTES;
+constexpr size_t kStaticKeysOff   = (kStaticJobsOff + (size_t)SVTME_STATIC_MAX_B64 * SVTME_MAX_LISTS * SVTME_MAX_REFS * sizeof(MeJob) + 255) / 256 * 256;
+constexpr size_t kStaticBytes     = kStaticKeysOff + (size_t)SVTME_STATIC_MAX_B64 * SVTME_MAX_LISTS * SVTME_MAX_REFS * SVTME_PU_COUNT * sizeof(unsigned long long);
+static_assert(kStaticBytes <= 14u << 20, "the static scratch is meant to stay modest (13.1 MiB for 3840x2160)");
+static __device__ __align__(256) unsigned char scratch[kStaticBytes];
+
+constexpr int      kMaxDevices = 64;
+static std::mutex  g_static_mu; // guards g_static_ptr and orders the calls that share a device's scratch within this process
+static uint8_t    *g_static_ptr[kMaxDevices];
+
+// Device address of this device's copy of `scratch`; the device must be current. Resolved once per device.
+static uint8_t *static_scratch_of(int device) {
+    if (device < 0 || device >= kMaxDevices) return nullptr;
+    std::lock_guard<std::mutex> lock(g_static_mu);
+    if (!g_static_ptr[device]) {
+        void      *ptr = nullptr;
+        hipError_t err = hipGetSymbolAddress(&ptr, HIP_SYMBOL(scratch));
+        if (err != hipSuccess || !ptr) {
+            fprintf(stderr, "svtme: hipGetSymbolAddress(scratch) failed on device %d: %s\n", device, hipGetErrorString(err));
+            return nullptr;
+        }
+        g_static_ptr[device] = static_cast<uint8_t *>(ptr);
+    }
+    return g_static_ptr[device];
+}
+
 struct svtme_engine {
+    uint8_t            *static_scratch = nullptr; // this device's copy of `scratch` (device address), set by svtme_create
     svtme_config        cfg{};
     std::mutex          mu;
     hipStream_t         s_store = nullptr, s_me[4] = {nullptr, nullptr, nullptr, nullptr}, s_copy = nullptr;
@@ -192,6 +226,8 @@ extern "C" int svtme_create(const svtme_config *cfg, svtme_engine **out) {
         svtme_destroy(e);
         return code;
     };
+    e->static_scratch = static_scratch_of(cfg->device);
+    if (!e->static_scratch) return fail(SVTME_ERR_DEVICE);
     if (hipStreamCreateWithFlags(&e->s_store, hipStreamNonBlocking) != hipSuccess ||
         hipStreamCreateWithFlags(&e->s_me[0], hipStreamNonBlocking) != hipSuccess ||
         hipStreamCreateWithFlags(&e->s_me[1], hipStreamNonBlocking) != hipSuccess ||
@@ -480,6 +516,129 @@ extern "C" int svtme_picture_submit(svtme_engine *e, const svtme_picture *pic, s
     f->slots  = used;
     f->ticket = e->next_ticket++;
     *ticket   = f->ticket;
+    return SVTME_OK;
+}
+
+// The allocation-free form of svtme_picture_submit + svtme_picture_wait: same kernels, same results, but the kernels'
+// intermediates live in this device's copy of the file-scope `scratch` array and the results go straight into memory
+// the caller owns. Nothing here allocates or frees (no hipMalloc / hipFree / hipHostMalloc, no event or stream
+// creation, no heap containers): the stream is one svtme_create made, the store planes are the slots svtme_create made.
+extern "C" int svtme_picture_search_static(svtme_engine *e, const svtme_picture *pic, void *result_block, size_t result_bytes,
+                                           svtme_results *out) {
+    if (!e || !pic || !result_block || !out) return SVTME_ERR_BAD_ARG;
+    const svtme_controls &k = pic->ctrl;
+    if (pic->num_of_list_to_search < 1 || pic->num_of_list_to_search > 2 || pic->num_of_ref_pic_to_search[0] < 1 ||
+        pic->num_of_ref_pic_to_search[0] > SVTME_MAX_REFS ||
+        (pic->num_of_list_to_search == 2 && (pic->num_of_ref_pic_to_search[1] < 1 || pic->num_of_ref_pic_to_search[1] > SVTME_MAX_REFS)) ||
+        k.num_hme_sa_w < 1 || k.num_hme_sa_w > 2 || k.num_hme_sa_h < 1 || k.num_hme_sa_h > 2)
+        return SVTME_ERR_BAD_ARG;
+    if (k.me_search_method != 0) return SVTME_ERR_UNSUPPORTED;
+    if ((pic->me_type != 0 && pic->me_type != SVTME_ME_OPEN_LOOP && pic->me_type != SVTME_ME_MCTF && pic->me_type != SVTME_ME_FIRST_PASS) ||
+        pic->bypass_zz_check > 1 || pic->restricted_motion_vector > 1)
+        return SVTME_ERR_BAD_ARG;
+    if (pic->me_type == SVTME_ME_MCTF && (pic->num_of_list_to_search != 1 || pic->num_of_ref_pic_to_search[0] != 1)) return SVTME_ERR_BAD_ARG;
+    if (pic->tail.enable) return SVTME_ERR_UNSUPPORTED; // the device tail's outputs are not part of this form's result block
+    if (e->cfg.serial_hme) return SVTME_ERR_UNSUPPORTED;
+    if (reinterpret_cast<uintptr_t>(result_block) % 64) return SVTME_ERR_BAD_ARG;
+    const size_t n_b64 = (size_t)((pic->width + 63) / 64) * ((pic->height + 63) / 64);
+    if (n_b64 > SVTME_STATIC_MAX_B64) {
+        fprintf(stderr, "svtme: svtme_picture_search_static takes pictures of at most %d 64x64 blocks (3840x2160); %ux%u has %zu\n",
+                SVTME_STATIC_MAX_B64, pic->width, pic->height, n_b64);
+        return SVTME_ERR_BAD_ARG;
+    }
+    const int    n_ref0 = pic->num_of_ref_pic_to_search[0], n_ref1 = pic->num_of_list_to_search == 2 ? pic->num_of_ref_pic_to_search[1] : 0;
+    if (result_bytes < SVTME_STATIC_RESULT_BYTES(n_b64, (size_t)(n_ref0 + n_ref1))) return SVTME_ERR_BAD_ARG;
+
+    std::lock_guard<std::mutex> lock(e->mu);
+    DEVICE_OR_FAIL(e->cfg.device);
+    PicParams p;
+    memset(&p, 0, sizeof(p));
+    int       used[1 + SVTME_MAX_LISTS * SVTME_MAX_REFS], n_used = 0;
+    const int ci = find_slot(e, pic->cur_key);
+    if (ci < 0) return SVTME_ERR_NOT_FOUND;
+    if (e->slots[ci].width != pic->width || e->slots[ci].height != pic->height) return SVTME_ERR_BAD_ARG;
+    p.cur          = e->slots[ci].pic;
+    used[n_used++] = ci;
+    p.n_list   = pic->num_of_list_to_search;
+    p.n_ref[0] = n_ref0;
+    p.n_ref[1] = n_ref1;
+    for (int l = 0; l < p.n_list; ++l)
+        for (int r = 0; r < p.n_ref[l]; ++r) {
+            const int ri = find_slot(e, pic->ref_key[l][r]);
+            if (ri < 0) return SVTME_ERR_NOT_FOUND;
+            if (e->slots[ri].width != pic->width || e->slots[ri].height != pic->height) return SVTME_ERR_BAD_ARG;
+            p.ref[l][r] = e->slots[ri].pic;
+            const int64_t d = (int64_t)pic->picture_number - (int64_t)pic->ref_picture_number[l][r];
+            p.dist[l][r] = (uint16_t)(int16_t)(d < 0 ? -d : d);
+            used[n_used++] = ri;
+        }
+    p.ctrl   = k;
+    p.width  = (int32_t)pic->width;
+    p.height = (int32_t)pic->height;
+    p.b64_w  = (int32_t)((pic->width + 63) / 64);
+    p.b64_h  = (int32_t)((pic->height + 63) / 64);
+    p.temporal_layer  = pic->temporal_layer_index;
+    p.is_ref          = pic->is_used_as_reference_flag;
+    p.me_type         = pic->me_type ? pic->me_type : SVTME_ME_OPEN_LOOP;
+    p.bypass_zz_check = pic->me_type == SVTME_ME_FIRST_PASS && pic->bypass_zz_check;
+    p.restricted      = pic->restricted_motion_vector;
+    p.tf_me_exit_th   = pic->tf_me_exit_th;
+    p.dep_pre = k.prehme_enable && k.prehme_l1_early_exit && p.n_list == 2;
+    p.dep_l0  = k.enable_hme_flag && k.enable_hme_level0_flag && k.enable_me_sr_adjustment && k.distance_based_hme_resizing &&
+        k.reduce_hme_l0_sr_th_min && k.reduce_hme_l0_sr_th_max && p.n_ref[0] + p.n_ref[1] > 1;
+    {
+        const int w_max = (std::max<int>(k.me_sa.sa_max.width, 1) + 7) & ~7, h_max = std::max<int>(k.me_sa.sa_max.height, 3);
+        p.me_max_items  = ((w_max + 63) / 64) * ((h_max + 7) / 8);
+    }
+    // intermediates: this device's copy of the static array, through the pointer taken with hipGetSymbolAddress
+    uint8_t *sc = e->static_scratch;
+    p.hme_out = reinterpret_cast<HmeRefOut *>(sc);
+    p.ops     = reinterpret_cast<unsigned long long *>(sc + kStaticOpsOff);
+    p.me_jobs = reinterpret_cast<MeJob *>(sc + kStaticJobsOff);
+    p.me_keys = reinterpret_cast<unsigned long long *>(sc + kStaticKeysOff);
+    // results: the caller's block, laid out like a picture without device tail
+    Flight lay;
+    lay.layout(n_b64, (size_t)(n_ref0 + n_ref1), false);
+    uint8_t *res = static_cast<uint8_t *>(result_block);
+    p.best_sad       = reinterpret_cast<uint32_t *>(res + lay.off_sad);
+    p.best_mv        = reinterpret_cast<uint32_t *>(res + lay.off_mv);
+    p.search_results = reinterpret_cast<svtme_search_result *>(res + lay.off_sr);
+    p.zz_sad         = reinterpret_cast<uint32_t *>(res + lay.off_zz);
+    p.sr_divisor     = reinterpret_cast<uint32_t *>(res + lay.off_div);
+    p.ops_out        = reinterpret_cast<unsigned long long *>(res + lay.off_ops);
+
+    // calls that share this device's scratch within the process take turns; the array keeps the last call's contents, so
+    // what the kernels expect to start from zero (HME records, counters) is cleared here whatever the last call left
+    std::lock_guard<std::mutex> scratch_turn(g_static_mu);
+    const hipStream_t sm = e->s_me[3]; // created by svtme_create, used by this entry point only
+    for (int i = 0; i < n_used; ++i) HIP_TRY(hipStreamWaitEvent(sm, e->slots[used[i]].ready, 0));
+    HIP_TRY(hipMemsetAsync(sc, 0, n_b64 * SVTME_MAX_LISTS * SVTME_MAX_REFS * sizeof(HmeRefOut), sm));
+    HIP_TRY(hipMemsetAsync(sc + kStaticOpsOff, 0, SVTME_OPS_BYTES, sm));
+    hipEvent_t no_marks[3] = {nullptr, nullptr, nullptr};
+    launch_hme(p, sm, no_marks);
+    launch_me(p, sm, no_marks);
+    const hipError_t launch_err = hipGetLastError();
+    // the planes must not be rewritten and the scratch not reused before the kernels are through: always drain the stream
+    const hipError_t sync_err = hipStreamSynchronize(sm);
+    if (launch_err != hipSuccess || sync_err != hipSuccess) {
+        fprintf(stderr, "svtme: svtme_picture_search_static: %s\n", hipGetErrorString(launch_err != hipSuccess ? launch_err : sync_err));
+        return SVTME_ERR_DEVICE;
+    }
+    out->n_b64                = (uint32_t)n_b64;
+    out->p_sb_best_sad        = reinterpret_cast<const uint32_t *>(res + lay.off_sad);
+    out->p_sb_best_mv         = reinterpret_cast<const uint32_t *>(res + lay.off_mv);
+    out->search_results       = reinterpret_cast<const svtme_search_result *>(res + lay.off_sr);
+    out->zz_sad               = reinterpret_cast<const uint32_t *>(res + lay.off_zz);
+    out->reduce_me_sr_divisor = reinterpret_cast<const uint32_t *>(res + lay.off_div);
+    out->total_me_candidate_index = nullptr;
+    out->me_mv_array = nullptr;
+    out->me_candidate_array = nullptr;
+    out->me_distortion = nullptr;
+    out->b64_stats = nullptr;
+    out->final_do_ref = nullptr;
+    out->final_hme_sad = nullptr;
+    out->n_ref[0] = (uint32_t)n_ref0;
+    out->n_ref[1] = (uint32_t)n_ref1;
     return SVTME_OK;
 }
 

@@ -114,7 +114,15 @@ class Results(C.Structure):
 EXPORTS = ("svtme_version", "svtme_derive_controls", "svtme_derive_tf_controls", "svtme_derive_first_pass_controls",
            "svtme_input_resolution", "svtme_create", "svtme_destroy",
            "svtme_store_put", "svtme_store_release", "svtme_store_read", "svtme_picture_submit", "svtme_picture_wait",
-           "svtme_picture_done", "svtme_picture_timing", "svtme_picture_ops", "svtme_unpack_b64")
+           "svtme_picture_done", "svtme_picture_timing", "svtme_picture_ops", "svtme_unpack_b64",
+           "svtme_picture_search_static")
+STATIC_MAX_B64 = 2040
+
+
+def static_result_bytes(n_b64, n_refs):
+    """SVTME_STATIC_RESULT_BYTES of include/svtme.h."""
+    return n_b64 * 256 + 4096 + n_refs * n_b64 * PU_COUNT * 8
+
 
 _lib = None
 
@@ -145,6 +153,7 @@ def load_library():
     lib.svtme_picture_timing.argtypes = [C.c_void_p, C.c_uint64, C.POINTER(C.c_float * 8)]
     lib.svtme_picture_ops.argtypes = [C.c_void_p, C.c_uint64, C.POINTER(C.c_uint64 * 6)]
     lib.svtme_unpack_b64.argtypes = [C.POINTER(Results), C.c_uint32] + [C.c_void_p] * 5
+    lib.svtme_picture_search_static.argtypes = [C.c_void_p, C.POINTER(Picture), C.c_void_p, C.c_size_t, C.POINTER(Results)]
     _lib = lib
     return lib
 
@@ -301,6 +310,15 @@ class Engine:
         if copy:
             out = {k: np.array(v) for k, v in out.items()}
         return out
+
+    def search_static(self, pic, result_block, result_bytes):
+        """svtme_picture_search_static: the picture's search without any allocation, results into caller-owned memory the
+        device can write (`result_block`: an address). Returns the Results struct, whose pointers lie inside the block."""
+        r = Results()
+        rc = self.lib.svtme_picture_search_static(self.h, C.byref(pic), result_block, result_bytes, C.byref(r))
+        if rc:
+            raise SvtmeError(rc, "svtme_picture_search_static")
+        return r
 
     def timing(self, ticket):
         ms = (C.c_float * 8)()
