@@ -77,8 +77,9 @@ def synth_sequence(width, height, n_frames, seed=1, motion=(3, -2), noise=2, bit
             f = f + (nz % (2 * noise + 1)) - noise
         f = np.clip(f, 0, 255)
         if bit_depth == 10:
-            lsb = _raw_bytes(seed * 1000003 + k + 977, height * width).reshape(height, width) & 3
-            f10 = f * scale10 + lsb
+            # a 10-bit picture with detail of its own below the 8-bit step (+-6 of 1023), then the MSB plane the ME reads
+            fine = _raw_bytes(seed * 1000003 + k + 977, height * width).reshape(height, width).astype(np.int32)
+            f10 = np.clip(f * scale10 + (fine % 13) - 6, 0, 1023)
             f = f10 >> 2
         frames[k] = f.astype(np.uint8)
     return frames

@@ -46,7 +46,10 @@ DIGEST_CASES = {
 }
 # the benchmark's largest picture sizes: digests only, checked by the GPU tests (the CPU restatement is not run on them)
 BIG_DIGEST_CASES = {
-    "m8_ra_3840x2160": dict(width=3840, height=2160, n_frames=5, enc_mode=8, seed=34, structure="ra", motion=(7, -4)),
+    # the benchmark's headline shape: 1080p random access, mini-GOP 16, preset 3 (4 + 3 references, HME levels 0-2)
+    "m3_ra_1920x1080": dict(width=1920, height=1080, n_frames=17, enc_mode=3, seed=36, structure="ra", motion=(5, -3)),
+    # 10-bit input: the ME reads the 8-bit MSB plane (pixel >> 2)
+    "m8_ra_3840x2160": dict(width=3840, height=2160, n_frames=5, enc_mode=8, seed=34, structure="ra", motion=(7, -4), bit_depth=10),
     "m2_ra_7680x4320": dict(width=7680, height=4320, n_frames=5, enc_mode=2, seed=35, structure="ra", motion=(9, -6)),
 }
 
@@ -103,21 +106,30 @@ def tf_canonical(bd):
     return out
 
 
-def run_case(c, threads=1):
+def run_case(c, threads=1, use_avx2=0):
     frames, pics, rc = support.make_job(c["width"], c["height"], c["n_frames"], c["enc_mode"], c["seed"],
-                                        c.get("structure", "ra"), c.get("kind", "synth"), c.get("motion", (3, -2)))
+                                        c.get("structure", "ra"), c.get("kind", "synth"), c.get("motion", (3, -2)),
+                                        bit_depth=c.get("bit_depth", 8))
     kw = dict(ref_counts=rc, sc_class1=c.get("sc_class1", 0), frame_rate=c.get("frame_rate", 30 << 16),
               gm_enabled=1, gm_dist_th=1, restricted_motion_vector=c.get("restricted", 0))
-    hdr, recs = refio.run_reference(frames, pics, c["enc_mode"], threads=threads, use_avx2=0, **kw)
+    hdr, recs = refio.run_reference(frames, pics, c["enc_mode"], threads=threads, use_avx2=use_avx2, **kw)
+    assert bool(hdr["used_avx2"]) == bool(use_avx2)
     return frames, pics, recs
 
 
 def digest_case(c, threads=8):
-    frames, pics, recs = run_case(c, threads=threads)
-    d = {"frames_sha256": hashlib.sha256(frames.tobytes()).hexdigest(), "pictures": []}
-    for (pd, bd) in recs:
-        canon = support.canonical(bd, pics[len(d["pictures"])], bool(pd["ctrl"]["enable_me_hme_ref_pruning"]))
-        d["pictures"].append({f: hashlib.sha256(v.tobytes()).hexdigest() for f, v in canon.items()})
+    """Digests of the reference's C kernels; the same job through the reference's AVX2 SAD kernels (what an encoder
+    built with SIMD runs, configs[0] of the benchmark) must give the same digests, which is recorded beside them."""
+    def digests(use_avx2):
+        frames, pics, recs = run_case(c, threads=threads, use_avx2=use_avx2)
+        d = {"frames_sha256": hashlib.sha256(frames.tobytes()).hexdigest(), "pictures": []}
+        for (pd, bd) in recs:
+            canon = support.canonical(bd, pics[len(d["pictures"])], bool(pd["ctrl"]["enable_me_hme_ref_pruning"]))
+            d["pictures"].append({f: hashlib.sha256(v.tobytes()).hexdigest() for f, v in canon.items()})
+        return d
+    d = digests(0)
+    assert digests(1) == d, "the reference's AVX2 kernels and its C kernels disagree"
+    d["avx2_kernels_give_the_same_digests"] = True
     return d
 
 
@@ -127,6 +139,8 @@ def main_big():
     with open(path) as f:
         doc = json.load(f)
     for name, c in BIG_DIGEST_CASES.items():
+        if "--only" in sys.argv and name not in sys.argv:
+            continue
         doc["digests"][name] = digest_case(c)
         doc["cases"][name] = dict(c)
         print(name, "digested", len(doc["digests"][name]["pictures"]), "pictures")

@@ -13,9 +13,9 @@ TAIL_FIELDS = ["do_ref", "hme_sad", "me_distortion", "total_me_candidate_index",
                "me_8x8_distortion", "me_8x8_cost_variance", "stationary_block_present_sb", "rc_me_allow_gm"]
 
 
-def make_job(width, height, n_frames, enc_mode, seed=1, structure="ra", kind="synth", motion=(3, -2)):
+def make_job(width, height, n_frames, enc_mode, seed=1, structure="ra", kind="synth", motion=(3, -2), bit_depth=8):
     if kind in ("synth", "half_static"):
-        frames = synth.synth_sequence(width, height, n_frames, seed=seed, motion=motion)
+        frames = synth.synth_sequence(width, height, n_frames, seed=seed, motion=motion, bit_depth=bit_depth)
         if kind == "half_static":  # the left half never changes: perfect zero-vector matches there
             frames[:, :, :width // 2] = frames[0, :, :width // 2]
     else:

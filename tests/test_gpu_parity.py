@@ -270,13 +270,14 @@ def test_scheduler_runs_a_sequence_on_the_engine_with_store_reuse():
 
 @pytest.mark.parametrize("name", sorted(MOD.DIGEST_CASES) + sorted(MOD.BIG_DIGEST_CASES))
 def test_engine_matches_reference_digests_at_full_size(name):
-    """1080p preset 8 / 720p preset 12 / 360p preset 3 / 4K preset 8 / 8K preset 2: sha256 of the engine's masked best
+    """1080p preset 8 and preset 3 (the benchmark's headline shape) / 720p preset 12 / 360p preset 3 / 4K preset 8 from
+    10-bit input / 8K preset 2: sha256 of the engine's masked best
     SAD / MV arrays and search centres against digests of the real reference's output (tests/golden/digests.json)."""
     with open(os.path.join(GOLDEN, "digests.json")) as f:
         dig = json.load(f)["digests"][name]
     c = MOD.DIGEST_CASES.get(name) or MOD.BIG_DIGEST_CASES[name]
     frames, pics, _ = support.make_job(c["width"], c["height"], c["n_frames"], c["enc_mode"], c["seed"], c["structure"],
-                                       motion=c.get("motion", (3, -2)))
+                                       motion=c.get("motion", (3, -2)), bit_depth=c.get("bit_depth", 8))
     assert hashlib.sha256(frames.tobytes()).hexdigest() == dig["frames_sha256"]
     outs = support.run_engine_job(frames, pics, c["enc_mode"])
     for i, (p, out) in enumerate(zip(pics, outs)):
