@@ -116,6 +116,11 @@ def main():
     ap.add_argument("--search-streams", type=int, default=3, choices=[1, 2, 3])
     ap.add_argument("--kernel-steps", type=int, default=8, help="steps of the one-stream pass that times the kernels")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--with-upload", action="store_true",
+                    help="every step also puts each of its source pictures into the device store once, inside the timed "
+                         "region (host -> device included; reported as a second line of evidence, never as `value` of the default run)")
+    ap.add_argument("--upload-mode", default="pinned", choices=["pinned", "copy"],
+                    help="--with-upload: zero-copy puts from page-locked buffers with the encoder's stride, or svtme_store_put")
     ap.add_argument("--device-tail-only", action="store_true", help="--device-tail, and do not copy the search arrays back")
     ap.add_argument("--device-tail", action="store_true",
                     help="also run me_prune_ref / candidate construction / distortions / GM detection on the device")
@@ -169,8 +174,10 @@ def main():
                           max_cand=l0 + l1 + l0 * l1 + (l0 - 1) + (1 if l1 == 3 else 0), max_l0=l0, input_resolution=res,
                           gm_enabled=1, gm_use_distance_based_active_th=1)
 
+    KEY_SETS = 2  # --with-upload: consecutive steps use different store slots, as new pictures do in the encoder's pool
+
     def make_engine(search_streams, kernel_timing):
-        e = svtme.Engine(w, h, store_slots=n + 1, max_in_flight=args.in_flight, device=local_rank,
+        e = svtme.Engine(w, h, store_slots=KEY_SETS * n + 1, max_in_flight=args.in_flight, device=local_rank,
                          search_streams=search_streams, kernel_timing=kernel_timing)
         for i in range(n):
             e.store_put(i, i, frames[i])  # inputs resident in HBM before the timed region
@@ -183,15 +190,43 @@ def main():
     new_stats = lambda: {"ms": np.zeros(8, np.float64), "launches": 0, "ops": np.zeros(6, np.float64)}  # noqa: E731
     stats = new_stats()
 
-    def run_steps(k, collect, e=None, ds=None):
+    # --with-upload: the sources as the encoder holds them, padded input buffers (origin 72, 72; stride = width + 144)
+    # registered once; each step puts every source of its mini-GOP once, right before the first picture that needs it
+    pool = None
+    if args.with_upload:
+        pool = eng.host_alloc((n, h + 144, w + 144)) if args.upload_mode == "pinned" else np.zeros((n, h + 144, w + 144), np.uint8)
+        pool[:, 72:72 + h, 72:72 + w] = frames
+        # the same pictures under a second set of store keys for every other step
+        descs_alt = [[eng.make_picture(w, h, p.poc, p.temporal_layer, p.is_ref, p.refs, ctrl, tail=tail,
+                                       tf_me_exit_th=tf[1] if tf else None, first_pass_bypass_zz=fp[0] if fp else None,
+                                       key_of=lambda poc, ks=ks: 1000 * ks + poc) for p in pics] for ks in range(KEY_SETS)]
+        need_before = []  # per picture of the dispatch order: the sources no earlier picture of the step has needed
+        seen = set()
+        for p in pics:
+            srcs = [p.poc] + [r for lst in p.refs for r in lst]
+            need_before.append([k_ for k_ in dict.fromkeys(srcs) if k_ not in seen])
+            seen.update(srcs)
+
+    def put_sources(e, i, ks):
+        for k_ in need_before[i]:
+            view = pool[k_, 72:72 + h, 72:72 + w]
+            if args.upload_mode == "pinned":
+                e.store_put_pinned(1000 * ks + k_, k_, view)
+            else:
+                e.store_put(1000 * ks + k_, k_, view)
+
+    def run_steps(k, collect, e=None, ds=None, upload=False):
         """k steps back to back: at most --in-flight pictures outstanding, also across step boundaries (mini-GOPs follow
         each other without a pause, as they do in the encoder); everything has been waited for on return."""
         e, ds = e or eng, ds or descs
         tickets = []
-        for _ in range(k):
-            for d in ds:
+        for step in range(k):
+            ks = step % KEY_SETS
+            for i, d in enumerate(descs_alt[ks] if upload else ds):
                 if len(tickets) == args.in_flight:
                     finish(e, tickets.pop(0), collect)
+                if upload:
+                    put_sources(e, i, ks)
                 tickets.append(e.submit(d))
         while tickets:
             finish(e, tickets.pop(0), collect)
@@ -209,10 +244,10 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    run_steps(args.warmup, None)
+    run_steps(args.warmup, None, upload=args.with_upload)
     barrier()
     t0 = time.perf_counter()
-    run_steps(args.steps, None)  # nothing but submit / wait / done per picture inside the timed region
+    run_steps(args.steps, None, upload=args.with_upload)  # nothing but (put,) submit / wait / done per picture inside the timed region
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
     barrier()
@@ -299,6 +334,9 @@ def main():
             "picture_kernels_ms_in_timed_region": float(ms_shared[5]),  # first kernel start to last kernel end
             "search_streams": args.search_streams, "device_tail": (2 if args.device_tail_only else 1) if tail is not None else 0,
             "store_put_pictures_per_s": upload_pps,
+            "with_upload": ({"mode": args.upload_mode, "sources_put_per_step": n,
+                             "note": "every source picture of a step is put into the device store once inside the timed region"}
+                            if args.with_upload else None),
             "ops_by_stage": dict(zip(STAGES, [float(v) for v in ops])),
             "picture_ms_incl_d2h": float(ms[6]),
         }

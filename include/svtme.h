@@ -160,10 +160,36 @@ void svtme_destroy(svtme_engine *e);
  * downsample_filtering_input_picture (EbPictureAnalysisProcess.c:2688-2752). `key` identifies the slot
  * (the integration uses the EbPaReferenceObject pointer); putting an existing key overwrites it (the
  * temporal filter rewrites planes, EbTemporalFiltering.c:5169-5217). The host buffer may be reused as
- * soon as the call returns.
+ * soon as the call returns. A picture that reads the slot can be submitted once the put has returned; puts of
+ * different keys may run concurrently from several threads (the frame copy is outside the engine's lock).
  */
 int svtme_store_put(svtme_engine *e, uint64_t key, uint64_t picture_number, const uint8_t *luma,
                     uint32_t stride, uint32_t width, uint32_t height);
+/*
+ * The same put without the host-side frame copy, for luma that already lies in page-locked memory: the rows are fetched
+ * by DMA from the caller's buffer as they lie, `stride` apart (the encoder's y8b input buffers, the pool created at
+ * Source/Lib/Encoder/Globals/EbEncHandle.c:1778-1787 by svt_input_y8b_creator, which the PA reference object's full
+ * plane aliases, EbResourceCoordinationProcess.c:1294: allocate the pool with svtme_host_alloc or page-lock it once with
+ * svtme_host_register). The call returns
+ * at once; the buffer must stay unchanged until svtme_store_wait(key) has returned or a picture that reads the slot has
+ * been waited for. That is the encoder's own rule for these buffers: they live as long as the PA reference object and are
+ * only rewritten by the temporal filter, before the picture is put again. Memory that is not page-locked still works
+ * (the runtime then stages the copy itself, slower); a stride that is not a multiple of 4 or exceeds width + 256 is
+ * handled like svtme_store_put.
+ */
+int svtme_store_put_pinned(svtme_engine *e, uint64_t key, uint64_t picture_number, const uint8_t *luma,
+                           uint32_t stride, uint32_t width, uint32_t height);
+/* Blocks until the planes of `key` are built on the device (its last put has run). */
+int svtme_store_wait(svtme_engine *e, uint64_t key);
+/* Page-locked host memory for svtme_store_put_pinned behind plain-C signatures, so that the encoder-side shim needs no HIP
+ * headers. Either the shim allocates the luma buffers of the y8b pool with svtme_host_alloc (in svt_input_y8b_creator, in
+ * place of its EB_MALLOC of buffer_y), or it page-locks the buffers it has with svtme_host_register. The latter depends on
+ * the driver being able to lock user pages and returns SVTME_ERR_UNSUPPORTED where it cannot (some virtual machines);
+ * registering a range twice is not an error. */
+int svtme_host_alloc(svtme_engine *e, size_t bytes, void **out);
+int svtme_host_free(svtme_engine *e, void *ptr);
+int svtme_host_register(svtme_engine *e, void *ptr, size_t bytes);
+int svtme_host_unregister(svtme_engine *e, void *ptr);
 /* Mirrors release_pa_reference_objects (EbReferenceObject.c:298): frees the slot once no submitted
  * picture still reads it. */
 int svtme_store_release(svtme_engine *e, uint64_t key);

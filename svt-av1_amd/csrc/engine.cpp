@@ -1,11 +1,13 @@
 // engine.cpp - host side of the engine: device picture store, picture queue, C ABI (include/svtme.h).
 //
-// HIP streams: `s_store` carries the uploads and the store-building kernels, the `s_me` streams the search kernels
+// HIP streams: the `s_store` streams carry the uploads and the store-building kernels (puts take turns on them, each with
+// its own upload buffer, so one put's DMA overlaps the previous put's kernels), the `s_me` streams the search kernels
 // (pictures take turns on up to three of them, so one picture's kernel tails overlap the others' kernels), `s_copy`
 // the result copies when fewer than three search streams are in use (with three, a picture's copy follows its kernels
-// on its own stream: four hardware queues in all). A picture waits (on the device, through events) for the store slots
-// it reads; a slot that is rewritten waits for the last picture that read it. Nothing here blocks the host except
-// svtme_picture_wait (and svtme_store_put when it reuses a slot whose previous upload is still in flight).
+// on its own stream). A picture waits (on the device, through events) for the store slots it reads; a slot that is
+// rewritten waits for the last picture that read it. Nothing here blocks the host except svtme_picture_wait,
+// svtme_store_wait and a put that reuses a slot whose previous upload is still in flight; the engine mutex is held for
+// bookkeeping and stream enqueues only, never across a frame copy or a wait.
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
@@ -13,6 +15,7 @@
 #include <mutex>
 #include <new>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 #include <vector>
 
@@ -32,9 +35,12 @@ using namespace svtme;
 namespace {
 
 constexpr int kPad[3] = {16, 32, 72}; // sixteenth, quarter, full: EbEncHandle.c:1331-1355, :3447-3460
+constexpr uint32_t kMaxExtraStride = 256; // svtme_store_put_pinned: stride - width it copies in one piece (the encoder's is 144)
 
 struct Slot {
     bool       used = false;
+    bool       putting = false; // a put has reserved the slot and is copying outside the lock: not yet visible to submits
+    bool       uploaded = false; // `ready` has been recorded at least once (an upload from host_stage may be in flight)
     bool       release_pending = false;
     uint64_t   key = 0, picture_number = 0;
     int        readers = 0; // submitted pictures that have not been waited for yet
@@ -135,13 +141,15 @@ struct svtme_engine {
     uint8_t            *static_scratch = nullptr; // this device's copy of `scratch` (device address), set by svtme_create
     svtme_config        cfg{};
     std::mutex          mu;
-    hipStream_t         s_store = nullptr, s_me[4] = {nullptr, nullptr, nullptr, nullptr}, s_copy = nullptr;
-    unsigned            next_me = 0;
+    hipStream_t         s_store[2] = {nullptr, nullptr}, s_me[4] = {nullptr, nullptr, nullptr, nullptr}, s_copy = nullptr;
+    unsigned            next_me = 0, next_upload = 0, n_upload = 1;
+    int                 copy_on_search_stream = -1; // -1: with three search streams only; 0 / 1: diagnostic override
     std::vector<Slot>   slots;
     std::vector<Flight> flights;
     svtme_ticket        next_ticket = 1;
     size_t              slot_bytes = 0, max_b64 = 0;
-    uint8_t            *d_upload = nullptr; // un-padded luma of the picture being put (the store stream orders its reuse)
+    uint8_t            *d_upload[2] = {nullptr, nullptr}; // un-padded luma of the pictures being put (a store stream orders the reuse of its buffer)
+    size_t              upload_bytes = 0;
 };
 
 namespace {
@@ -188,9 +196,10 @@ void layout_planes(uint8_t *mem, uint32_t w, uint32_t h, DevPicture *pic, size_t
     *bytes = off;
 }
 
-int find_slot(svtme_engine *e, uint64_t key) {
+// with_putting: also slots a put has reserved but not yet enqueued (only the store calls themselves want those)
+int find_slot(svtme_engine *e, uint64_t key, bool with_putting = false) {
     for (size_t i = 0; i < e->slots.size(); ++i)
-        if (e->slots[i].used && e->slots[i].key == key) return (int)i;
+        if (e->slots[i].used && e->slots[i].key == key && (with_putting || !e->slots[i].putting)) return (int)i;
     return -1;
 }
 
@@ -228,7 +237,8 @@ extern "C" int svtme_create(const svtme_config *cfg, svtme_engine **out) {
     };
     e->static_scratch = static_scratch_of(cfg->device);
     if (!e->static_scratch) return fail(SVTME_ERR_DEVICE);
-    if (hipStreamCreateWithFlags(&e->s_store, hipStreamNonBlocking) != hipSuccess ||
+    if (hipStreamCreateWithFlags(&e->s_store[0], hipStreamNonBlocking) != hipSuccess ||
+        hipStreamCreateWithFlags(&e->s_store[1], hipStreamNonBlocking) != hipSuccess ||
         hipStreamCreateWithFlags(&e->s_me[0], hipStreamNonBlocking) != hipSuccess ||
         hipStreamCreateWithFlags(&e->s_me[1], hipStreamNonBlocking) != hipSuccess ||
         hipStreamCreateWithFlags(&e->s_me[2], hipStreamNonBlocking) != hipSuccess ||
@@ -238,7 +248,15 @@ extern "C" int svtme_create(const svtme_config *cfg, svtme_engine **out) {
     DevPicture tmp;
     layout_planes(nullptr, cfg->max_width, cfg->max_height, &tmp, &e->slot_bytes);
     e->max_b64 = (size_t)((cfg->max_width + 63) / 64) * ((cfg->max_height + 63) / 64);
-    if (hipMalloc((void **)&e->d_upload, (size_t)cfg->max_width * cfg->max_height) != hipSuccess) return fail(SVTME_ERR_NO_RESOURCES);
+    // room for rows that arrive with the caller's stride (svtme_store_put_pinned copies them as they lie)
+    e->upload_bytes = (size_t)(cfg->max_width + kMaxExtraStride) * cfg->max_height;
+    // One upload stream by default: a second one (puts alternating, one DMA overlapping the other put's kernels) raises the
+    // put-only rate at 4K from 5.6 k to 6.2 k pictures/s but lowers the rate of searches that run beside the puts (a fifth
+    // active stream on four hardware queues). SVTME_UPLOAD_RINGS=2 selects it.
+    if (const char *v = getenv("SVTME_UPLOAD_RINGS")) e->n_upload = atoi(v) == 2 ? 2 : 1;
+    if (const char *v = getenv("SVTME_COPY_ON_SEARCH_STREAM")) e->copy_on_search_stream = atoi(v) != 0; // diagnostic
+    for (unsigned i = 0; i < e->n_upload; ++i)
+        if (hipMalloc((void **)&e->d_upload[i], e->upload_bytes) != hipSuccess) return fail(SVTME_ERR_NO_RESOURCES);
     e->slots.resize(cfg->store_slots);
     for (auto &s : e->slots) {
         if (hipMalloc((void **)&s.mem, e->slot_bytes) != hipSuccess ||
@@ -269,59 +287,174 @@ extern "C" void svtme_destroy(svtme_engine *e) {
     for (auto sm : e->s_me)
         if (sm) (void)hipStreamSynchronize(sm);
     if (e->s_copy) (void)hipStreamSynchronize(e->s_copy);
-    if (e->s_store) (void)hipStreamSynchronize(e->s_store);
+    for (auto ss : e->s_store)
+        if (ss) (void)hipStreamSynchronize(ss);
     for (auto &s : e->slots) {
         if (s.mem) (void)hipFree(s.mem);
         if (s.host_stage) (void)hipHostFree(s.host_stage);
         if (s.ready) (void)hipEventDestroy(s.ready);
     }
-    if (e->d_upload) (void)hipFree(e->d_upload);
+    for (auto d : e->d_upload)
+        if (d) (void)hipFree(d);
     for (auto &f : e->flights) free_flight(f);
     for (auto sm : e->s_me)
         if (sm) (void)hipStreamDestroy(sm);
-    if (e->s_store) (void)hipStreamDestroy(e->s_store);
+    for (auto ss : e->s_store)
+        if (ss) (void)hipStreamDestroy(ss);
     if (e->s_copy) (void)hipStreamDestroy(e->s_copy);
     delete e;
 }
 
-extern "C" int svtme_store_put(svtme_engine *e, uint64_t key, uint64_t picture_number, const uint8_t *luma, uint32_t stride,
-                               uint32_t width, uint32_t height) {
+// The two forms of a put. `pinned`: the rows are copied from the caller's buffer as they lie (one linear DMA of
+// (height - 1) * stride + width bytes), the store kernels pick the pixels out of the strided copy; the caller keeps the
+// buffer unchanged until the planes are built. Otherwise the rows are packed into the slot's pinned staging buffer first
+// and the caller's buffer is free on return.
+static int store_put_impl(svtme_engine *e, uint64_t key, uint64_t picture_number, const uint8_t *luma, uint32_t stride,
+                          uint32_t width, uint32_t height, bool pinned) {
     if (!e || !luma || width < 64 || height < 64 || width % 8 || height % 8 || width > e->cfg.max_width ||
         height > e->cfg.max_height || stride < width)
         return SVTME_ERR_BAD_ARG;
-    std::lock_guard<std::mutex> lock(e->mu);
+    // a strided copy needs dword-aligned rows and has to fit the upload buffer; anything else takes the packing path
+    if (pinned && (stride % 4 || stride - width > kMaxExtraStride)) pinned = false;
     DEVICE_OR_FAIL(e->cfg.device);
-    int si = find_slot(e, key);
-    if (si < 0) {
-        for (size_t i = 0; i < e->slots.size(); ++i)
-            if (!e->slots[i].used) {
-                si = (int)i;
-                break;
-            }
-        if (si < 0) return SVTME_ERR_NO_RESOURCES;
+    int      si;
+    bool     fresh, wait_upload;
+    unsigned ring;
+    {
+        std::lock_guard<std::mutex> lock(e->mu);
+        si    = find_slot(e, key, true);
+        fresh = si < 0;
+        if (fresh) {
+            for (size_t i = 0; i < e->slots.size(); ++i)
+                if (!e->slots[i].used) {
+                    si = (int)i;
+                    break;
+                }
+            if (si < 0) return SVTME_ERR_NO_RESOURCES;
+        }
+        Slot &s = e->slots[si];
+        if (s.putting) return SVTME_ERR_BAD_ARG; // two puts of one key at the same time
+        s.used            = true;
+        s.putting         = true; // reserved: other puts leave the slot alone, submits do not see it yet
+        s.release_pending = false;
+        s.key             = key;
+        wait_upload       = s.uploaded;
+        ring              = e->next_upload++ % e->n_upload;
     }
-    Slot &s = e->slots[si];
-    for (int m = 0; m < 4; ++m) // rewrite after the readers
-        if (s.used && s.read_recorded[m]) HIP_TRY(hipStreamWaitEvent(e->s_store, s.last_read[m], 0));
-    if (s.used) HIP_TRY(hipEventSynchronize(s.ready)); // the pinned staging buffer of this slot is free again
-    s.used = true;
-    s.release_pending = false;
-    s.key = key;
+    Slot &s = e->slots[si]; // (the vector never grows after svtme_create)
+    auto  give_up = [&](int code) {
+        std::lock_guard<std::mutex> lock(e->mu);
+        s.putting = false;
+        if (fresh) s.used = false;
+        return code;
+    };
+    // ---- outside the lock: the slot's staging buffer is free once its previous upload has run, whether or not the slot
+    // was in use in between; then the frame copy
+    const uint8_t *src        = luma;
+    uint32_t       src_stride = stride;
+    size_t         bytes      = (size_t)(height - 1) * stride + width;
+    if (!pinned) {
+        if (wait_upload && hipEventSynchronize(s.ready) != hipSuccess) return give_up(SVTME_ERR_DEVICE);
+        if (stride == width) memcpy(s.host_stage, luma, (size_t)width * height); // one large copy: streaming stores
+        else
+            for (uint32_t y = 0; y < height; ++y) memcpy(s.host_stage + (size_t)y * width, luma + (size_t)y * stride, width);
+        src        = s.host_stage;
+        src_stride = width;
+        bytes      = (size_t)width * height;
+    }
+    // ---- enqueue: one linear DMA (a pitched copy into the padded plane runs at a quarter of the link's rate), then the
+    // store kernels place the rows into the padded planes while they decimate
+    std::lock_guard<std::mutex> lock(e->mu);
+    const hipStream_t ss = e->s_store[ring];
+    hipError_t        err = hipSuccess;
+    for (int m = 0; m < 4 && err == hipSuccess; ++m) // rewrite after the readers
+        if (s.read_recorded[m]) err = hipStreamWaitEvent(ss, s.last_read[m], 0);
+    if (err == hipSuccess && s.uploaded) err = hipStreamWaitEvent(ss, s.ready, 0); // and after the slot's previous build (other ring)
     s.picture_number = picture_number;
-    s.width = width;
-    s.height = height;
-    size_t bytes;
-    layout_planes(s.mem, width, height, &s.pic, &bytes);
-    if (stride == width) memcpy(s.host_stage, luma, (size_t)width * height); // one large copy: streaming stores
-    else
-        for (uint32_t y = 0; y < height; ++y) memcpy(s.host_stage + (size_t)y * width, luma + (size_t)y * stride, width);
-    // one linear DMA (a pitched copy into the padded plane runs at a quarter of the link's rate), then the store kernels
-    // place the rows into the padded plane while they decimate
-    HIP_TRY(hipMemcpyAsync(e->d_upload, s.host_stage, (size_t)width * height, hipMemcpyHostToDevice, e->s_store));
-    launch_store_build(e->d_upload, (int)width, s.pic, 1, e->s_store);
-    HIP_TRY(hipGetLastError());
-    HIP_TRY(hipEventRecord(s.ready, e->s_store));
+    s.width          = width;
+    s.height         = height;
+    size_t plane_bytes;
+    layout_planes(s.mem, width, height, &s.pic, &plane_bytes);
+    if (err == hipSuccess) err = hipMemcpyAsync(e->d_upload[ring], src, bytes, hipMemcpyHostToDevice, ss);
+    if (err == hipSuccess) {
+        launch_store_build(e->d_upload[ring], (int)src_stride, s.pic, 1, ss);
+        err = hipGetLastError();
+    }
+    if (err == hipSuccess) err = hipEventRecord(s.ready, ss);
+    s.putting = false;
+    if (err != hipSuccess) {
+        fprintf(stderr, "svtme: svtme_store_put: %s\n", hipGetErrorString(err));
+        (void)hipStreamSynchronize(ss); // nothing of a failed put stays in flight
+        if (fresh) s.used = false;
+        return SVTME_ERR_DEVICE;
+    }
+    s.uploaded = true;
     s.ready_seen[0] = s.ready_seen[1] = s.ready_seen[2] = s.ready_seen[3] = false;
+    return SVTME_OK;
+}
+
+extern "C" int svtme_store_put(svtme_engine *e, uint64_t key, uint64_t picture_number, const uint8_t *luma, uint32_t stride,
+                               uint32_t width, uint32_t height) {
+    return store_put_impl(e, key, picture_number, luma, stride, width, height, false);
+}
+
+extern "C" int svtme_store_put_pinned(svtme_engine *e, uint64_t key, uint64_t picture_number, const uint8_t *luma, uint32_t stride,
+                                      uint32_t width, uint32_t height) {
+    return store_put_impl(e, key, picture_number, luma, stride, width, height, true);
+}
+
+extern "C" int svtme_store_wait(svtme_engine *e, uint64_t key) {
+    if (!e) return SVTME_ERR_BAD_ARG;
+    hipEvent_t ready;
+    {
+        std::lock_guard<std::mutex> lock(e->mu);
+        const int si = find_slot(e, key);
+        if (si < 0) return SVTME_ERR_NOT_FOUND;
+        ready = e->slots[si].ready;
+    }
+    DEVICE_OR_FAIL(e->cfg.device);
+    HIP_TRY(hipEventSynchronize(ready));
+    return SVTME_OK;
+}
+
+extern "C" int svtme_host_register(svtme_engine *e, void *ptr, size_t bytes) {
+    if (!e || !ptr || !bytes) return SVTME_ERR_BAD_ARG;
+    DEVICE_OR_FAIL(e->cfg.device);
+    const hipError_t err = hipHostRegister(ptr, bytes, hipHostRegisterDefault);
+    if (err == hipErrorHostMemoryAlreadyRegistered) {
+        (void)hipGetLastError();
+        return SVTME_OK;
+    }
+    if (err != hipSuccess) { // e.g. a virtual machine whose driver cannot lock user pages: use svtme_host_alloc there
+        (void)hipGetLastError();
+        return SVTME_ERR_UNSUPPORTED;
+    }
+    return SVTME_OK;
+}
+
+extern "C" int svtme_host_alloc(svtme_engine *e, size_t bytes, void **out) {
+    if (!e || !bytes || !out) return SVTME_ERR_BAD_ARG;
+    DEVICE_OR_FAIL(e->cfg.device);
+    void *ptr = nullptr;
+    if (hipHostMalloc(&ptr, bytes, hipHostMallocDefault) != hipSuccess || !ptr) {
+        (void)hipGetLastError();
+        return SVTME_ERR_NO_RESOURCES;
+    }
+    *out = ptr;
+    return SVTME_OK;
+}
+
+extern "C" int svtme_host_free(svtme_engine *e, void *ptr) {
+    if (!e || !ptr) return SVTME_ERR_BAD_ARG;
+    DEVICE_OR_FAIL(e->cfg.device);
+    HIP_TRY(hipHostFree(ptr));
+    return SVTME_OK;
+}
+
+extern "C" int svtme_host_unregister(svtme_engine *e, void *ptr) {
+    if (!e || !ptr) return SVTME_ERR_BAD_ARG;
+    DEVICE_OR_FAIL(e->cfg.device);
+    HIP_TRY(hipHostUnregister(ptr));
     return SVTME_OK;
 }
 
@@ -460,23 +593,16 @@ extern "C" int svtme_picture_submit(svtme_engine *e, const svtme_picture *pic, s
     const unsigned    n_sm = e->cfg.search_streams ? e->cfg.search_streams : 3;
     const unsigned    mi = e->next_me++ % n_sm;
     const hipStream_t sm = e->s_me[mi];
-    for (int si : used)
-        if (!e->slots[si].ready_seen[mi]) { // later pictures on this stream are ordered behind this wait anyway
-            HIP_TRY(hipStreamWaitEvent(sm, e->slots[si].ready, 0));
-            e->slots[si].ready_seen[mi] = true;
-        }
-    HIP_TRY(hipEventRecord(f->ev[0], sm));
-    // (the HME records and the counters are zero: allocated so, and every picture's last search kernel clears them again)
+    // results back to pinned host memory on the copy stream, so that the next picture's kernels do not wait for PCIe
+    // (with three search streams the copy stays on the picture's own stream: the other two keep the GPU busy, and
+    // the process stays within four hardware queues)
+    const hipStream_t sc = (e->copy_on_search_stream < 0 ? n_sm >= 3 : e->copy_on_search_stream != 0) ? sm : e->s_copy;
     const bool  kt = e->cfg.kernel_timing != 0;
-    hipEvent_t  hme_marks[2] = {kt ? f->ev[1] : nullptr, kt ? f->ev[2] : nullptr};
-    hipEvent_t  me_marks[3]  = {kt ? f->ev[3] : nullptr, kt ? f->ev[4] : nullptr, f->ev[5]};
     f->kernel_timing = kt;
-    launch_hme(p, sm, hme_marks);
-    // (the last ME mark is recorded after the optional tail kernel, so that it ends the picture's kernels either way)
-    hipEvent_t last_mark = me_marks[2];
     f->tail = pic->tail.enable != 0;
+    // tail.enable == 2: the host wants finished results only, the best SAD / MV planes (the end of the block) stay on the device
+    f->skip_search_arrays = f->tail && pic->tail.enable == 2;
     if (f->tail) {
-        me_marks[2]    = nullptr;
         p.tail         = pic->tail;
         p.t_hme_sad    = reinterpret_cast<unsigned long long *>(f->d_res + f->off_thme);
         p.t_mv_array   = reinterpret_cast<uint32_t *>(f->d_res + f->off_tmv);
@@ -488,28 +614,49 @@ extern "C" int svtme_picture_submit(svtme_engine *e, const svtme_picture *pic, s
         p.t_zero_begin = f->d_res + f->off_thme;
         p.t_zero_bytes = f->tail_end - f->off_thme;
     }
-    launch_me(p, sm, me_marks);
-    if (f->tail) {
-        launch_tail(p, sm);
-        HIP_TRY(hipEventRecord(last_mark, sm));
+    // ---- everything the picture puts on its streams. (The HME records and the counters are zero on entry: allocated so,
+    // and every picture's last search kernel clears them again.)
+    auto enqueue = [&]() -> hipError_t {
+        hipError_t err;
+        for (int si : used)
+            if (!e->slots[si].ready_seen[mi]) { // later pictures on this stream are ordered behind this wait anyway
+                if ((err = hipStreamWaitEvent(sm, e->slots[si].ready, 0)) != hipSuccess) return err;
+                e->slots[si].ready_seen[mi] = true;
+            }
+        if ((err = hipEventRecord(f->ev[0], sm)) != hipSuccess) return err;
+        hipEvent_t hme_marks[2] = {kt ? f->ev[1] : nullptr, kt ? f->ev[2] : nullptr};
+        // (the last ME mark is recorded after the optional tail kernel, so that it ends the picture's kernels either way)
+        hipEvent_t me_marks[3] = {kt ? f->ev[3] : nullptr, kt ? f->ev[4] : nullptr, f->tail ? nullptr : f->ev[5]};
+        launch_hme(p, sm, hme_marks);
+        launch_me(p, sm, me_marks);
+        if (f->tail) {
+            launch_tail(p, sm);
+            if ((err = hipEventRecord(f->ev[5], sm)) != hipSuccess) return err;
+        }
+        if ((err = hipGetLastError()) != hipSuccess) return err;
+        if (sc != sm && (err = hipStreamWaitEvent(sc, f->ev[5], 0)) != hipSuccess) return err;
+        const size_t c1 = f->skip_search_arrays ? f->tail_end : f->res_bytes;
+        if ((err = hipMemcpyAsync(f->h_res, f->d_res, c1, hipMemcpyDeviceToHost, sc)) != hipSuccess) return err;
+        return hipEventRecord(f->ev[6], sc);
+    };
+    const hipError_t enq_err = enqueue();
+    if (enq_err != hipSuccess) {
+        // Part of the picture may be on its stream already. The flight and the slots are not accounted for yet, so nothing
+        // may stay in flight: drain the streams, then restore what the next picture expects of this buffer (zeroed HME
+        // records and counters), and report.
+        fprintf(stderr, "svtme: svtme_picture_submit: %s\n", hipGetErrorString(enq_err));
+        (void)hipStreamSynchronize(sm);
+        if (sc != sm) (void)hipStreamSynchronize(sc);
+        (void)hipMemset(f->d_hme, 0, e->max_b64 * SVTME_MAX_LISTS * SVTME_MAX_REFS * sizeof(HmeRefOut) + SVTME_OPS_BYTES);
+        (void)hipGetLastError();
+        return SVTME_ERR_DEVICE;
     }
-    HIP_TRY(hipGetLastError());
     for (int si : used) { // ev[5] was recorded behind the picture's last kernel
         e->slots[si].last_read[mi]     = f->ev[5];
         e->slots[si].read_recorded[mi] = true;
         e->slots[si].readers++;
     }
     f->stream_index = mi;
-    // results back to pinned host memory on the copy stream, so that the next picture's kernels do not wait for PCIe
-    // (with three search streams the copy stays on the picture's own stream: the other two keep the GPU busy, and
-    // the process stays within four hardware queues)
-    const hipStream_t sc = n_sm >= 3 ? sm : e->s_copy;
-    if (sc != sm) HIP_TRY(hipStreamWaitEvent(sc, f->ev[5], 0));
-    // tail.enable == 2: the host wants finished results only, the best SAD / MV planes (the end of the block) stay on the device
-    f->skip_search_arrays = f->tail && pic->tail.enable == 2;
-    const size_t c1 = f->skip_search_arrays ? f->tail_end : f->res_bytes;
-    HIP_TRY(hipMemcpyAsync(f->h_res, f->d_res, c1, hipMemcpyDeviceToHost, sc));
-    HIP_TRY(hipEventRecord(f->ev[6], sc));
     f->busy   = true;
     f->waited = false;
     f->n_b64  = (uint32_t)n_b64;

@@ -115,7 +115,8 @@ EXPORTS = ("svtme_version", "svtme_derive_controls", "svtme_derive_tf_controls",
            "svtme_input_resolution", "svtme_create", "svtme_destroy",
            "svtme_store_put", "svtme_store_release", "svtme_store_read", "svtme_picture_submit", "svtme_picture_wait",
            "svtme_picture_done", "svtme_picture_timing", "svtme_picture_ops", "svtme_unpack_b64",
-           "svtme_picture_search_static")
+           "svtme_picture_search_static", "svtme_store_put_pinned", "svtme_store_wait", "svtme_host_register",
+           "svtme_host_unregister", "svtme_host_alloc", "svtme_host_free")
 STATIC_MAX_B64 = 2040
 
 
@@ -146,6 +147,12 @@ def load_library():
     lib.svtme_destroy.restype = None
     lib.svtme_store_put.argtypes = [C.c_void_p, C.c_uint64, C.c_uint64, C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32]
     lib.svtme_store_release.argtypes = [C.c_void_p, C.c_uint64]
+    lib.svtme_store_put_pinned.argtypes = lib.svtme_store_put.argtypes
+    lib.svtme_store_wait.argtypes = [C.c_void_p, C.c_uint64]
+    lib.svtme_host_register.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
+    lib.svtme_host_unregister.argtypes = [C.c_void_p, C.c_void_p]
+    lib.svtme_host_alloc.argtypes = [C.c_void_p, C.c_size_t, C.POINTER(C.c_void_p)]
+    lib.svtme_host_free.argtypes = [C.c_void_p, C.c_void_p]
     lib.svtme_store_read.argtypes = [C.c_void_p, C.c_uint64, C.c_int, C.c_void_p, C.c_size_t] + [C.POINTER(C.c_uint32)] * 4
     lib.svtme_picture_submit.argtypes = [C.c_void_p, C.POINTER(Picture), C.POINTER(C.c_uint64)]
     lib.svtme_picture_wait.argtypes = [C.c_void_p, C.c_uint64, C.POINTER(Results)]
@@ -218,6 +225,45 @@ class Engine:
         rc = self.lib.svtme_store_put(self.h, key, picture_number, luma.ctypes.data, w, w, h)
         if rc:
             raise SvtmeError(rc, "svtme_store_put")
+
+    def host_alloc(self, shape):
+        """A uint8 numpy array over page-locked host memory (svtme_host_alloc); give it back with host_free(array)."""
+        n = int(np.prod(shape))
+        p = C.c_void_p()
+        rc = self.lib.svtme_host_alloc(self.h, n, C.byref(p))
+        if rc:
+            raise SvtmeError(rc, "svtme_host_alloc")
+        return np.ctypeslib.as_array((C.c_uint8 * n).from_address(p.value)).reshape(shape)
+
+    def host_free(self, array):
+        rc = self.lib.svtme_host_free(self.h, array.ctypes.data)
+        if rc:
+            raise SvtmeError(rc, "svtme_host_free")
+
+    def host_register(self, array):
+        """Page-locks a numpy array's memory for store_put_pinned; keep the array alive until host_unregister."""
+        rc = self.lib.svtme_host_register(self.h, array.ctypes.data, array.nbytes)
+        if rc:
+            raise SvtmeError(rc, "svtme_host_register")
+
+    def host_unregister(self, array):
+        rc = self.lib.svtme_host_unregister(self.h, array.ctypes.data)
+        if rc:
+            raise SvtmeError(rc, "svtme_host_unregister")
+
+    def store_put_pinned(self, key, picture_number, luma):
+        """luma: a 2-D uint8 view whose rows are contiguous (any row stride); copied by DMA as it lies, after the call
+        returns: leave it unchanged until store_wait(key) or a wait of a picture that reads it."""
+        h, w = luma.shape
+        assert luma.dtype == np.uint8 and luma.strides[1] == 1
+        rc = self.lib.svtme_store_put_pinned(self.h, key, picture_number, luma.ctypes.data, luma.strides[0], w, h)
+        if rc:
+            raise SvtmeError(rc, "svtme_store_put_pinned")
+
+    def store_wait(self, key):
+        rc = self.lib.svtme_store_wait(self.h, key)
+        if rc:
+            raise SvtmeError(rc, "svtme_store_wait")
 
     def store_release(self, key):
         rc = self.lib.svtme_store_release(self.h, key)

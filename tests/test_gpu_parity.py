@@ -410,6 +410,89 @@ def test_device_store_planes_match_oracle():
         eng.close()
 
 
+def test_zero_copy_put_from_a_strided_page_locked_buffer_builds_the_same_planes():
+    """svtme_store_put_pinned: rows fetched by DMA as they lie in the caller's buffer (the encoder's padded input buffer:
+    origin (72, 72), stride = width + 144) in page-locked memory from svtme_host_alloc; same planes as the oracle's, also
+    when the same slot is put again, from memory that is not page-locked, and with a stride the strided copy does not
+    take (falls back to packing). svtme_host_register either works or reports that this machine cannot lock user pages."""
+    frames, pics, rc = support.make_job(200, 136, 3, 8, seed=5)
+    _, planes = refio.run_oracle(frames, [], 8, mode=refio.MODE_PLANES, ref_counts=rc)
+    eng = svtme.Engine(256, 192, store_slots=4)
+    pool = eng.host_alloc((3, 136 + 144, 200 + 144))  # three "y8b" buffers with their padding
+    pool[:] = 0x5A
+    pool[:, 72:72 + 136, 72:72 + 200] = frames
+    odd = np.full((136, 200 + 1000), 0x33, np.uint8)
+    odd[:, :200] = frames[1]
+    pageable = np.full((136 + 144, 200 + 144), 0x11, np.uint8)
+    pageable[72:72 + 136, 72:72 + 200] = frames[0]
+    try:
+        try:
+            eng.host_register(pageable)
+            eng.host_register(pageable)  # registering twice is not an error
+            eng.host_unregister(pageable)
+        except svtme.SvtmeError as ex:
+            assert ex.code == svtme.ERR_UNSUPPORTED
+        eng.store_put_pinned(30, 0, pageable[72:72 + 136, 72:72 + 200])
+        assert np.array_equal(eng.store_read(30, 2, frames[0].shape), planes[0][2])
+        eng.store_release(30)
+        for i in range(3):
+            eng.store_put_pinned(20 + i, i, pool[i, 72:72 + 136, 72:72 + 200])
+        for i in range(3):
+            eng.store_wait(20 + i)
+            for level in range(3):
+                assert np.array_equal(eng.store_read(20 + i, level, frames[i].shape), planes[i][level]), (i, level)
+        eng.store_put_pinned(20, 0, pool[2, 72:72 + 136, 72:72 + 200])  # the temporal filter's rewrite
+        assert np.array_equal(eng.store_read(20, 1, frames[0].shape), planes[2][1])
+        eng.store_put_pinned(21, 0, odd[:, :200])  # stride 1200: too far apart for one strided copy
+        assert np.array_equal(eng.store_read(21, 2, frames[0].shape), planes[1][2])
+        with pytest.raises(svtme.SvtmeError) as ei:
+            eng.store_wait(99)
+        assert ei.value.code == svtme.ERR_NOT_FOUND
+    finally:
+        eng.host_free(pool)
+        eng.close()
+
+
+def test_concurrent_puts_and_searches_from_several_threads():
+    """Four threads put their own sources and search them at the same time (the frame copies run outside the engine's
+    lock): every picture's results equal a quiet run's."""
+    import threading
+    jobs = [support.make_job(256, 128, 5, 8, seed=40 + t) for t in range(4)]
+    want = [support.run_engine_job(fr, pics, 8) for fr, pics, _ in jobs]
+    eng = svtme.Engine(256, 128, store_slots=24, max_in_flight=8)
+    ctrl = svtme.derive_controls(8, 256, 128)
+    got, errs = [None] * 4, []
+
+    def work(t):
+        try:
+            fr, pics, _ = jobs[t]
+            for rep in range(3):
+                for i in range(len(fr)):
+                    eng.store_put(1000 * t + i, i, fr[i])
+                outs = []
+                for p in pics:
+                    pic = eng.make_picture(256, 128, p.poc, p.temporal_layer, p.is_ref, p.refs, ctrl, key_of=lambda poc: 1000 * t + poc)
+                    outs.append(eng.run_picture(pic))
+                got[t] = outs
+        except Exception as ex:  # noqa: BLE001
+            errs.append((t, ex))
+
+    try:
+        th = [threading.Thread(target=work, args=(t,)) for t in range(4)]
+        for x in th:
+            x.start()
+        for x in th:
+            x.join()
+    finally:
+        eng.close()
+    assert not errs, errs
+    for t in range(4):
+        for a, b in zip(want[t], got[t]):
+            for f in ("best_sad", "best_mv", "zz_sad", "sr_divisor"):
+                assert np.array_equal(a[f], b[f]), (t, f)
+            assert a["search_results"].tobytes() == b["search_results"].tobytes()
+
+
 def test_pictures_in_flight_and_unpack():
     """Several pictures queued before the first wait give the same results as one at a time; svtme_unpack_b64
     copies the MeContext-shaped arrays of one block."""
