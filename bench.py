@@ -34,18 +34,20 @@ import numpy as np  # noqa: E402
 # search, up to 4+3 references (preset 3 = MRP level 3), the single-GPU 1080p configuration the metric is quoted on.
 WORKLOADS = {
     "1080p_ra_m3": dict(width=1920, height=1080, enc_mode=3, structure="ra", n_frames=17, bit_depth=8),
-    "1080p_ra_m8": dict(width=1920, height=1080, enc_mode=8, structure="ra", n_frames=17, bit_depth=8),
-    "720p_ld_m12": dict(width=1280, height=720, enc_mode=12, structure="ldp", n_frames=17, bit_depth=8),
+    # "batch": pictures per svtme_pictures_submit call. The fast presets are bound by per-launch costs, which a mini-GOP
+    # submitted at once pays once; the others gain nothing from it (measured: profiles/r02_batch_sweep.txt)
+    "1080p_ra_m8": dict(width=1920, height=1080, enc_mode=8, structure="ra", n_frames=17, bit_depth=8, batch=16),
+    "720p_ld_m12": dict(width=1280, height=720, enc_mode=12, structure="ldp", n_frames=17, bit_depth=8, batch=16),
     "4k_ra_m8": dict(width=3840, height=2160, enc_mode=8, structure="ra", n_frames=17, bit_depth=10),
     "8k_ra_m2": dict(width=7680, height=4320, enc_mode=2, structure="ra", n_frames=17, bit_depth=8),
     # temporal-filter searches (ME_MCTF): a 7-frame window, the centre frame searched in each of its 6 neighbours; one
     # "picture" = one (centre, neighbour) pair. tf = (tf_ctrls.hme_me_level, tf_ctrls.me_exit_th): level 0 is what presets
     # up to M5 use, level 2 with the 16x16 exit threshold what the fast presets use (EbEncHandle.c:2556-2876).
     "1080p_tf_l0": dict(width=1920, height=1080, enc_mode=0, structure="tf", n_frames=7, bit_depth=8, tf=(0, 0)),
-    "1080p_tf_l2": dict(width=1920, height=1080, enc_mode=8, structure="tf", n_frames=7, bit_depth=8, tf=(2, 256)),
+    "1080p_tf_l2": dict(width=1920, height=1080, enc_mode=8, structure="tf", n_frames=7, bit_depth=8, tf=(2, 256), batch=6),
     # first-pass ME of a two-pass encode (ME_FIRST_PASS): every frame searches the previous and the first frame;
     # fp = (ipp_pass_ctrls.bypass_zz_check, ipp_pass_ctrls.reduce_me_search)
-    "1080p_first_pass": dict(width=1920, height=1080, enc_mode=8, structure="fp", n_frames=17, bit_depth=8, fp=(0, 0)),
+    "1080p_first_pass": dict(width=1920, height=1080, enc_mode=8, structure="fp", n_frames=17, bit_depth=8, fp=(0, 0), batch=16),
 }
 STAGES = ["zz_centre", "prehme", "hme_l0", "hme_l1", "hme_l2", "integer_search"]
 # Packed-SAD peak of gfx950: 256 CUs x 4 SIMDs x 16 lanes/clk (v_sad_u8 / v_qsad_pk_u16_u8 issue at a quarter of the
@@ -112,7 +114,9 @@ def main():
     ap.add_argument("--steps", type=int, default=120)
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--workload", default="1080p_ra_m3", choices=sorted(WORKLOADS))
-    ap.add_argument("--in-flight", type=int, default=6)
+    ap.add_argument("--in-flight", type=int, default=0, help="pictures outstanding at most (default: 6, or 3 batches)")
+    ap.add_argument("--batch", type=int, default=0,
+                    help="pictures per svtme_pictures_submit call (they share their kernel launches); 0 = the workload's default")
     ap.add_argument("--search-streams", type=int, default=3, choices=[1, 2, 3])
     ap.add_argument("--kernel-steps", type=int, default=8, help="steps of the one-stream pass that times the kernels")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -149,6 +153,12 @@ def main():
 
     import svtme
     wl = dict(WORKLOADS[args.workload], name=args.workload)
+    if args.batch <= 0:
+        args.batch = wl.get("batch", 1)
+    args.batch = min(args.batch, svtme.MAX_BATCH)
+    if args.in_flight <= 0:
+        args.in_flight = max(6, 3 * args.batch)
+    args.in_flight = max(args.in_flight, args.batch)
     frames, pics = make_pictures(wl, seed=1000 + rank)
     n, h, w = frames.shape
     tf, fp = wl.get("tf"), wl.get("fp")
@@ -219,15 +229,24 @@ def main():
         """k steps back to back: at most --in-flight pictures outstanding, also across step boundaries (mini-GOPs follow
         each other without a pause, as they do in the encoder); everything has been waited for on return."""
         e, ds = e or eng, ds or descs
-        tickets = []
+        tickets, group = [], []
+
+        def flush():
+            while len(tickets) + len(group) > args.in_flight:
+                finish(e, tickets.pop(0), collect)
+            tickets.extend(e.submit_batch(group) if len(group) > 1 else [e.submit(group[0])])
+            group.clear()
+
         for step in range(k):
             ks = step % KEY_SETS
             for i, d in enumerate(descs_alt[ks] if upload else ds):
-                if len(tickets) == args.in_flight:
-                    finish(e, tickets.pop(0), collect)
                 if upload:
                     put_sources(e, i, ks)
-                tickets.append(e.submit(d))
+                group.append(d)
+                if len(group) == args.batch:
+                    flush()
+        if group:
+            flush()
         while tickets:
             finish(e, tickets.pop(0), collect)
 
@@ -332,7 +351,7 @@ def main():
             "kernels": {k_: {"avg_ms": v[1], "ops_per_launch": v[0], "tops": v[0] / (v[1] * 1e-3) / 1e12 if v[1] > 0 else 0.0}
                         for k_, v in kernels.items()},
             "picture_kernels_ms_in_timed_region": float(ms_shared[5]),  # first kernel start to last kernel end
-            "search_streams": args.search_streams, "device_tail": (2 if args.device_tail_only else 1) if tail is not None else 0,
+            "search_streams": args.search_streams, "pictures_per_submit": args.batch, "in_flight": args.in_flight, "device_tail": (2 if args.device_tail_only else 1) if tail is not None else 0,
             "store_put_pictures_per_s": upload_pps,
             "with_upload": ({"mode": args.upload_mode, "sources_put_per_step": n,
                              "note": "every source picture of a step is put into the device store once inside the timed region"}

@@ -315,6 +315,15 @@ typedef uint64_t svtme_ticket;
  * Replaces the per-b64 calls motion_estimation_b64 -> init_me_hme_data / hme_b64 /
  * hme_prune_ref_and_adjust_sr / integer_search_b64 (EbMotionEstimation.c:2954-2970). */
 int svtme_picture_submit(svtme_engine *e, const svtme_picture *pic, svtme_ticket *ticket);
+/* The same for several pictures at once, which then share their kernel launches: the per-launch costs (launch latency,
+ * the under-filled tail of every kernel) are paid once per batch instead of once per picture, which is what bounds the
+ * fast presets. The natural batch is what send_picture_out() posts back to back for one mini-GOP
+ * (EbPictureDecisionProcess.c:6842-6874). The pictures must have one size, one set of controls, one me_type and one
+ * tail setting (SVTME_ERR_BAD_ARG otherwise; submit such pictures in batches of their own); they may differ in everything
+ * else. tickets[i] belongs to pics[i]; each picture is waited for and handed back on its own, and the results of all of
+ * them arrive together. Needs n free pictures in flight. */
+#define SVTME_MAX_BATCH 32
+int svtme_pictures_submit(svtme_engine *e, const svtme_picture *pics, uint32_t n, svtme_ticket *tickets);
 /* Blocks until the picture's results are in host memory. */
 int svtme_picture_wait(svtme_engine *e, svtme_ticket ticket, svtme_results *out);
 /* Returns the result buffers of a waited picture to the engine. */
@@ -346,8 +355,9 @@ int svtme_picture_search_static(svtme_engine *e, const svtme_picture *pic, void 
 /* Device time of a waited picture's kernels in milliseconds (HIP events on the stream the kernels run on):
  * [0] HME pre-HME + level-0 kernel (or the serial HME kernel), [1] HME level-1/2 kernel, [2] integer-search plan,
  * [3] integer-search kernel, [4] integer-search finish, [5] first kernel start to last kernel end,
- * [6] the same up to the end of the result copy, [7] 0. [0]..[4] are 0 unless the engine was created with
- * kernel_timing = 1. Diagnostic only. */
+ * [6] the same up to the end of the result copy, [7] the number of pictures in the picture's batch. [0]..[4] are 0 unless
+ * the engine was created with kernel_timing = 1. The pictures of a batch share their launches: each reports an equal
+ * share (1 / [7]) of the batch's durations. Diagnostic only. */
 int svtme_picture_timing(svtme_engine *e, svtme_ticket ticket, float ms[8]);
 
 /* Number of abs-diff-accumulate operations the waited picture's searches performed (after clipping, early exits

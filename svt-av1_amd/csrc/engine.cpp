@@ -96,10 +96,18 @@ struct Flight {
     }
     size_t off_thme = 0, off_tmv = 0, off_tdist = 0, off_tstat = 0, off_tcand = 0, off_ttot = 0, off_tdo = 0, tail_end = 0;
     uint32_t n_ref[2] = {0, 0};
-    unsigned stream_index = 0; // search stream the picture runs on
     bool   tail = false, skip_search_arrays = false;
-    // start, after each of the 2 HME and 3 ME kernels, after D2H
-    hipEvent_t           ev[7] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    int    batch = -1; // BatchRec the picture was submitted with
+    int    param = -1; // its record in the parameter ring
+};
+
+// The pictures of one svtme_pictures_submit call: they share their launches, hence their stream and events.
+struct BatchRec {
+    bool     used = false, kernel_timing = false;
+    int      n = 0, members_left = 0; // pictures; pictures not yet handed back with svtme_picture_done
+    unsigned stream_index = 0; // search stream the batch runs on
+    // start, after each of the 2 HME and 3 ME kernels, after the result copies
+    hipEvent_t ev[7] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
 };
 
 } // namespace
@@ -146,6 +154,12 @@ struct svtme_engine {
     int                 copy_on_search_stream = -1; // -1: with three search streams only; 0 / 1: diagnostic override
     std::vector<Slot>   slots;
     std::vector<Flight> flights;
+    std::vector<BatchRec> batches;
+    // the pictures' parameter records: a ring in device memory and its pinned host mirror; a batch takes a run of
+    // neighbouring records; the record behind the ring belongs to svtme_picture_search_static
+    PicParams          *d_params = nullptr, *h_params = nullptr;
+    std::vector<char>   param_busy;
+    unsigned            param_head = 0;
     svtme_ticket        next_ticket = 1;
     size_t              slot_bytes = 0, max_b64 = 0;
     uint8_t            *d_upload[2] = {nullptr, nullptr}; // un-padded luma of the pictures being put (a store stream orders the reuse of its buffer)
@@ -209,8 +223,6 @@ void free_flight(Flight &f) {
     if (f.d_keys) (void)hipFree(f.d_keys);
     if (f.d_res) (void)hipFree(f.d_res);
     if (f.h_res) (void)hipHostFree(f.h_res);
-    for (auto &ev : f.ev)
-        if (ev) (void)hipEventDestroy(ev);
     f = Flight();
 }
 
@@ -237,8 +249,10 @@ extern "C" int svtme_create(const svtme_config *cfg, svtme_engine **out) {
     };
     e->static_scratch = static_scratch_of(cfg->device);
     if (!e->static_scratch) return fail(SVTME_ERR_DEVICE);
+    if (const char *v = getenv("SVTME_UPLOAD_RINGS")) e->n_upload = atoi(v) == 2 ? 2 : 1;
+    // (only the streams that will carry work: every stream beyond the hardware queues shares one with another stream)
     if (hipStreamCreateWithFlags(&e->s_store[0], hipStreamNonBlocking) != hipSuccess ||
-        hipStreamCreateWithFlags(&e->s_store[1], hipStreamNonBlocking) != hipSuccess ||
+        (e->n_upload == 2 && hipStreamCreateWithFlags(&e->s_store[1], hipStreamNonBlocking) != hipSuccess) ||
         hipStreamCreateWithFlags(&e->s_me[0], hipStreamNonBlocking) != hipSuccess ||
         hipStreamCreateWithFlags(&e->s_me[1], hipStreamNonBlocking) != hipSuccess ||
         hipStreamCreateWithFlags(&e->s_me[2], hipStreamNonBlocking) != hipSuccess ||
@@ -252,8 +266,7 @@ extern "C" int svtme_create(const svtme_config *cfg, svtme_engine **out) {
     e->upload_bytes = (size_t)(cfg->max_width + kMaxExtraStride) * cfg->max_height;
     // One upload stream by default: a second one (puts alternating, one DMA overlapping the other put's kernels) raises the
     // put-only rate at 4K from 5.6 k to 6.2 k pictures/s but lowers the rate of searches that run beside the puts (a fifth
-    // active stream on four hardware queues). SVTME_UPLOAD_RINGS=2 selects it.
-    if (const char *v = getenv("SVTME_UPLOAD_RINGS")) e->n_upload = atoi(v) == 2 ? 2 : 1;
+    // active stream on four hardware queues). SVTME_UPLOAD_RINGS=2 selects it (read above, before the streams are made).
     if (const char *v = getenv("SVTME_COPY_ON_SEARCH_STREAM")) e->copy_on_search_stream = atoi(v) != 0; // diagnostic
     for (unsigned i = 0; i < e->n_upload; ++i)
         if (hipMalloc((void **)&e->d_upload[i], e->upload_bytes) != hipSuccess) return fail(SVTME_ERR_NO_RESOURCES);
@@ -274,9 +287,17 @@ extern "C" int svtme_create(const svtme_config *cfg, svtme_engine **out) {
             hipHostMalloc((void **)&f.h_res, f.res_bytes, hipHostMallocDefault) != hipSuccess)
             return fail(SVTME_ERR_NO_RESOURCES);
         if (hipMemset(f.d_hme, 0, n * sizeof(HmeRefOut) + SVTME_OPS_BYTES) != hipSuccess) return fail(SVTME_ERR_DEVICE);
-        for (auto &ev : f.ev)
-            if (hipEventCreate(&ev) != hipSuccess) return fail(SVTME_ERR_NO_RESOURCES);
     }
+    e->batches.resize(cfg->max_in_flight);
+    for (auto &b : e->batches)
+        for (auto &ev : b.ev)
+            if (hipEventCreate(&ev) != hipSuccess) return fail(SVTME_ERR_NO_RESOURCES);
+    const size_t n_params = 2 * (size_t)cfg->max_in_flight + SVTME_MAX_BATCH;
+    e->param_busy.assign(n_params, 0);
+    if (hipMalloc((void **)&e->d_params, (n_params + 1) * sizeof(PicParams)) != hipSuccess ||
+        hipHostMalloc((void **)&e->h_params, (n_params + 1) * sizeof(PicParams), hipHostMallocDefault) != hipSuccess)
+        return fail(SVTME_ERR_NO_RESOURCES);
+
     *out = e;
     return SVTME_OK;
 }
@@ -297,6 +318,11 @@ extern "C" void svtme_destroy(svtme_engine *e) {
     for (auto d : e->d_upload)
         if (d) (void)hipFree(d);
     for (auto &f : e->flights) free_flight(f);
+    for (auto &b : e->batches)
+        for (auto &ev : b.ev)
+            if (ev) (void)hipEventDestroy(ev);
+    if (e->d_params) (void)hipFree(e->d_params);
+    if (e->h_params) (void)hipHostFree(e->h_params);
     for (auto sm : e->s_me)
         if (sm) (void)hipStreamDestroy(sm);
     for (auto ss : e->s_store)
@@ -488,8 +514,8 @@ extern "C" int svtme_store_read(svtme_engine *e, uint64_t key, int level, uint8_
     return SVTME_OK;
 }
 
-extern "C" int svtme_picture_submit(svtme_engine *e, const svtme_picture *pic, svtme_ticket *ticket) {
-    if (!e || !pic || !ticket) return SVTME_ERR_BAD_ARG;
+// What both submit forms check of one picture description before anything is touched.
+static int check_picture(const svtme_picture *pic) {
     const svtme_controls &k = pic->ctrl;
     if (pic->num_of_list_to_search < 1 || pic->num_of_list_to_search > 2 || pic->num_of_ref_pic_to_search[0] < 1 ||
         pic->num_of_ref_pic_to_search[0] > SVTME_MAX_REFS ||
@@ -515,26 +541,21 @@ extern "C" int svtme_picture_submit(svtme_engine *e, const svtme_picture *pic, s
          (pic->num_of_list_to_search == 2 &&
           (pic->tail.max_l0 < pic->num_of_ref_pic_to_search[0] || pic->tail.max_refs < pic->tail.max_l0 + pic->num_of_ref_pic_to_search[1]))))
         return SVTME_ERR_BAD_ARG;
+    return SVTME_OK;
+}
 
-    std::lock_guard<std::mutex> lock(e->mu);
-    DEVICE_OR_FAIL(e->cfg.device);
-    Flight *f = nullptr;
-    for (auto &c : e->flights)
-        if (!c.busy) {
-            f = &c;
-            break;
-        }
-    if (!f) return SVTME_ERR_NO_RESOURCES;
-
-    PicParams p;
+// The part of a picture's parameter record that follows from its description and the store: planes, reference lists,
+// distances, controls. `used` receives the store slots the picture reads (at most 1 + 2 x 4).
+static int fill_params(svtme_engine *e, const svtme_picture *pic, PicParams &p, int *used, int *n_used) {
+    const svtme_controls &k = pic->ctrl;
     memset(&p, 0, sizeof(p));
-    std::vector<int> used;
-    const int        ci = find_slot(e, pic->cur_key);
+    *n_used = 0;
+    const int ci = find_slot(e, pic->cur_key);
     if (ci < 0) return SVTME_ERR_NOT_FOUND;
     const Slot &cs = e->slots[ci];
     if (cs.width != pic->width || cs.height != pic->height) return SVTME_ERR_BAD_ARG;
     p.cur = cs.pic;
-    used.push_back(ci);
+    used[(*n_used)++] = ci;
     p.n_list   = pic->num_of_list_to_search;
     p.n_ref[0] = pic->num_of_ref_pic_to_search[0];
     p.n_ref[1] = p.n_list == 2 ? pic->num_of_ref_pic_to_search[1] : 0;
@@ -546,7 +567,7 @@ extern "C" int svtme_picture_submit(svtme_engine *e, const svtme_picture *pic, s
             p.ref[l][r] = e->slots[ri].pic;
             const int64_t d = (int64_t)pic->picture_number - (int64_t)pic->ref_picture_number[l][r];
             p.dist[l][r] = (uint16_t)(int16_t)(d < 0 ? -d : d);
-            used.push_back(ri);
+            used[(*n_used)++] = ri;
         }
     p.ctrl = k;
     p.width  = (int32_t)pic->width;
@@ -565,14 +586,6 @@ extern "C" int svtme_picture_submit(svtme_engine *e, const svtme_picture *pic, s
     p.dep_l0  = k.enable_hme_flag && k.enable_hme_level0_flag && k.enable_me_sr_adjustment && k.distance_based_hme_resizing &&
         k.reduce_hme_l0_sr_th_min && k.reduce_hme_l0_sr_th_max && p.n_ref[0] + p.n_ref[1] > 1;
     p.serial_refs = e->cfg.serial_hme != 0;
-    const size_t n_b64 = (size_t)p.b64_w * p.b64_h;
-    if (n_b64 > e->max_b64) return SVTME_ERR_BAD_ARG;
-    f->layout(n_b64, (size_t)(p.n_ref[0] + p.n_ref[1]), pic->tail.enable != 0); // never larger than the allocation (n_b64 <= max_b64)
-    f->n_ref[0] = (uint32_t)p.n_ref[0];
-    f->n_ref[1] = (uint32_t)p.n_ref[1];
-    p.hme_out        = f->d_hme;
-    p.me_jobs        = f->d_jobs;
-    p.me_keys        = f->d_keys;
     {
         // search work items per (b64, ref): 64-position column chunks x groups of 8 rows of the largest window the
         // controls allow (integer_search_b64 :1319-1345 caps the window at sa_max, rounds the width up to 8 and keeps
@@ -580,15 +593,96 @@ extern "C" int svtme_picture_submit(svtme_engine *e, const svtme_picture *pic, s
         const int w_max = (std::max<int>(k.me_sa.sa_max.width, 1) + 7) & ~7, h_max = std::max<int>(k.me_sa.sa_max.height, 3);
         p.me_max_items  = ((w_max + 63) / 64) * ((h_max + 7) / 8);
     }
-    p.best_sad       = reinterpret_cast<uint32_t *>(f->d_res + f->off_sad);
-    p.best_mv        = reinterpret_cast<uint32_t *>(f->d_res + f->off_mv);
-    p.search_results = reinterpret_cast<svtme_search_result *>(f->d_res + f->off_sr);
-    p.zz_sad         = reinterpret_cast<uint32_t *>(f->d_res + f->off_zz);
-    p.sr_divisor     = reinterpret_cast<uint32_t *>(f->d_res + f->off_div);
-    // the counters sit right behind this picture's HME records
-    const size_t hme_bytes = n_b64 * SVTME_MAX_LISTS * SVTME_MAX_REFS * sizeof(HmeRefOut);
-    p.ops            = reinterpret_cast<unsigned long long *>(reinterpret_cast<uint8_t *>(f->d_hme) + hme_bytes);
-    p.ops_out        = reinterpret_cast<unsigned long long *>(f->d_res + f->off_ops);
+    return SVTME_OK;
+}
+
+// Where a picture's kernels leave their results: `res` is the result block (device memory, or memory of the caller's /
+// pinned host memory the device writes), laid out by `f`.
+static void point_results(PicParams &p, const Flight &f, uint8_t *res, const svtme_tail &tail) {
+    p.best_sad       = reinterpret_cast<uint32_t *>(res + f.off_sad);
+    p.best_mv        = reinterpret_cast<uint32_t *>(res + f.off_mv);
+    p.search_results = reinterpret_cast<svtme_search_result *>(res + f.off_sr);
+    p.zz_sad         = reinterpret_cast<uint32_t *>(res + f.off_zz);
+    p.sr_divisor     = reinterpret_cast<uint32_t *>(res + f.off_div);
+    p.ops_out        = reinterpret_cast<unsigned long long *>(res + f.off_ops);
+    if (tail.enable) {
+        p.tail         = tail;
+        p.t_hme_sad    = reinterpret_cast<unsigned long long *>(res + f.off_thme);
+        p.t_mv_array   = reinterpret_cast<uint32_t *>(res + f.off_tmv);
+        p.t_distortion = reinterpret_cast<uint32_t *>(res + f.off_tdist);
+        p.t_stats      = reinterpret_cast<uint32_t *>(res + f.off_tstat);
+        p.t_cand_array = res + f.off_tcand;
+        p.t_total_cand = res + f.off_ttot;
+        p.t_do_ref     = res + f.off_tdo;
+        p.t_zero_begin = res + f.off_thme;
+        p.t_zero_bytes = f.tail_end - f.off_thme;
+    }
+}
+
+extern "C" int svtme_pictures_submit(svtme_engine *e, const svtme_picture *pics, uint32_t n, svtme_ticket *tickets) {
+    if (!e || !pics || !tickets || n < 1 || n > SVTME_MAX_BATCH) return SVTME_ERR_BAD_ARG;
+    for (uint32_t i = 0; i < n; ++i) {
+        const int rc = check_picture(&pics[i]);
+        if (rc != SVTME_OK) return rc;
+        // one set of launches covers the batch: one size, one set of controls, one kind of search
+        const svtme_picture &a = pics[0], &b = pics[i];
+        if (a.width != b.width || a.height != b.height || memcmp(&a.ctrl, &b.ctrl, sizeof(a.ctrl)) || memcmp(&a.tail, &b.tail, sizeof(a.tail)) ||
+            (a.me_type ? a.me_type : SVTME_ME_OPEN_LOOP) != (b.me_type ? b.me_type : SVTME_ME_OPEN_LOOP) ||
+            a.bypass_zz_check != b.bypass_zz_check || a.restricted_motion_vector != b.restricted_motion_vector ||
+            a.tf_me_exit_th != b.tf_me_exit_th)
+            return SVTME_ERR_BAD_ARG;
+    }
+    std::lock_guard<std::mutex> lock(e->mu);
+    DEVICE_OR_FAIL(e->cfg.device);
+    // ---- resources: a flight per picture, a batch record, a run of parameter records
+    Flight *fl[SVTME_MAX_BATCH];
+    {
+        uint32_t got = 0;
+        for (auto &c : e->flights)
+            if (!c.busy && got < n) fl[got++] = &c;
+        if (got < n) return SVTME_ERR_NO_RESOURCES;
+    }
+    int bi = -1;
+    for (size_t i = 0; i < e->batches.size(); ++i)
+        if (!e->batches[i].used) {
+            bi = (int)i;
+            break;
+        }
+    if (bi < 0) return SVTME_ERR_NO_RESOURCES;
+    BatchRec &B = e->batches[bi];
+    int       run = -1;
+    {
+        const unsigned cap = (unsigned)e->param_busy.size();
+        for (unsigned tries = 0, at = e->param_head; tries < cap && run < 0; ++tries, at = (at + 1) % cap) {
+            if (at + n > cap) continue; // a run does not wrap
+            bool free_run = true;
+            for (unsigned j = 0; j < n && free_run; ++j) free_run = !e->param_busy[at + j];
+            if (free_run) run = (int)at;
+        }
+        if (run < 0) return SVTME_ERR_NO_RESOURCES;
+    }
+    // ---- the pictures' parameter records
+    PicParams *hp = e->h_params + run; // pinned: the records go to the device from here
+    int        used[SVTME_MAX_BATCH][1 + SVTME_MAX_LISTS * SVTME_MAX_REFS], n_used[SVTME_MAX_BATCH];
+    const bool tail = pics[0].tail.enable != 0, skip_arrays = tail && pics[0].tail.enable == 2;
+    for (uint32_t i = 0; i < n; ++i) {
+        PicParams &p  = hp[i];
+        const int  rc = fill_params(e, &pics[i], p, used[i], &n_used[i]);
+        if (rc != SVTME_OK) return rc;
+        Flight      *f     = fl[i];
+        const size_t n_b64 = (size_t)p.b64_w * p.b64_h;
+        if (n_b64 > e->max_b64) return SVTME_ERR_BAD_ARG;
+        f->layout(n_b64, (size_t)(p.n_ref[0] + p.n_ref[1]), tail); // never larger than the allocation (n_b64 <= max_b64)
+        f->n_ref[0] = (uint32_t)p.n_ref[0];
+        f->n_ref[1] = (uint32_t)p.n_ref[1];
+        f->n_b64    = (uint32_t)n_b64;
+        p.hme_out   = f->d_hme;
+        p.me_jobs   = f->d_jobs;
+        p.me_keys   = f->d_keys;
+        // the counters sit right behind this picture's HME records
+        p.ops = reinterpret_cast<unsigned long long *>(reinterpret_cast<uint8_t *>(f->d_hme) + n_b64 * SVTME_MAX_LISTS * SVTME_MAX_REFS * sizeof(HmeRefOut));
+        point_results(p, *f, f->d_res, pics[i].tail);
+    }
 
     const unsigned    n_sm = e->cfg.search_streams ? e->cfg.search_streams : 3;
     const unsigned    mi = e->next_me++ % n_sm;
@@ -598,72 +692,84 @@ extern "C" int svtme_picture_submit(svtme_engine *e, const svtme_picture *pic, s
     // the process stays within four hardware queues)
     const hipStream_t sc = (e->copy_on_search_stream < 0 ? n_sm >= 3 : e->copy_on_search_stream != 0) ? sm : e->s_copy;
     const bool  kt = e->cfg.kernel_timing != 0;
-    f->kernel_timing = kt;
-    f->tail = pic->tail.enable != 0;
-    // tail.enable == 2: the host wants finished results only, the best SAD / MV planes (the end of the block) stay on the device
-    f->skip_search_arrays = f->tail && pic->tail.enable == 2;
-    if (f->tail) {
-        p.tail         = pic->tail;
-        p.t_hme_sad    = reinterpret_cast<unsigned long long *>(f->d_res + f->off_thme);
-        p.t_mv_array   = reinterpret_cast<uint32_t *>(f->d_res + f->off_tmv);
-        p.t_distortion = reinterpret_cast<uint32_t *>(f->d_res + f->off_tdist);
-        p.t_stats      = reinterpret_cast<uint32_t *>(f->d_res + f->off_tstat);
-        p.t_cand_array = f->d_res + f->off_tcand;
-        p.t_total_cand = f->d_res + f->off_ttot;
-        p.t_do_ref     = f->d_res + f->off_tdo;
-        p.t_zero_begin = f->d_res + f->off_thme;
-        p.t_zero_bytes = f->tail_end - f->off_thme;
-    }
-    // ---- everything the picture puts on its streams. (The HME records and the counters are zero on entry: allocated so,
+    // ---- everything the batch puts on its streams. (The HME records and the counters are zero on entry: allocated so,
     // and every picture's last search kernel clears them again.)
     auto enqueue = [&]() -> hipError_t {
         hipError_t err;
-        for (int si : used)
-            if (!e->slots[si].ready_seen[mi]) { // later pictures on this stream are ordered behind this wait anyway
-                if ((err = hipStreamWaitEvent(sm, e->slots[si].ready, 0)) != hipSuccess) return err;
-                e->slots[si].ready_seen[mi] = true;
+        for (uint32_t i = 0; i < n; ++i)
+            for (int j = 0; j < n_used[i]; ++j) {
+                Slot &sl = e->slots[used[i][j]];
+                if (!sl.ready_seen[mi]) { // later pictures on this stream are ordered behind this wait anyway
+                    if ((err = hipStreamWaitEvent(sm, sl.ready, 0)) != hipSuccess) return err;
+                    sl.ready_seen[mi] = true;
+                }
             }
-        if ((err = hipEventRecord(f->ev[0], sm)) != hipSuccess) return err;
-        hipEvent_t hme_marks[2] = {kt ? f->ev[1] : nullptr, kt ? f->ev[2] : nullptr};
-        // (the last ME mark is recorded after the optional tail kernel, so that it ends the picture's kernels either way)
-        hipEvent_t me_marks[3] = {kt ? f->ev[3] : nullptr, kt ? f->ev[4] : nullptr, f->tail ? nullptr : f->ev[5]};
-        launch_hme(p, sm, hme_marks);
-        launch_me(p, sm, me_marks);
-        if (f->tail) {
-            launch_tail(p, sm);
-            if ((err = hipEventRecord(f->ev[5], sm)) != hipSuccess) return err;
+        if ((err = hipEventRecord(B.ev[0], sm)) != hipSuccess) return err;
+        if (n > 1) launch_params_write(hp, e->d_params + run, (int)n, sm); // (a single picture's record travels as kernel argument)
+        const Batch batch{hp, e->d_params + run, (int)n};
+        hipEvent_t  hme_marks[2] = {kt ? B.ev[1] : nullptr, kt ? B.ev[2] : nullptr};
+        // (the last ME mark is recorded after the optional tail kernel, so that it ends the batch's kernels either way)
+        hipEvent_t me_marks[3] = {kt ? B.ev[3] : nullptr, kt ? B.ev[4] : nullptr, tail ? nullptr : B.ev[5]};
+        launch_hme(batch, sm, hme_marks);
+        launch_me(batch, sm, me_marks);
+        if (tail) {
+            launch_tail(batch, sm);
+            if ((err = hipEventRecord(B.ev[5], sm)) != hipSuccess) return err;
         }
         if ((err = hipGetLastError()) != hipSuccess) return err;
-        if (sc != sm && (err = hipStreamWaitEvent(sc, f->ev[5], 0)) != hipSuccess) return err;
-        const size_t c1 = f->skip_search_arrays ? f->tail_end : f->res_bytes;
-        if ((err = hipMemcpyAsync(f->h_res, f->d_res, c1, hipMemcpyDeviceToHost, sc)) != hipSuccess) return err;
-        return hipEventRecord(f->ev[6], sc);
+        // (kernels that write their results straight into the pinned host block were measured against these copies: slower
+        // at 1080p and 4K - the finishing kernel then runs at the link's pace -, faster only at 720p)
+        if (sc != sm && (err = hipStreamWaitEvent(sc, B.ev[5], 0)) != hipSuccess) return err;
+        for (uint32_t i = 0; i < n; ++i) {
+            // tail.enable == 2: the host wants finished results only, the best SAD / MV planes (the end of the block)
+            // stay on the device
+            const size_t c1 = skip_arrays ? fl[i]->tail_end : fl[i]->res_bytes;
+            if ((err = hipMemcpyAsync(fl[i]->h_res, fl[i]->d_res, c1, hipMemcpyDeviceToHost, sc)) != hipSuccess) return err;
+        }
+        return hipEventRecord(B.ev[6], sc);
     };
     const hipError_t enq_err = enqueue();
     if (enq_err != hipSuccess) {
-        // Part of the picture may be on its stream already. The flight and the slots are not accounted for yet, so nothing
-        // may stay in flight: drain the streams, then restore what the next picture expects of this buffer (zeroed HME
+        // Part of the batch may be on its stream already. The flights and the slots are not accounted for yet, so nothing
+        // may stay in flight: drain the streams, then restore what the next picture expects of these buffers (zeroed HME
         // records and counters), and report.
-        fprintf(stderr, "svtme: svtme_picture_submit: %s\n", hipGetErrorString(enq_err));
+        fprintf(stderr, "svtme: svtme_pictures_submit: %s\n", hipGetErrorString(enq_err));
         (void)hipStreamSynchronize(sm);
         if (sc != sm) (void)hipStreamSynchronize(sc);
-        (void)hipMemset(f->d_hme, 0, e->max_b64 * SVTME_MAX_LISTS * SVTME_MAX_REFS * sizeof(HmeRefOut) + SVTME_OPS_BYTES);
+        for (uint32_t i = 0; i < n; ++i)
+            (void)hipMemset(fl[i]->d_hme, 0, e->max_b64 * SVTME_MAX_LISTS * SVTME_MAX_REFS * sizeof(HmeRefOut) + SVTME_OPS_BYTES);
         (void)hipGetLastError();
         return SVTME_ERR_DEVICE;
     }
-    for (int si : used) { // ev[5] was recorded behind the picture's last kernel
-        e->slots[si].last_read[mi]     = f->ev[5];
-        e->slots[si].read_recorded[mi] = true;
-        e->slots[si].readers++;
+    B.used          = true;
+    B.kernel_timing = kt;
+    B.n = B.members_left = (int)n;
+    B.stream_index  = mi;
+    e->param_head   = (unsigned)(run + n) % (unsigned)e->param_busy.size();
+    for (uint32_t i = 0; i < n; ++i) {
+        Flight *f = fl[i];
+        for (int j = 0; j < n_used[i]; ++j) { // ev[5] was recorded behind the batch's last kernel
+            Slot &sl = e->slots[used[i][j]];
+            sl.last_read[mi]     = B.ev[5];
+            sl.read_recorded[mi] = true;
+            sl.readers++;
+        }
+        f->slots.assign(used[i], used[i] + n_used[i]);
+        f->tail               = tail;
+        f->skip_search_arrays = skip_arrays;
+        f->batch              = bi;
+        f->param              = run + (int)i;
+        e->param_busy[run + i] = 1;
+        f->busy   = true;
+        f->waited = false;
+        f->ticket = e->next_ticket++;
+        tickets[i] = f->ticket;
     }
-    f->stream_index = mi;
-    f->busy   = true;
-    f->waited = false;
-    f->n_b64  = (uint32_t)n_b64;
-    f->slots  = used;
-    f->ticket = e->next_ticket++;
-    *ticket   = f->ticket;
     return SVTME_OK;
+}
+
+extern "C" int svtme_picture_submit(svtme_engine *e, const svtme_picture *pic, svtme_ticket *ticket) {
+    return svtme_pictures_submit(e, pic, 1, ticket);
 }
 
 // The allocation-free form of svtme_picture_submit + svtme_picture_wait: same kernels, same results, but the kernels'
@@ -673,17 +779,8 @@ extern "C" int svtme_picture_submit(svtme_engine *e, const svtme_picture *pic, s
 extern "C" int svtme_picture_search_static(svtme_engine *e, const svtme_picture *pic, void *result_block, size_t result_bytes,
                                            svtme_results *out) {
     if (!e || !pic || !result_block || !out) return SVTME_ERR_BAD_ARG;
-    const svtme_controls &k = pic->ctrl;
-    if (pic->num_of_list_to_search < 1 || pic->num_of_list_to_search > 2 || pic->num_of_ref_pic_to_search[0] < 1 ||
-        pic->num_of_ref_pic_to_search[0] > SVTME_MAX_REFS ||
-        (pic->num_of_list_to_search == 2 && (pic->num_of_ref_pic_to_search[1] < 1 || pic->num_of_ref_pic_to_search[1] > SVTME_MAX_REFS)) ||
-        k.num_hme_sa_w < 1 || k.num_hme_sa_w > 2 || k.num_hme_sa_h < 1 || k.num_hme_sa_h > 2)
-        return SVTME_ERR_BAD_ARG;
-    if (k.me_search_method != 0) return SVTME_ERR_UNSUPPORTED;
-    if ((pic->me_type != 0 && pic->me_type != SVTME_ME_OPEN_LOOP && pic->me_type != SVTME_ME_MCTF && pic->me_type != SVTME_ME_FIRST_PASS) ||
-        pic->bypass_zz_check > 1 || pic->restricted_motion_vector > 1)
-        return SVTME_ERR_BAD_ARG;
-    if (pic->me_type == SVTME_ME_MCTF && (pic->num_of_list_to_search != 1 || pic->num_of_ref_pic_to_search[0] != 1)) return SVTME_ERR_BAD_ARG;
+    const int rc0 = check_picture(pic);
+    if (rc0 != SVTME_OK) return rc0;
     if (pic->tail.enable) return SVTME_ERR_UNSUPPORTED; // the device tail's outputs are not part of this form's result block
     if (e->cfg.serial_hme) return SVTME_ERR_UNSUPPORTED;
     if (reinterpret_cast<uintptr_t>(result_block) % 64) return SVTME_ERR_BAD_ARG;
@@ -698,45 +795,14 @@ extern "C" int svtme_picture_search_static(svtme_engine *e, const svtme_picture 
 
     std::lock_guard<std::mutex> lock(e->mu);
     DEVICE_OR_FAIL(e->cfg.device);
-    PicParams p;
-    memset(&p, 0, sizeof(p));
-    int       used[1 + SVTME_MAX_LISTS * SVTME_MAX_REFS], n_used = 0;
-    const int ci = find_slot(e, pic->cur_key);
-    if (ci < 0) return SVTME_ERR_NOT_FOUND;
-    if (e->slots[ci].width != pic->width || e->slots[ci].height != pic->height) return SVTME_ERR_BAD_ARG;
-    p.cur          = e->slots[ci].pic;
-    used[n_used++] = ci;
-    p.n_list   = pic->num_of_list_to_search;
-    p.n_ref[0] = n_ref0;
-    p.n_ref[1] = n_ref1;
-    for (int l = 0; l < p.n_list; ++l)
-        for (int r = 0; r < p.n_ref[l]; ++r) {
-            const int ri = find_slot(e, pic->ref_key[l][r]);
-            if (ri < 0) return SVTME_ERR_NOT_FOUND;
-            if (e->slots[ri].width != pic->width || e->slots[ri].height != pic->height) return SVTME_ERR_BAD_ARG;
-            p.ref[l][r] = e->slots[ri].pic;
-            const int64_t d = (int64_t)pic->picture_number - (int64_t)pic->ref_picture_number[l][r];
-            p.dist[l][r] = (uint16_t)(int16_t)(d < 0 ? -d : d);
-            used[n_used++] = ri;
-        }
-    p.ctrl   = k;
-    p.width  = (int32_t)pic->width;
-    p.height = (int32_t)pic->height;
-    p.b64_w  = (int32_t)((pic->width + 63) / 64);
-    p.b64_h  = (int32_t)((pic->height + 63) / 64);
-    p.temporal_layer  = pic->temporal_layer_index;
-    p.is_ref          = pic->is_used_as_reference_flag;
-    p.me_type         = pic->me_type ? pic->me_type : SVTME_ME_OPEN_LOOP;
-    p.bypass_zz_check = pic->me_type == SVTME_ME_FIRST_PASS && pic->bypass_zz_check;
-    p.restricted      = pic->restricted_motion_vector;
-    p.tf_me_exit_th   = pic->tf_me_exit_th;
-    p.dep_pre = k.prehme_enable && k.prehme_l1_early_exit && p.n_list == 2;
-    p.dep_l0  = k.enable_hme_flag && k.enable_hme_level0_flag && k.enable_me_sr_adjustment && k.distance_based_hme_resizing &&
-        k.reduce_hme_l0_sr_th_min && k.reduce_hme_l0_sr_th_max && p.n_ref[0] + p.n_ref[1] > 1;
-    {
-        const int w_max = (std::max<int>(k.me_sa.sa_max.width, 1) + 7) & ~7, h_max = std::max<int>(k.me_sa.sa_max.height, 3);
-        p.me_max_items  = ((w_max + 63) / 64) * ((h_max + 7) / 8);
-    }
+    // calls that share this device's scratch within the process take turns
+    std::lock_guard<std::mutex> scratch_turn(g_static_mu);
+    // the picture's parameter record: the one behind the ring, in pinned host memory svtme_create allocated
+    const size_t pi = e->param_busy.size();
+    PicParams   &p  = e->h_params[pi];
+    int          used[1 + SVTME_MAX_LISTS * SVTME_MAX_REFS], n_used = 0;
+    const int    rc = fill_params(e, pic, p, used, &n_used);
+    if (rc != SVTME_OK) return rc;
     // intermediates: this device's copy of the static array, through the pointer taken with hipGetSymbolAddress
     uint8_t *sc = e->static_scratch;
     p.hme_out = reinterpret_cast<HmeRefOut *>(sc);
@@ -747,23 +813,18 @@ extern "C" int svtme_picture_search_static(svtme_engine *e, const svtme_picture 
     Flight lay;
     lay.layout(n_b64, (size_t)(n_ref0 + n_ref1), false);
     uint8_t *res = static_cast<uint8_t *>(result_block);
-    p.best_sad       = reinterpret_cast<uint32_t *>(res + lay.off_sad);
-    p.best_mv        = reinterpret_cast<uint32_t *>(res + lay.off_mv);
-    p.search_results = reinterpret_cast<svtme_search_result *>(res + lay.off_sr);
-    p.zz_sad         = reinterpret_cast<uint32_t *>(res + lay.off_zz);
-    p.sr_divisor     = reinterpret_cast<uint32_t *>(res + lay.off_div);
-    p.ops_out        = reinterpret_cast<unsigned long long *>(res + lay.off_ops);
+    point_results(p, lay, res, pic->tail);
 
-    // calls that share this device's scratch within the process take turns; the array keeps the last call's contents, so
-    // what the kernels expect to start from zero (HME records, counters) is cleared here whatever the last call left
-    std::lock_guard<std::mutex> scratch_turn(g_static_mu);
+    // The array keeps the last call's contents, so what the kernels expect to start from zero (HME records, counters) is
+    // cleared here whatever the last call left.
     const hipStream_t sm = e->s_me[3]; // created by svtme_create, used by this entry point only
     for (int i = 0; i < n_used; ++i) HIP_TRY(hipStreamWaitEvent(sm, e->slots[used[i]].ready, 0));
     HIP_TRY(hipMemsetAsync(sc, 0, n_b64 * SVTME_MAX_LISTS * SVTME_MAX_REFS * sizeof(HmeRefOut), sm));
     HIP_TRY(hipMemsetAsync(sc + kStaticOpsOff, 0, SVTME_OPS_BYTES, sm));
-    hipEvent_t no_marks[3] = {nullptr, nullptr, nullptr};
-    launch_hme(p, sm, no_marks);
-    launch_me(p, sm, no_marks);
+    const Batch batch{&p, e->d_params + pi, 1};
+    hipEvent_t  no_marks[3] = {nullptr, nullptr, nullptr};
+    launch_hme(batch, sm, no_marks);
+    launch_me(batch, sm, no_marks);
     const hipError_t launch_err = hipGetLastError();
     // the planes must not be rewritten and the scratch not reused before the kernels are through: always drain the stream
     const hipError_t sync_err = hipStreamSynchronize(sm);
@@ -804,13 +865,14 @@ extern "C" int svtme_picture_wait(svtme_engine *e, svtme_ticket ticket, svtme_re
         if (!f) return SVTME_ERR_NOT_FOUND;
     }
     DEVICE_OR_FAIL(e->cfg.device);
-    HIP_TRY(hipEventSynchronize(f->ev[6]));
+    BatchRec &B = e->batches[f->batch]; // (stays the picture's batch until svtme_picture_done)
+    HIP_TRY(hipEventSynchronize(B.ev[6]));
     std::lock_guard<std::mutex> lock(e->mu);
     if (!f->waited) {
         f->waited = true;
         for (int si : f->slots) {
             Slot &s = e->slots[si];
-            if (s.last_read[f->stream_index] == f->ev[5]) s.read_recorded[f->stream_index] = false; // that read is over
+            if (s.last_read[B.stream_index] == B.ev[5]) s.read_recorded[B.stream_index] = false; // that read is over
             if (--s.readers == 0 && s.release_pending) {
                 s.used = false;
                 s.release_pending = false;
@@ -848,6 +910,9 @@ extern "C" int svtme_picture_done(svtme_engine *e, svtme_ticket ticket) {
     if (!f) return SVTME_ERR_NOT_FOUND;
     if (!f->waited) return SVTME_ERR_BAD_ARG;
     f->busy = false;
+    e->param_busy[f->param] = 0;
+    BatchRec &B = e->batches[f->batch];
+    if (--B.members_left == 0) B.used = false;
     return SVTME_OK;
 }
 
@@ -856,13 +921,16 @@ extern "C" int svtme_picture_timing(svtme_engine *e, svtme_ticket ticket, float 
     std::lock_guard<std::mutex> lock(e->mu);
     Flight *f = find_flight(e, ticket);
     if (!f || !f->waited) return SVTME_ERR_NOT_FOUND;
+    // the pictures of a batch share their launches: each reports an equal share of the batch's durations
+    const BatchRec &B = e->batches[f->batch];
     for (int i = 0; i < 5; ++i) {
         ms[i] = 0.f;
-        if (f->kernel_timing) HIP_TRY(hipEventElapsedTime(&ms[i], f->ev[i], f->ev[i + 1]));
+        if (B.kernel_timing) HIP_TRY(hipEventElapsedTime(&ms[i], B.ev[i], B.ev[i + 1]));
     }
-    HIP_TRY(hipEventElapsedTime(&ms[5], f->ev[0], f->ev[5]));
-    HIP_TRY(hipEventElapsedTime(&ms[6], f->ev[0], f->ev[6]));
-    ms[7] = 0.f;
+    HIP_TRY(hipEventElapsedTime(&ms[5], B.ev[0], B.ev[5]));
+    HIP_TRY(hipEventElapsedTime(&ms[6], B.ev[0], B.ev[6]));
+    for (int i = 0; i < 7; ++i) ms[i] /= (float)B.n;
+    ms[7] = (float)B.n;
     return SVTME_OK;
 }
 

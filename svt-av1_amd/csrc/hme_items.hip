@@ -32,18 +32,16 @@ constexpr int HI_WIN2_BYTES = 6144; // levels 1 and 2
 constexpr int HI_WIN2_BYTES_FS = 8192; // the same with FULL_SAD_SEARCH: 16 + 63 rows of the 64x64 block's 16x16 window
 constexpr int HI_THREADS_FS = 64; // threads of a level-1/2 work item with FULL_SAD_SEARCH
 
+// Per-wave LDS of a level-0 / pre-HME search: the sampled rows of the 16x16 sixteenth-resolution block.
 struct L0Shared {
-    u64      key;
-    uint32_t red;
-    int      zero; // always 0, but only known at run time
     uint32_t src[16 * 4];
 };
 
-// Level-0 vector of region (0,0) of list 0 / reference 0 as hme_level0_b64 leaves it (:1967-1999): the region's own
-// result unless it is the worst of the regions and a pre-HME result beats it; zero on the zero-MV early exit (:1916).
-__device__ void first_ref_l0_centre(const PicParams &p, int b64, int &mvx, int &mvy) {
+// Level-0 vector of region (0,0) of list 0 / reference 0 (record `o`) as hme_level0_b64 leaves it (:1967-1999): the
+// region's own result unless it is the worst of the regions and a pre-HME result beats it; zero on the zero-MV early exit
+// (:1916).
+__device__ void first_ref_l0_centre(const PicParams &p, const HmeRefOut &o, int &mvx, int &mvy) {
     const svtme_controls &k = p.ctrl;
-    const HmeRefOut      &o = p.hme_out[b64 * SVTME_MAX_LISTS * SVTME_MAX_REFS];
     mvx = mvy = 0;
     if (!k.enable_hme_level0_flag || (k.me_early_exit_th && o.zz_sad < (k.me_early_exit_th >> 2))) return;
     mvx = o.raw_x[0];
@@ -66,15 +64,15 @@ __device__ void first_ref_l0_centre(const PicParams &p, int b64, int &mvx, int &
 }
 
 // get_hme_l0_search_area :1827-1894. With p.dep_l0 every reference but the first reads the first one's level-0
-// vector, which the items of the first phase have written.
-__device__ void l0_area(const PicParams &p, int b64, int l, int r, int16_t &sa_w, int16_t &sa_h) {
+// vector (`first`: the record of list 0 / reference 0, complete by then).
+__device__ void l0_area(const PicParams &p, const HmeRefOut &first, int l, int r, int16_t &sa_w, int16_t &sa_h) {
     const svtme_controls &k  = p.ctrl;
     svtme_sa_minmax       sa = k.hme_l0_sa;
     if (k.enable_me_sr_adjustment && k.distance_based_hme_resizing) {
         int is_hor = 1, is_ver = 1, is_still = 0;
         if (k.reduce_hme_l0_sr_th_min && k.reduce_hme_l0_sr_th_max && (l || r)) {
             int mvx, mvy;
-            first_ref_l0_centre(p, b64, mvx, mvy);
+            first_ref_l0_centre(p, first, mvx, mvy);
             is_ver   = abs(mvx) < k.reduce_hme_l0_sr_th_min && abs(mvy) > k.reduce_hme_l0_sr_th_max;
             is_hor   = abs(mvx) > k.reduce_hme_l0_sr_th_max && abs(mvy) < k.reduce_hme_l0_sr_th_min;
             is_still = abs(mvx) < k.reduce_hme_l0_sr_th_min * 3 && abs(mvy) < k.reduce_hme_l0_sr_th_min * 3;
@@ -137,7 +135,7 @@ __device__ uint32_t slow_sad(const DevPlane &cur, const DevPlane &ref, int ox, i
 template <int T, bool FULL, int NR = 8, int STEP = 2>
 __device__ __forceinline__ void strip_units(const uint32_t *win, int pd, int n_xg, int brows, bool skip_even, const uint32_t (&src)[NR][4],
                                             int rows, int zero, int y_abs0, int x_abs0, int sa_w, u64 &best) {
-    const int lane   = threadIdx.x;
+    const int lane   = threadIdx.x & 63;
     const int n_yg   = (brows + STEP * T - 1) / (STEP * T);
     const int n_unit = n_xg * n_yg * ((skip_even || STEP == 1) ? 1 : 2);
     const uint32_t xg_magic = div_magic((uint32_t)n_xg);
@@ -215,10 +213,10 @@ __device__ __forceinline__ void strip_units(const uint32_t *win, int pd, int n_x
 // the sa_w x sa_h window of `ref` whose first position is plane pixel (wx, wy). Returns min (SAD << 32 | y * sa_w + x),
 // ~0 when no position was evaluated (skip_even with a single row). Whole wave. skip_even needs FS == false.
 template <bool FS>
-__device__ __forceinline__ u64 l0_search(L0Shared &S, uint32_t *win, const DevPlane &cur, const DevPlane &ref, int ox, int oy, int bw, int rows, int wx,
-                         int wy, int sa_w, int sa_h, bool skip_even) {
+__device__ __forceinline__ u64 l0_search(L0Shared &S, uint32_t *win, int zero, const DevPlane &cur, const DevPlane &ref, int ox, int oy, int bw,
+                                         int rows, int wx, int wy, int sa_w, int sa_h, bool skip_even) {
     constexpr int NR = FS ? 16 : 8, STEP = FS ? 1 : 2;
-    const int lane = threadIdx.x;
+    const int lane = threadIdx.x & 63;
     u64       best = ~0ull;
     if (sa_w <= 0 || sa_h <= 0 || rows <= 0) return best;
     if (bw != 16) {
@@ -231,14 +229,12 @@ __device__ __forceinline__ u64 l0_search(L0Shared &S, uint32_t *win, const DevPl
     } else {
         if (lane < rows * 4)
             S.src[lane] = *reinterpret_cast<const uint32_t *>(cur.pix + (ptrdiff_t)(oy + STEP * (lane >> 2)) * cur.stride + ox + 4 * (lane & 3));
-        if (lane == 0) S.zero = 0;
-        __syncthreads();
+        wave_sync();
         uint32_t src[NR][4];
 #pragma unroll
         for (int m = 0; m < NR; ++m)
 #pragma unroll
             for (int j = 0; j < 4; ++j) src[m][j] = (uint32_t)__builtin_amdgcn_readfirstlane((int)S.src[(m < rows ? m : 0) * 4 + j]);
-        const int zero = S.zero;
         for (int x0 = 0; x0 < sa_w; x0 += HI_XCHUNK) {
             const int n_xg = (min(HI_XCHUNK, sa_w - x0) + 3) >> 2;
             const int pd   = (n_xg + 4 + 3) & ~3; // dwords per staged row: the positions + 15 more pixels, in 16-byte pieces
@@ -250,9 +246,9 @@ __device__ __forceinline__ u64 l0_search(L0Shared &S, uint32_t *win, const DevPl
             band           = band >= 16 ? band & ~15 : max(band, 1);
             for (int y0 = 0; y0 < sa_h; y0 += band) {
                 const int brows = min(band, sa_h - y0);
-                __syncthreads();
+                wave_sync();
                 stage_window<5>(win, ref.pix + (ptrdiff_t)(wy + y0) * ref.stride + wx + x0, ref.stride, pd, brows + under);
-                __syncthreads();
+                wave_sync();
                 // rows per unit: as many as still give every lane a unit
                 const int cells = n_xg * ((brows + STEP - 1) / STEP); // position quads x rows of one walk direction
                 const int t = brows > 8 && cells >= 8 * HI_THREADS ? 8 : (brows > 4 && cells >= 4 * HI_THREADS ? 4 : 2);
@@ -268,23 +264,21 @@ __device__ __forceinline__ u64 l0_search(L0Shared &S, uint32_t *win, const DevPl
             }
         }
     }
-    if (lane == 0) S.key = ~0ull;
-    __syncthreads();
-    if (best != ~0ull) atomicMin(&S.key, best);
-    __syncthreads();
-    best = S.key;
-    __syncthreads();
-    return best;
+    wave_sync(); // the window and the block rows may be rewritten by this wave's next search
+    return wave_min_u64(best);
 }
 
 // Zero-MV SAD of every (b64, reference) for the controls with me_early_exit_th (init_zz_sad :2318-2333, get_zz_sad
 // :1720-1742: the 64x64 block on every other row, x2), once instead of in each of the six level-0 / pre-HME items that
 // test it; also the per-reference header fields. One wave per (b64, reference).
-__global__ void __launch_bounds__(HI_THREADS) hme_zz_kernel(PicParams p) {
-    const int b64 = blockIdx.x;
+template <class PICS>
+__global__ void __launch_bounds__(HI_THREADS) hme_zz_kernel(PICS pp, int n_b64) {
+    const PicParams &p   = pp[blockIdx.x / n_b64];
+    const int        b64 = blockIdx.x % n_b64;
     const int b64x = (b64 % p.b64_w) * 64, b64y = (b64 / p.b64_w) * 64;
     const int block_w = min(p.width - b64x, 64), block_h = min(p.height - b64y, 64);
     int       l = 0, r = (int)blockIdx.y;
+    if (r >= p.n_ref[0] + (p.n_list == 2 ? p.n_ref[1] : 0)) return; // the grid covers the batch's longest reference list
     if (r >= p.n_ref[0]) {
         r -= p.n_ref[0];
         l = 1;
@@ -300,47 +294,20 @@ __global__ void __launch_bounds__(HI_THREADS) hme_zz_kernel(PicParams p) {
     }
 }
 
+// One pre-HME shape (sub 0, 1) or level-0 region (sub 2..5, in the reference's visiting order) of reference (l, r),
+// whole wave. `rec` is the reference's record (global or LDS), `first` the record of list 0 / reference 0 and `same0`
+// the record of list 0 / reference r: both are only read when the picture's controls make references depend on each
+// other (p.dep_l0, p.dep_pre), and are complete by then. zz: the zero-MV SAD of the reference (~0 when not computed).
 template <bool FS>
-__global__ void __launch_bounds__(HI_THREADS, 3) hme_l0_kernel(PicParams p) {
-    __shared__ L0Shared               S;
-    __shared__ __align__(16) uint32_t win[HI_WIN_BYTES / 4 + 64];
-    const svtme_controls &k   = p.ctrl;
-    const int             b64 = blockIdx.x;
-    const int             b64x = (b64 % p.b64_w) * 64, b64y = (b64 / p.b64_w) * 64;
-    const int             block_w = min(p.width - b64x, 64), block_h = min(p.height - b64y, 64);
-    // references in reverse order: the closest references (smallest areas, cheapest items) are dispatched last and keep
-    // the kernel's tail short
-    int                   l = 0, r = (int)(gridDim.z - 1 - blockIdx.z);
-    if (r >= p.n_ref[0]) {
-        r -= p.n_ref[0];
-        l = 1;
-    }
-    const int  sub      = blockIdx.y; // 0, 1: pre-HME shapes; 2..: level-0 regions in the reference's visiting order
-    // items that read another reference's result run in a second launch
-    if (p.hme_phase) {
-        const bool dependent = sub < 2 ? (p.dep_pre && l == 1) : (p.dep_l0 && (l || r));
-        if (dependent != (p.hme_phase == 2)) return;
-    }
-    const bool searched = ref_searched(p, l);
-    HmeRefOut *out      = &p.hme_out[(b64 * SVTME_MAX_LISTS + l) * SVTME_MAX_REFS + r];
-    const bool header   = sub == 2; // this item also writes the per-reference fields
-
-    // zero-MV SAD (init_zz_sad :2318-2333); stays ~0 (init_me_hme_data :2921) when not computed. With the early exit on,
-    // hme_zz_kernel has computed it once for the six items of this (b64, reference) and has written the header fields.
-    uint32_t zz = ~0u;
-    if (k.me_early_exit_th) {
-        if (searched) zz = out->zz_sad;
-    } else if (header && threadIdx.x == 0) {
-        out->zz_sad = zz;
-        out->valid  = searched ? 1u : 0u;
-    }
-    if (!searched) return;
-
-    const DevPlane &cur = p.cur.lvl[0];
-    const DevPlane &ref = p.ref[l][r].lvl[0];
-    const int       ox = b64x >> 2, oy = b64y >> 2;
-    const int       bw = block_w >> 2, bh = block_h >> 2;
-    const int       rows = FS ? bh : bh >> 1;
+__device__ __forceinline__ void l0_item(const PicParams &p, L0Shared &S, uint32_t *win, int b64x, int b64y, int block_w, int block_h, int l, int r,
+                                        int sub, uint32_t zz, HmeRefOut *rec, const HmeRefOut *first, const HmeRefOut *same0) {
+    const svtme_controls &k    = p.ctrl;
+    const int             lane = threadIdx.x & 63;
+    const DevPlane       &cur  = p.cur.lvl[0];
+    const DevPlane       &ref  = p.ref[l][r].lvl[0];
+    const int             ox = b64x >> 2, oy = b64y >> 2;
+    const int             bw = block_w >> 2, bh = block_h >> 2;
+    const int             rows = FS ? bh : bh >> 1;
     // the search this item runs: window (origin relative to the block, size), row skipping, where the result goes
     int16_t   w = 0, h = 0, org_x = 0, org_y = 0;
     bool      skip = false;
@@ -353,14 +320,13 @@ __global__ void __launch_bounds__(HI_THREADS, 3) hme_l0_kernel(PicParams p) {
         if (k.prehme_l1_early_exit && l == 1) {
             // a list-1 search is skipped when the list-0 search of the same index found a good or a short vector: it
             // mirrors that result (:1759-1768)
-            const HmeRefOut &o0 = p.hme_out[(b64 * SVTME_MAX_LISTS + 0) * SVTME_MAX_REFS + r];
-            const int16_t    x0 = o0.pre_x[sub], y0 = o0.pre_y[sub];
-            const uint32_t   s0 = o0.pre_sad[sub];
+            const int16_t  x0 = same0->pre_x[sub], y0 = same0->pre_y[sub];
+            const uint32_t s0 = same0->pre_sad[sub];
             if (s0 < 32 * 32 || (abs(x0) < 16 && abs(y0) < 16)) {
-                if (threadIdx.x == 0) {
-                    out->pre_x[sub]   = (int16_t)-x0;
-                    out->pre_y[sub]   = (int16_t)-y0;
-                    out->pre_sad[sub] = s0;
+                if (lane == 0) {
+                    rec->pre_x[sub]   = (int16_t)-x0;
+                    rec->pre_y[sub]   = (int16_t)-y0;
+                    rec->pre_sad[sub] = s0;
                 }
                 return;
             }
@@ -375,9 +341,9 @@ __global__ void __launch_bounds__(HI_THREADS, 3) hme_l0_kernel(PicParams p) {
         clip_axis(oy, org_y, h, -(ref.pad - 1), ref.height);
         // svt_sad_loop_kernel_c skips even rows only for 16-wide blocks of height <= 16
         skip    = k.prehme_skip_search_line && bw == 16 && rows <= 16;
-        res_x   = &out->pre_x[sub];
-        res_y   = &out->pre_y[sub];
-        res_sad = &out->pre_sad[sub];
+        res_x   = &rec->pre_x[sub];
+        res_y   = &rec->pre_y[sub];
+        res_sad = &rec->pre_sad[sub];
         ops_k   = 1;
     } else {
         // level 0 (:1899-2004): a region per item; the early exit leaves zeros
@@ -386,7 +352,7 @@ __global__ void __launch_bounds__(HI_THREADS, 3) hme_l0_kernel(PicParams p) {
         if (k.me_early_exit_th && zz < (k.me_early_exit_th >> 2)) return;
         const int sw = q % nw, sh = q / nw, i = sw * 2 + sh;
         int16_t   sa_w = 0, sa_h = 0;
-        l0_area(p, b64, l, r, sa_w, sa_h);
+        l0_area(p, *first, l, r, sa_w, sa_h);
         w     = (int16_t)((sa_w + 7) & ~0x07);
         h     = sa_h;
         org_x = (int16_t)(-(int16_t)((w * nw) >> 1) + (int16_t)(w * sw));
@@ -394,21 +360,61 @@ __global__ void __launch_bounds__(HI_THREADS, 3) hme_l0_kernel(PicParams p) {
         clip_axis(ox, org_x, w, -(ref.pad - 1), ref.width);
         w = (int16_t)(w < 8 ? w : (w & ~0x07));
         clip_axis(oy, org_y, h, -(ref.pad - 1), ref.height);
-        res_x   = &out->raw_x[i];
-        res_y   = &out->raw_y[i];
-        res_sad = &out->raw_sad[i];
+        res_x   = &rec->raw_x[i];
+        res_y   = &rec->raw_y[i];
+        res_sad = &rec->raw_sad[i];
         ops_k   = 2;
     }
-    if (threadIdx.x == 0) count_ops(p, ops_k, (unsigned long long)max(skip ? h >> 1 : (int)h, 0) * max((int)w, 0) * rows * bw);
-    const u64 key = l0_search<FS>(S, win, cur, ref, ox, oy, bw, rows, ox + org_x, oy + org_y, w, h, skip);
-    if (threadIdx.x == 0) decode_key(key, w, org_x, org_y, 4, *res_x, *res_y, *res_sad, !FS);
+    if (lane == 0) count_ops(p, ops_k, (unsigned long long)max(skip ? h >> 1 : (int)h, 0) * max((int)w, 0) * rows * bw);
+    const u64 key = l0_search<FS>(S, win, p.zero, cur, ref, ox, oy, bw, rows, ox + org_x, oy + org_y, w, h, skip);
+    if (lane == 0) decode_key(key, w, org_x, org_y, 4, *res_x, *res_y, *res_sad, !FS);
+}
+
+template <bool FS, class PICS>
+__global__ void __launch_bounds__(HI_THREADS, 3) hme_l0_kernel(PICS pp, int n_b64, int hme_phase) {
+    __shared__ L0Shared               S;
+    __shared__ __align__(16) uint32_t win[HI_WIN_BYTES / 4 + 64];
+    const PicParams      &p   = pp[blockIdx.x / n_b64];
+    const svtme_controls &k   = p.ctrl;
+    const int             b64 = blockIdx.x % n_b64;
+    const int             b64x = (b64 % p.b64_w) * 64, b64y = (b64 / p.b64_w) * 64;
+    const int             block_w = min(p.width - b64x, 64), block_h = min(p.height - b64y, 64);
+    // references in reverse order: the closest references (smallest areas, cheapest items) are dispatched last and keep
+    // the kernel's tail short (the grid covers the batch's longest reference list)
+    int                   l = 0, r = p.n_ref[0] + (p.n_list == 2 ? p.n_ref[1] : 0) - 1 - (int)blockIdx.z;
+    if (r < 0) return;
+    if (r >= p.n_ref[0]) {
+        r -= p.n_ref[0];
+        l = 1;
+    }
+    const int  sub      = blockIdx.y; // 0, 1: pre-HME shapes; 2..: level-0 regions in the reference's visiting order
+    // hme_phase 0: every item; 1: the items others depend on; 2: the items that read another reference's result, which
+    // run in a second launch
+    if (hme_phase) {
+        const bool dependent = sub < 2 ? (p.dep_pre && l == 1) : (p.dep_l0 && (l || r));
+        if (dependent != (hme_phase == 2)) return;
+    }
+    const bool searched = ref_searched(p, l);
+    HmeRefOut *b64_out  = &p.hme_out[b64 * SVTME_MAX_LISTS * SVTME_MAX_REFS];
+    HmeRefOut *out      = &b64_out[l * SVTME_MAX_REFS + r];
+    const bool header   = sub == 2; // this item also writes the per-reference fields
+
+    // zero-MV SAD (init_zz_sad :2318-2333); stays ~0 (init_me_hme_data :2921) when not computed. With the early exit on,
+    // hme_zz_kernel has computed it once for the six items of this (b64, reference) and has written the header fields.
+    uint32_t zz = ~0u;
+    if (k.me_early_exit_th) {
+        if (searched) zz = out->zz_sad;
+    } else if (header && threadIdx.x == 0) {
+        out->zz_sad = zz;
+        out->valid  = searched ? 1u : 0u;
+    }
+    if (!searched) return;
+    l0_item<FS>(p, S, win, b64x, b64y, block_w, block_h, l, r, sub, zz, out, b64_out, &b64_out[r]);
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
 template <bool FS>
 struct L12Shared {
-    u64      key;
-    int      zero; // always 0, but only known at run time
     uint32_t src1[(FS ? 32 : 16) * 16]; // sampled rows of the quarter-resolution 32x32 block, 16 dwords apart
     uint32_t src2[(FS ? 64 : 32) * 16]; // sampled rows of the full-resolution 64x64 block
 };
@@ -420,8 +426,7 @@ struct L12Shared {
 // row. Issues its loads and stores without waiting: the caller's next barrier orders them.
 template <int K = 8, int STEP = 2>
 __device__ __forceinline__ void stage_block(uint32_t *dst, const DevPlane &cur, int ox, int oy, int bw, int rows) {
-    if (threadIdx.x >= 64) return; // the first wave fetches
-    const int bwd = bw >> 2, lane = threadIdx.x & 63, d = lane & 15;
+    const int bwd = bw >> 2, lane = threadIdx.x & 63, d = lane & 15; // one wave fetches
     if (d >= bwd) return;
     uint32_t v[K];
 #pragma unroll
@@ -450,17 +455,14 @@ __device__ __forceinline__ u64 row_qsad(const uint32_t *rr, const uint32_t *ss, 
 }
 
 template <bool FS>
-__device__ u64 small_search(L12Shared<FS> &S, const uint32_t *src, uint32_t *win, const DevPlane &ref, int bw, int rows, int wx, int wy,
-                            int sa_w, int sa_h) {
+__device__ u64 small_search(const uint32_t *src, uint32_t *win, const DevPlane &ref, int bw, int rows, int wx, int wy, int sa_w, int sa_h) {
     constexpr int STEP = FS ? 1 : 2; // plane rows between sampled block rows
-    constexpr int NT   = FS ? HI_THREADS_FS : HI_THREADS;
+    constexpr int NT   = 64;
     constexpr int WINB = FS ? HI_WIN2_BYTES_FS : HI_WIN2_BYTES;
-    const int lane = threadIdx.x;
+    const int lane = threadIdx.x & 63;
     u64       best = ~0ull;
     if (sa_w <= 0 || sa_h <= 0 || rows <= 0) return best;
     const int bwd = bw >> 2;
-    __syncthreads();
-    if (lane == 0) S.key = ~0ull;
     const int span       = (rows - 1) * STEP + 1;
     const int chunk_log2 = rows >= 16 ? 3 : (rows >= 4 ? 2 : 0), chunks = 1 << chunk_log2;
     const int rpc        = (rows + chunks - 1) >> chunk_log2; // sampled block rows per lane
@@ -470,9 +472,9 @@ __device__ u64 small_search(L12Shared<FS> &S, const uint32_t *src, uint32_t *win
         const int band = max(WINB / (4 * pd) - (span - 1), 1);
         for (int y0 = 0; y0 < sa_h; y0 += band) {
             const int brows = min(band, sa_h - y0);
-            __syncthreads();
+            wave_sync();
             stage_window<FS ? 2 : 6, NT>(win, ref.pix + (ptrdiff_t)(wy + y0) * ref.stride + wx + x0, ref.stride, pd, brows + span - 1);
-            __syncthreads();
+            wave_sync();
             const int total = (n_xg * brows) << chunk_log2;
             for (int base = 0; base < total; base += NT) {
                 const int  t     = base + lane;
@@ -526,11 +528,8 @@ __device__ u64 small_search(L12Shared<FS> &S, const uint32_t *src, uint32_t *win
             }
         }
     }
-    if (best != ~0ull) atomicMin(&S.key, best);
-    __syncthreads();
-    best = S.key;
-    __syncthreads();
-    return best;
+    wave_sync();
+    return wave_min_u64(best);
 }
 
 // FULL_SAD_SEARCH levels 1 / 2 in the temporal filter's shape: a window of at most 16 x 16 positions, a full-width block
@@ -540,20 +539,14 @@ __device__ u64 small_search(L12Shared<FS> &S, const uint32_t *src, uint32_t *win
 // operands) and each block row once (one 16-byte read): 4 T v_qsad_pk_u16_u8 per step. The packed 16-bit sums are
 // folded into 32-bit sums every 16 block rows (16 x 16 x 255 < 65536); the strips' sums meet through DPP lane exchanges.
 template <int NSTRIP, int NR, int T>
-__device__ u64 strip_search_fs(L12Shared<true> &S, const uint32_t *src, uint32_t *win, const DevPlane &ref, int rows, int wx, int wy,
-                               int sa_w, int sa_h) {
+__device__ u64 strip_search_fs(const uint32_t *src, uint32_t *win, int zero, const DevPlane &ref, int rows, int wx, int wy, int sa_w, int sa_h) {
     constexpr int PD = 4 + 4 * NSTRIP; // dwords per staged row: 16 positions + the block width - 1 more pixels, rounded up
     static_assert(64 / NSTRIP / 4 * T >= 16, "the wave covers 16 search rows");
-    const int lane = threadIdx.x;
+    const int lane = threadIdx.x & 63;
     const int n_xg = (sa_w + 3) >> 2, n_yg = (sa_h + T - 1) / T;
-    __syncthreads();
-    if (lane == 0) {
-        S.key  = ~0ull;
-        S.zero = 0;
-    }
+    wave_sync();
     stage_window<2>(win, ref.pix + (ptrdiff_t)wy * ref.stride + wx, ref.stride, PD, n_yg * T + NR - 1);
-    __syncthreads();
-    const int  zero  = S.zero;
+    wave_sync();
     const int  strip = lane % NSTRIP, unit = lane / NSTRIP, xg = unit & 3, yg = unit >> 2;
     const bool valid = xg < n_xg && yg < n_yg;
     const int  yfirst = valid ? yg * T : 0;
@@ -624,11 +617,8 @@ __device__ u64 strip_search_fs(L12Shared<true> &S, const uint32_t *src, uint32_t
             }
         }
     }
-    if (best != ~0ull) atomicMin(&S.key, best);
-    __syncthreads();
-    best = S.key;
-    __syncthreads();
-    return best;
+    wave_sync();
+    return wave_min_u64(best);
 }
 
 // small_search for the shapes the presets use at these levels - 8 x (1..MAXH) positions (3 rows in the pre-analysis ME, 8 in
@@ -636,14 +626,13 @@ __device__ u64 strip_search_fs(L12Shared<true> &S, const uint32_t *src, uint32_t
 // full-resolution block) - with everything unrolled: lane = (position quad: 2 per row x 4 rows) x (8 chunks of BWD / 4
 // sampled block rows), 4 search rows per trip; window staged in one memory round trip.
 template <int BWD, int MAXH>
-__device__ u64 quick_search(L12Shared<false> &S, const uint32_t *src, uint32_t *win, const DevPlane &ref, int rows, int wx, int wy, int sa_h) {
+__device__ u64 quick_search(const uint32_t *src, uint32_t *win, const DevPlane &ref, int rows, int wx, int wy, int sa_h) {
     constexpr int PD  = BWD + 2; // dwords per staged row: 8 positions + the block width - 1 more pixels, rounded up
     constexpr int RPC = BWD / 4; // sampled block rows per lane (rows <= 8 RPC); RPC x 4 BWD x 255 fits the 16-bit sums
     constexpr int NB  = ((MAXH + 2 * (8 * RPC - 1)) * PD + 63) / 64;
-    const int     lane = threadIdx.x;
+    const int     lane = threadIdx.x & 63;
     const int     n = (sa_h + 2 * (rows - 1)) * PD;
-    __syncthreads();
-    if (lane == 0) S.key = ~0ull;
+    wave_sync();
     {
         // element i = lane + 64 k of the window; indices past the end repeat the last element (same value, same slot)
         const uint8_t *g = ref.pix + (ptrdiff_t)wy * ref.stride + wx;
@@ -656,7 +645,7 @@ __device__ u64 quick_search(L12Shared<false> &S, const uint32_t *src, uint32_t *
 #pragma unroll
         for (int k = 0; k < NB; ++k) win[min(lane + 64 * k, n - 1)] = v[k];
     }
-    __syncthreads();
+    wave_sync();
     const int chunk = lane & 7, q = lane >> 3, xg = q & 1;
     u64       best = ~0ull;
 #pragma unroll
@@ -698,71 +687,51 @@ __device__ u64 quick_search(L12Shared<false> &S, const uint32_t *src, uint32_t *
             }
         }
     }
-    if (best != ~0ull) atomicMin(&S.key, best);
-    __syncthreads();
-    best = S.key;
-    __syncthreads();
-    return best;
+    wave_sync();
+    return wave_min_u64(best);
 }
 
+// Levels 1 and 2 of region q of reference (l, r), whole wave: first the level-0 result of the region, which gives way
+// to the better pre-HME result when it is the worst region (:1967-1999), then level 1 around the level-0 vector and
+// level 2 around the level-1 vector. `rec`: the reference's record with zz_sad, pre_* and raw_* complete (global or LDS);
+// src1 / src2: the sampled rows of the block at quarter / full resolution, staged by the caller.
 template <bool FS>
-__global__ void __launch_bounds__(FS ? HI_THREADS_FS : HI_THREADS) hme_l12_kernel(PicParams p) {
-    __shared__ L12Shared<FS>          S;
-    __shared__ __align__(16) uint32_t win[(FS ? HI_WIN2_BYTES_FS : HI_WIN2_BYTES) / 4 + 64];
-    const svtme_controls &k   = p.ctrl;
+__device__ __forceinline__ void l12_region(const PicParams &p, const uint32_t *src1, const uint32_t *src2, uint32_t *win, int b64x, int b64y,
+                                           int block_w, int block_h, int l, int r, int q, HmeRefOut *rec) {
+    const svtme_controls &k    = p.ctrl;
+    const int             lane = threadIdx.x & 63;
     const int             nw = k.num_hme_sa_w, nh = k.num_hme_sa_h;
-    const int             n_refs = p.n_ref[0] + (p.n_list == 2 ? p.n_ref[1] : 0);
-    int                   b64, item;
-    if (!b64_band_item(blockIdx.x, p.b64_w * p.b64_h, n_refs * nw * nh, b64, item)) return;
-    const int             b64x = (b64 % p.b64_w) * 64, b64y = (b64 / p.b64_w) * 64;
-    const int             block_w = min(p.width - b64x, 64), block_h = min(p.height - b64y, 64);
-    int                   l = 0, r = item / (nw * nh);
-    const int             q = item - r * (nw * nh);
-    if (r >= p.n_ref[0]) {
-        r -= p.n_ref[0];
-        l = 1;
-    }
-    if (!ref_searched(p, l) || !k.enable_hme_flag || q >= nw * nh) return;
-    // both levels' source blocks are fetched while the level-0 results arrive
-    if constexpr (FS) {
-        if (k.enable_hme_level1_flag) stage_block<8, 1>(S.src1, p.cur.lvl[1], b64x >> 1, b64y >> 1, block_w >> 1, block_h >> 1);
-        if (k.enable_hme_level2_flag) stage_block<16, 1>(S.src2, p.cur.lvl[2], b64x, b64y, block_w, block_h);
-    } else {
-        if (k.enable_hme_level1_flag) stage_block(S.src1, p.cur.lvl[1], b64x >> 1, b64y >> 1, block_w >> 1, block_h >> 2);
-        if (k.enable_hme_level2_flag) stage_block(S.src2, p.cur.lvl[2], b64x, b64y, block_w, block_h >> 1);
-    }
-    const int  sw = q % nw, sh = q / nw, i = sw * 2 + sh;
-    HmeRefOut *out = &p.hme_out[(b64 * SVTME_MAX_LISTS + l) * SVTME_MAX_REFS + r];
-    const bool early = k.me_early_exit_th && out->zz_sad < (k.me_early_exit_th >> 2);
+    const int             sw = q % nw, sh = q / nw, i = sw * 2 + sh;
+    const bool            early = k.me_early_exit_th && rec->zz_sad < (k.me_early_exit_th >> 2);
 
     // level-0 result of this region: the worst region (strict '>', sr_h outer / sr_w inner) gives way to the better
     // pre-HME result (:1967-1999)
     int16_t  cx = 0, cy = 0; // vector of the previous level (zero when that level did not run)
     uint32_t csad = 0;
     if (k.enable_hme_level0_flag && !early) {
-        cx   = out->raw_x[i];
-        cy   = out->raw_y[i];
-        csad = out->raw_sad[i];
+        cx   = rec->raw_x[i];
+        cy   = rec->raw_y[i];
+        csad = rec->raw_sad[i];
         if (k.prehme_enable) {
             uint32_t max_sad = 0;
             int      mi      = 0;
             for (int h_ = 0; h_ < nh; ++h_)
                 for (int w_ = 0; w_ < nw; ++w_)
-                    if (out->raw_sad[w_ * 2 + h_] > max_sad) {
-                        max_sad = out->raw_sad[w_ * 2 + h_];
+                    if (rec->raw_sad[w_ * 2 + h_] > max_sad) {
+                        max_sad = rec->raw_sad[w_ * 2 + h_];
                         mi      = w_ * 2 + h_;
                     }
-            const int s = out->pre_sad[0] <= out->pre_sad[1] ? 0 : 1;
-            if (mi == i && out->pre_sad[s] < csad) {
-                csad = out->pre_sad[s];
-                cx   = out->pre_x[s];
-                cy   = out->pre_y[s];
+            const int s = rec->pre_sad[0] <= rec->pre_sad[1] ? 0 : 1;
+            if (mi == i && rec->pre_sad[s] < csad) {
+                csad = rec->pre_sad[s];
+                cx   = rec->pre_x[s];
+                cy   = rec->pre_y[s];
             }
         }
-        if (threadIdx.x == 0) {
-            out->lx[0][i]   = cx;
-            out->ly[0][i]   = cy;
-            out->lsad[0][i] = csad;
+        if (lane == 0) {
+            rec->lx[0][i]   = cx;
+            rec->ly[0][i]   = cy;
+            rec->lsad[0][i] = csad;
         }
     }
     for (int level = 1; level <= 2; ++level) {
@@ -787,60 +756,106 @@ __global__ void __launch_bounds__(FS ? HI_THREADS_FS : HI_THREADS) hme_l12_kerne
         clip_axis(ox, org_x, w, -pad, ref.width);
         w = (int16_t)(w < 8 ? w : (w & ~0x07));
         clip_axis(oy, org_y, h, -pad, ref.height);
-        if (threadIdx.x == 0) count_ops(p, 2 + level, (unsigned long long)max((int)h, 0) * max((int)w, 0) * rows * bw);
-        u64 key;
+        if (lane == 0) count_ops(p, 2 + level, (unsigned long long)max((int)h, 0) * max((int)w, 0) * rows * bw);
+        const uint32_t *src = level == 1 ? src1 : src2;
+        u64             key;
         if constexpr (!FS) {
             if (block_w == 64 && w == 8 && h >= 1 && h <= 3)
-                key = level == 1 ? quick_search<8, 3>(S, S.src1, win, ref, rows, ox + org_x, oy + org_y, h)
-                                 : quick_search<16, 3>(S, S.src2, win, ref, rows, ox + org_x, oy + org_y, h);
+                key = level == 1 ? quick_search<8, 3>(src, win, ref, rows, ox + org_x, oy + org_y, h)
+                                 : quick_search<16, 3>(src, win, ref, rows, ox + org_x, oy + org_y, h);
             else if (block_w == 64 && w == 8 && h >= 4 && h <= 8) // the first pass's 8 x 8 windows
-                key = level == 1 ? quick_search<8, 8>(S, S.src1, win, ref, rows, ox + org_x, oy + org_y, h)
-                                 : quick_search<16, 8>(S, S.src2, win, ref, rows, ox + org_x, oy + org_y, h);
+                key = level == 1 ? quick_search<8, 8>(src, win, ref, rows, ox + org_x, oy + org_y, h)
+                                 : quick_search<16, 8>(src, win, ref, rows, ox + org_x, oy + org_y, h);
             else
-                key = small_search<FS>(S, level == 1 ? S.src1 : S.src2, win, ref, bw, rows, ox + org_x, oy + org_y, w, h);
+                key = small_search<FS>(src, win, ref, bw, rows, ox + org_x, oy + org_y, w, h);
         } else {
             if (block_w == 64 && w >= 1 && w <= 16 && h >= 1 && h <= 16)
-                key = level == 1 ? strip_search_fs<2, 32, 2>(S, S.src1, win, ref, rows, ox + org_x, oy + org_y, w, h)
-                                 : strip_search_fs<4, 64, 4>(S, S.src2, win, ref, rows, ox + org_x, oy + org_y, w, h);
+                key = level == 1 ? strip_search_fs<2, 32, 2>(src, win, p.zero, ref, rows, ox + org_x, oy + org_y, w, h)
+                                 : strip_search_fs<4, 64, 4>(src, win, p.zero, ref, rows, ox + org_x, oy + org_y, w, h);
             else
-                key = small_search<FS>(S, level == 1 ? S.src1 : S.src2, win, ref, bw, rows, ox + org_x, oy + org_y, w, h);
+                key = small_search<FS>(src, win, ref, bw, rows, ox + org_x, oy + org_y, w, h);
         }
         uint32_t  sad;
         decode_key(key, w, org_x, org_y, level == 1 ? 2 : 1, cx, cy, sad, !FS);
-        if (threadIdx.x == 0) {
-            out->lx[level][i]   = cx;
-            out->ly[level][i]   = cy;
-            out->lsad[level][i] = sad;
+        if (lane == 0) {
+            rec->lx[level][i]   = cx;
+            rec->ly[level][i]   = cy;
+            rec->lsad[level][i] = sad;
         }
     }
 }
 
-void launch_hme_items(const PicParams &p, hipStream_t s, hipEvent_t marks[2]) {
-    const int n_refs = p.n_ref[0] + (p.n_list == 2 ? p.n_ref[1] : 0);
-    const int n_b64  = p.b64_w * p.b64_h;
-    const int n_reg  = p.ctrl.num_hme_sa_w * p.ctrl.num_hme_sa_h;
-    const bool fs = p.ctrl.hme_search_method == 1; // FULL_SAD_SEARCH
-    const dim3 g0(n_b64, 2 + max(n_reg, 1), n_refs), g12((n_b64 + 7) / 8 * 8 * n_refs * n_reg);
-    PicParams  q = p;
-    const int  n_phase = (p.dep_pre || p.dep_l0) ? 2 : 1;
-    if (p.ctrl.me_early_exit_th) hipLaunchKernelGGL(hme_zz_kernel, dim3(n_b64, n_refs), dim3(HI_THREADS), 0, s, p);
+// Both levels' source blocks of a 64x64 block: sampled rows of the quarter- and the full-resolution block, one wave.
+template <bool FS>
+__device__ __forceinline__ void stage_l12_blocks(const PicParams &p, L12Shared<FS> &S, int b64x, int b64y, int block_w, int block_h) {
+    const svtme_controls &k = p.ctrl;
+    if constexpr (FS) {
+        if (k.enable_hme_level1_flag) stage_block<8, 1>(S.src1, p.cur.lvl[1], b64x >> 1, b64y >> 1, block_w >> 1, block_h >> 1);
+        if (k.enable_hme_level2_flag) stage_block<16, 1>(S.src2, p.cur.lvl[2], b64x, b64y, block_w, block_h);
+    } else {
+        if (k.enable_hme_level1_flag) stage_block(S.src1, p.cur.lvl[1], b64x >> 1, b64y >> 1, block_w >> 1, block_h >> 2);
+        if (k.enable_hme_level2_flag) stage_block(S.src2, p.cur.lvl[2], b64x, b64y, block_w, block_h >> 1);
+    }
+}
+
+template <bool FS, class PICS>
+__global__ void __launch_bounds__(FS ? HI_THREADS_FS : HI_THREADS) hme_l12_kernel(PICS pp) {
+    __shared__ L12Shared<FS>          S;
+    __shared__ __align__(16) uint32_t win[(FS ? HI_WIN2_BYTES_FS : HI_WIN2_BYTES) / 4 + 64];
+    const PicParams      &p   = pp[blockIdx.y];
+    const svtme_controls &k   = p.ctrl;
+    const int             nw = k.num_hme_sa_w, nh = k.num_hme_sa_h;
+    const int             n_refs = p.n_ref[0] + (p.n_list == 2 ? p.n_ref[1] : 0);
+    int                   b64, item;
+    if (!b64_band_item(blockIdx.x, p.b64_w * p.b64_h, n_refs * nw * nh, b64, item)) return;
+    const int             b64x = (b64 % p.b64_w) * 64, b64y = (b64 / p.b64_w) * 64;
+    const int             block_w = min(p.width - b64x, 64), block_h = min(p.height - b64y, 64);
+    int                   l = 0, r = item / (nw * nh);
+    const int             q = item - r * (nw * nh);
+    if (r >= p.n_ref[0]) {
+        r -= p.n_ref[0];
+        l = 1;
+    }
+    if (!ref_searched(p, l) || !k.enable_hme_flag || q >= nw * nh) return;
+    // both levels' source blocks are fetched while the level-0 results arrive
+    stage_l12_blocks<FS>(p, S, b64x, b64y, block_w, block_h);
+    wave_sync();
+    l12_region<FS>(p, S.src1, S.src2, win, b64x, b64y, block_w, block_h, l, r, q, &p.hme_out[(b64 * SVTME_MAX_LISTS + l) * SVTME_MAX_REFS + r]);
+}
+
+template <class PICS>
+static void launch_hme_items_as(const Batch &b, PICS pics, hipStream_t s, hipEvent_t marks[2]) {
+    const PicParams &p0 = b.host[0]; // size, controls and me_type are the batch's
+    const int n_refs = b.max_refs(), n_b64 = b.n_b64();
+    const int n_reg  = p0.ctrl.num_hme_sa_w * p0.ctrl.num_hme_sa_h;
+    const bool fs = p0.ctrl.hme_search_method == 1; // FULL_SAD_SEARCH
+    const dim3 g0(n_b64 * b.n, 2 + max(n_reg, 1), n_refs), g12((n_b64 + 7) / 8 * 8 * n_refs * n_reg, b.n);
+    bool       deps = false;
+    for (int i = 0; i < b.n; ++i) deps = deps || b.host[i].dep_pre || b.host[i].dep_l0;
+    const int n_phase = deps ? 2 : 1;
+    if (p0.ctrl.me_early_exit_th) hipLaunchKernelGGL(hme_zz_kernel<PICS>, dim3(n_b64 * b.n, n_refs), dim3(HI_THREADS), 0, s, pics, n_b64);
     for (int phase = 1; phase <= n_phase; ++phase) {
-        q.hme_phase = n_phase == 1 ? 0 : phase;
-        if (fs) hipLaunchKernelGGL(hme_l0_kernel<true>, g0, dim3(HI_THREADS), 0, s, q);
-        else hipLaunchKernelGGL(hme_l0_kernel<false>, g0, dim3(HI_THREADS), 0, s, q);
+        const int hme_phase = n_phase == 1 ? 0 : phase;
+        if (fs) hipLaunchKernelGGL((hme_l0_kernel<true, PICS>), g0, dim3(HI_THREADS), 0, s, pics, n_b64, hme_phase);
+        else hipLaunchKernelGGL((hme_l0_kernel<false, PICS>), g0, dim3(HI_THREADS), 0, s, pics, n_b64, hme_phase);
     }
     if (marks[0]) (void)hipEventRecord(marks[0], s);
-    if (p.ctrl.enable_hme_flag) {
-        if (fs) hipLaunchKernelGGL(hme_l12_kernel<true>, g12, dim3(HI_THREADS_FS), 0, s, p);
-        else hipLaunchKernelGGL(hme_l12_kernel<false>, g12, dim3(HI_THREADS), 0, s, p);
+    if (p0.ctrl.enable_hme_flag) {
+        if (fs) hipLaunchKernelGGL((hme_l12_kernel<true, PICS>), g12, dim3(HI_THREADS_FS), 0, s, pics);
+        else hipLaunchKernelGGL((hme_l12_kernel<false, PICS>), g12, dim3(HI_THREADS), 0, s, pics);
     }
     if (marks[1]) (void)hipEventRecord(marks[1], s);
 }
 
+void launch_hme_items(const Batch &b, hipStream_t s, hipEvent_t marks[2]) {
+    if (b.n == 1) launch_hme_items_as(b, OnePicture{b.host[0]}, s, marks);
+    else launch_hme_items_as(b, ManyPictures{b.dev}, s, marks);
+}
+
 // resident workgroups per CU the runtime expects for the two kernels (diagnostic)
 void occupancy_hme_items(int out[2]) {
-    (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&out[0], hme_l0_kernel<false>, HI_THREADS, 0);
-    (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&out[1], hme_l12_kernel<false>, HI_THREADS, 0);
+    (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&out[0], hme_l0_kernel<false, OnePicture>, HI_THREADS, 0);
+    (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&out[1], hme_l12_kernel<false, OnePicture>, HI_THREADS, 0);
 }
 
 } // namespace svtme

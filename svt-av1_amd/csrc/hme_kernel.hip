@@ -456,10 +456,12 @@ __device__ void hme_one_ref(const PicParams &p, HmeShared &S, uint8_t *win, int 
     __syncthreads();
 }
 
-__global__ void __launch_bounds__(HME_THREADS) hme_kernel(PicParams p) {
+template <class PICS>
+__global__ void __launch_bounds__(HME_THREADS) hme_kernel(PICS pp, int n_b64) {
     __shared__ HmeShared                  S;
     extern __shared__ __align__(16) uint8_t win[];
-    const int                             b64 = blockIdx.x;
+    const PicParams                      &p   = pp[blockIdx.x / n_b64];
+    const int                             b64 = blockIdx.x % n_b64;
     if (threadIdx.x == 0) {
         S.l0c00_x = S.l0c00_y = 0;
         for (int r = 0; r < SVTME_MAX_REFS; ++r)
@@ -474,6 +476,7 @@ __global__ void __launch_bounds__(HME_THREADS) hme_kernel(PicParams p) {
             for (int r = 0; r < p.n_ref[l]; ++r) hme_one_ref(p, S, win, b64, l, r);
     } else {
         int g = blockIdx.y, l = 0;
+        if (g >= p.n_ref[0] + (p.n_list == 2 ? p.n_ref[1] : 0)) return; // the grid covers the batch's longest reference list
         if (g >= p.n_ref[0]) {
             g -= p.n_ref[0];
             l = 1;
@@ -482,18 +485,20 @@ __global__ void __launch_bounds__(HME_THREADS) hme_kernel(PicParams p) {
     }
 }
 
-void launch_hme(const PicParams &p, hipStream_t s, hipEvent_t marks[2]) {
+void launch_hme(const Batch &b, hipStream_t s, hipEvent_t marks[2]) {
     // Kernels of independent work items, unless the caller asked for the serial kernel (one workgroup per b64 walks the
     // references in order). (The itemised full-SAD form has no row skipping for pre-HME; no preset combines the two.)
+    const PicParams &p = b.host[0];
     const bool fs_skip = p.ctrl.hme_search_method != 0 && p.ctrl.prehme_enable && p.ctrl.prehme_skip_search_line;
     if (!p.serial_refs && p.ctrl.hme_search_method <= 1 && !fs_skip) {
-        launch_hme_items(p, s, marks);
+        launch_hme_items(b, s, marks);
         return;
     }
-    const int n_refs = p.n_ref[0] + (p.n_list == 2 ? p.n_ref[1] : 0);
-    const bool dep = p.dep_pre || p.dep_l0 || p.serial_refs;
-    dim3       grid(p.b64_w * p.b64_h, dep ? 1 : n_refs);
-    hipLaunchKernelGGL(hme_kernel, grid, dim3(HME_THREADS), HME_WIN_BYTES + 64, s, p);
+    bool dep = p.serial_refs != 0;
+    for (int i = 0; i < b.n; ++i) dep = dep || b.host[i].dep_pre || b.host[i].dep_l0;
+    dim3 grid(b.n_b64() * b.n, dep ? 1 : b.max_refs());
+    if (b.n == 1) hipLaunchKernelGGL(hme_kernel<OnePicture>, grid, dim3(HME_THREADS), HME_WIN_BYTES + 64, s, OnePicture{b.host[0]}, b.n_b64());
+    else hipLaunchKernelGGL(hme_kernel<ManyPictures>, grid, dim3(HME_THREADS), HME_WIN_BYTES + 64, s, ManyPictures{b.dev}, b.n_b64());
     if (marks[0]) (void)hipEventRecord(marks[0], s);
     if (marks[1]) (void)hipEventRecord(marks[1], s);
 }

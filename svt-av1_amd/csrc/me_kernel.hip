@@ -73,15 +73,20 @@ __device__ __forceinline__ void min4(const uint32_t (&k)[4], uint32_t &best, uin
 // Work items of a w x h window: one per (64-position column chunk, group of 8 rows).
 __device__ __forceinline__ int me_item_count(int w, int h) { return ((w + ME_TILE - 1) / ME_TILE) * ((h + 7) >> 3); }
 
-__global__ void __launch_bounds__(ME_THREADS) me_plan_kernel(PicParams p) {
+template <class PICS>
+__global__ void __launch_bounds__(ME_THREADS) me_plan_kernel(PICS pp, int n_b64, int me_ref0) {
     __shared__ MeShared S;
+    const PicParams      &p   = pp[blockIdx.x / n_b64];
     const svtme_controls &k   = p.ctrl;
     const int             tid = threadIdx.x;
-    const int             b64 = blockIdx.x;
+    const int             b64 = blockIdx.x % n_b64;
     const int             b64x = (b64 % p.b64_w) * 64, b64y = (b64 / p.b64_w) * 64;
     const int             block_w = min(p.width - b64x, 64), block_h = min(p.height - b64y, 64);
 
-    const int my_idx = p.me_ref0 + (int)blockIdx.y;
+    // me_ref0: first reference (list-0 references first, then list 1) this launch covers; the grid covers the batch's
+    // longest reference list
+    const int my_idx = me_ref0 + (int)blockIdx.y;
+    if (my_idx >= p.n_ref[0] + (p.n_list == 2 ? p.n_ref[1] : 0)) return;
     int       my_l = 0, my_r = my_idx;
     if (my_r >= p.n_ref[0]) {
         my_r -= p.n_ref[0];
@@ -285,15 +290,19 @@ __global__ void __launch_bounds__(ME_THREADS) me_plan_kernel(PicParams p) {
     }
 }
 
-__global__ void __launch_bounds__(ME_THREADS, 2) me_search_kernel(PicParams p) {
+template <class PICS>
+__global__ void __launch_bounds__(ME_THREADS, 2) me_search_kernel(PICS pp, int n_b64, int ref_first, int ref_last) {
     __shared__ MeShared               S;
     __shared__ __align__(16) uint32_t win[ME_WIN_BYTES / 4];
+    const PicParams &p = pp[blockIdx.x / n_b64];
     const int tid = threadIdx.x;
-    const int b64 = blockIdx.x;
+    const int b64 = blockIdx.x % n_b64;
     const int b64x = (b64 % p.b64_w) * 64, b64y = (b64 / p.b64_w) * 64;
     // references in reverse order: the closest references (smallest windows, cheapest items) are dispatched last and
-    // keep the kernel's tail short
-    int       my_l = 0, my_r = p.me_ref0 + (int)(gridDim.z - 1 - blockIdx.z);
+    // keep the kernel's tail short. The grid covers the batch's longest reference list; the launch covers references
+    // ref_first .. ref_last (list-0 references first, then list 1).
+    int       my_l = 0, my_r = p.n_ref[0] + (p.n_list == 2 ? p.n_ref[1] : 0) - 1 - (int)blockIdx.z;
+    if (my_r < ref_first || my_r > ref_last) return;
     if (my_r >= p.n_ref[0]) {
         my_r -= p.n_ref[0];
         my_l = 1;
@@ -567,7 +576,9 @@ __global__ void __launch_bounds__(ME_THREADS, 2) me_search_kernel(PicParams p) {
 
 // ---- results: p_sb_best_sad / p_sb_best_mv, one plane per reference of the picture. SADs were taken on every other
 // row: x2 (:248-305). References that were not searched (pruned) read as zero.
-__global__ void __launch_bounds__(256) me_finish_kernel(PicParams p) {
+template <class PICS>
+__global__ void __launch_bounds__(256) me_finish_kernel(PICS pp) {
+    const PicParams &p = pp[blockIdx.y];
     const int n_b64 = p.b64_w * p.b64_h, per_plane = n_b64 * SVTME_PU_COUNT;
     const int n = (p.n_ref[0] + p.n_ref[1]) * per_plane;
     const int i = blockIdx.x * 256 + threadIdx.x;
@@ -606,35 +617,62 @@ __global__ void __launch_bounds__(256) me_finish_kernel(PicParams p) {
     p.best_mv[i]  = mv;
 }
 
-void launch_me(const PicParams &p_in, hipStream_t s, hipEvent_t marks[3]) {
-    PicParams p      = p_in;
-    const int n_refs = p.n_ref[0] + (p.n_list == 2 ? p.n_ref[1] : 0);
-    const int n_b64  = p.b64_w * p.b64_h;
+// The parameter records of a batch go to device memory as kernel arguments of a one-workgroup kernel, three per launch:
+// a copy engine in the middle of a stream of kernels costs the stream tens of microseconds of hand-over each way, a kernel
+// in front of kernels costs a launch.
+struct ParamsArg {
+    PicParams p[3];
+};
+static_assert(sizeof(ParamsArg) + 16 <= 4096, "kernel arguments are limited to 4 KB");
+__global__ void __launch_bounds__(256) params_write_kernel(ParamsArg a, PicParams *dst, int n) {
+    const uint32_t *src = reinterpret_cast<const uint32_t *>(&a);
+    uint32_t       *d   = reinterpret_cast<uint32_t *>(dst);
+    for (int i = threadIdx.x; i < n * (int)(sizeof(PicParams) / 4); i += 256) d[i] = src[i];
+}
+
+void launch_params_write(const PicParams *host, PicParams *dev, int n, hipStream_t s) {
+    for (int i = 0; i < n; i += 3) {
+        ParamsArg a;
+        const int m = n - i < 3 ? n - i : 3;
+        for (int j = 0; j < 3; ++j) a.p[j] = host[i + (j < m ? j : 0)];
+        hipLaunchKernelGGL(params_write_kernel, dim3(1), dim3(256), 0, s, a, dev + i, m);
+    }
+}
+
+template <class PICS>
+static void launch_me_as(const Batch &b, PICS pics, hipStream_t s, hipEvent_t marks[3]) {
+    const PicParams &p = b.host[0]; // size, controls and me_type are the batch's
+    const int n_refs = b.max_refs(), n_b64 = b.n_b64();
     // The screen-content search-range rule (enable_me_sr_adjustment == 2 without the zero-MV early exit) makes every
     // other reference's area depend on the first reference's 64x64 result (EbMotionEstimation.c:1390-1399): that
     // reference is planned and searched first, the others after it. (When list 0 / reference 0 is not searched at all
     // the reference code reads whatever the previous block left; protect_closest_refs rules that out for the presets
     // that use the rule.)
     const bool two_phase = p.ctrl.enable_me_sr_adjustment == 2 && p.ctrl.me_early_exit_th == 0 && n_refs > 1;
+    int        me_ref0 = 0;
     if (two_phase) {
-        p.me_ref0 = 0;
-        hipLaunchKernelGGL(me_plan_kernel, dim3(n_b64, 1), dim3(ME_THREADS), 0, s, p);
-        hipLaunchKernelGGL(me_search_kernel, dim3(n_b64, p.me_max_items, 1), dim3(ME_THREADS), 0, s, p);
-        p.me_ref0 = 1;
+        hipLaunchKernelGGL(me_plan_kernel<PICS>, dim3(n_b64 * b.n, 1), dim3(ME_THREADS), 0, s, pics, n_b64, 0);
+        hipLaunchKernelGGL(me_search_kernel<PICS>, dim3(n_b64 * b.n, p.me_max_items, n_refs), dim3(ME_THREADS), 0, s, pics, n_b64, 0, 0);
+        me_ref0 = 1;
     }
-    const int n_now = n_refs - p.me_ref0;
-    hipLaunchKernelGGL(me_plan_kernel, dim3(n_b64, n_now), dim3(ME_THREADS), 0, s, p);
+    const int n_now = n_refs - me_ref0;
+    hipLaunchKernelGGL(me_plan_kernel<PICS>, dim3(n_b64 * b.n, n_now), dim3(ME_THREADS), 0, s, pics, n_b64, me_ref0);
     if (marks[0]) (void)hipEventRecord(marks[0], s);
-    hipLaunchKernelGGL(me_search_kernel, dim3(n_b64, p.me_max_items, n_now), dim3(ME_THREADS), 0, s, p);
+    hipLaunchKernelGGL(me_search_kernel<PICS>, dim3(n_b64 * b.n, p.me_max_items, n_refs), dim3(ME_THREADS), 0, s, pics, n_b64, me_ref0, 1 << 30);
     if (marks[1]) (void)hipEventRecord(marks[1], s);
-    hipLaunchKernelGGL(me_finish_kernel, dim3((n_b64 * n_refs * SVTME_PU_COUNT + 255) / 256), dim3(256), 0, s, p);
+    hipLaunchKernelGGL(me_finish_kernel<PICS>, dim3((n_b64 * n_refs * SVTME_PU_COUNT + 255) / 256, b.n), dim3(256), 0, s, pics);
     if (marks[2]) (void)hipEventRecord(marks[2], s);
+}
+
+void launch_me(const Batch &b, hipStream_t s, hipEvent_t marks[3]) {
+    if (b.n == 1) launch_me_as(b, OnePicture{b.host[0]}, s, marks);
+    else launch_me_as(b, ManyPictures{b.dev}, s, marks);
 }
 
 // resident workgroups per CU the runtime expects for the search kernel (diagnostic)
 int occupancy_me_search() {
     int n = 0;
-    (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, me_search_kernel, ME_THREADS, 0);
+    (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, me_search_kernel<OnePicture>, ME_THREADS, 0);
     return n;
 }
 

@@ -38,6 +38,15 @@ __device__ __forceinline__ void clip_axis(int o, int16_t &org, int16_t &size, in
     if (o + org + size > dim) size = (int16_t)max(1, size - ((o + org + size) - dim));
 }
 
+// Orders the LDS traffic of one wave: what its lanes wrote before is what its lanes read after. A wave's LDS instructions
+// execute in order, so nothing has to be waited for; the fence and the scheduling barrier only keep the compiler from moving
+// accesses across this point. For code that runs as one wave among several of a workgroup, where __syncthreads() would
+// make every wave of the workgroup meet.
+__device__ __forceinline__ void wave_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+}
+
 // lane ^ 1 and lane ^ 2 within a quad, as DPP quad_perm moves (no LDS traffic)
 __device__ __forceinline__ uint32_t quad_xor1(uint32_t v) { return (uint32_t)__builtin_amdgcn_mov_dpp((int)v, 0xB1, 0xF, 0xF, true); }
 __device__ __forceinline__ uint32_t quad_xor2(uint32_t v) { return (uint32_t)__builtin_amdgcn_mov_dpp((int)v, 0x4E, 0xF, 0xF, true); }

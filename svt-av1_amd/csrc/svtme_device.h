@@ -45,7 +45,10 @@ struct MeJob {
     int16_t org_x, org_y, w, h;
 };
 
-// Everything a picture's kernels need, passed by value as the kernel argument.
+// Everything a picture's kernels need. A launch covers the pictures of one batch: their records lie next to each other in
+// device memory and a workgroup picks its picture from its index (blockIdx.x / n_b64, or a grid dimension of its own).
+// The pictures of a batch have one size, one set of controls and one me_type; they differ in planes, reference lists,
+// distances, layer and buffers.
 struct PicParams {
     DevPicture     cur;
     DevPicture     ref[SVTME_MAX_LISTS][SVTME_MAX_REFS];
@@ -60,13 +63,12 @@ struct PicParams {
     int32_t        serial_refs; // 1: one workgroup walks all references of a b64 in order (the serial HME kernel)
     int32_t        dep_pre; // list-1 pre-HME searches read the list-0 results (check_prehme_early_exit :1759-1768)
     int32_t        dep_l0; // the level-0 area of every reference but the first depends on the first one's vector (:1838-1850)
-    int32_t        hme_phase; // 0: every level-0 / pre-HME item; 1: the items others depend on; 2: the dependent items
     int32_t        me_type; // SVTME_ME_OPEN_LOOP / SVTME_ME_MCTF / SVTME_ME_FIRST_PASS
     int32_t        bypass_zz_check; // first pass only
     int32_t        restricted; // integer search windows stay inside the picture (restricted_motion_vector, one tile)
     uint32_t       tf_me_exit_th;
-    int32_t        me_ref0; // first reference (list-0 references first, then list 1) the integer-search launch covers
     int32_t        me_max_items; // upper bound of search work items per (b64, ref) for this picture's controls
+    int32_t        zero; // always 0, but the compiler cannot know: keeps it from merging loads that must stay apart
     // intermediates
     MeJob              *me_jobs; // [n_b64][2][4]
     unsigned long long *me_keys; // [n_b64][2][4][85] running minima (SAD << 32 | y << 16 | x), window-relative
@@ -98,15 +100,43 @@ struct PicParams {
 constexpr int SVTME_OPS_SLOTS = 64;
 constexpr int SVTME_OPS_BYTES = SVTME_OPS_SLOTS * 8 * 8;
 
+// How a kernel receives its pictures' records. One picture: the record itself is the kernel argument (it arrives with
+// the dispatch, in scalar registers' reach, nothing to fetch). A batch: a pointer to the records in device memory.
+struct OnePicture {
+    PicParams p;
+    __device__ __forceinline__ const PicParams &operator[](int) const { return p; }
+};
+struct ManyPictures {
+    const PicParams *__restrict__ pp;
+    __device__ __forceinline__ const PicParams &operator[](int i) const { return pp[i]; }
+};
+
+// The pictures one set of launches covers.
+struct Batch {
+    const PicParams *host; // n records: the host's copies of what `dev` holds
+    const PicParams *dev; // the same n records in device memory
+    int              n;
+    int              n_b64() const { return host[0].b64_w * host[0].b64_h; }
+    int              max_refs() const {
+        int m = 0;
+        for (int i = 0; i < n; ++i) {
+            const int r = host[i].n_ref[0] + (host[i].n_list == 2 ? host[i].n_ref[1] : 0);
+            m           = r > m ? r : m;
+        }
+        return m;
+    }
+};
+
 // store kernels (store_kernels.hip)
 void launch_store_build(const uint8_t *luma, int luma_stride, const DevPicture &pic, int hme_level1, hipStream_t s);
 // search kernels
 // Each launcher records marks[i] (when not null) on the stream after its i-th kernel (timing only). The buffers hold
 // zeroed hme_out and operation counters on entry (me_finish_kernel leaves them so).
-void launch_hme(const PicParams &p, hipStream_t s, hipEvent_t marks[2]); // picks the serial or the itemised kernels
-void launch_hme_items(const PicParams &p, hipStream_t s, hipEvent_t marks[2]);
-void launch_me(const PicParams &p, hipStream_t s, hipEvent_t marks[3]);
-void launch_tail(const PicParams &p, hipStream_t s); // after launch_me, when p.tail.enable
+void launch_params_write(const PicParams *host, PicParams *dev, int n, hipStream_t s); // n records -> device memory, by kernel
+void launch_hme(const Batch &b, hipStream_t s, hipEvent_t marks[2]); // picks the serial or the itemised kernels
+void launch_hme_items(const Batch &b, hipStream_t s, hipEvent_t marks[2]);
+void launch_me(const Batch &b, hipStream_t s, hipEvent_t marks[3]);
+void launch_tail(const Batch &b, hipStream_t s); // after launch_me, when the pictures have a device tail
 
 int  occupancy_me_search();
 void occupancy_hme_items(int out[2]);

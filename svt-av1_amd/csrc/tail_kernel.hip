@@ -41,12 +41,14 @@ __device__ __forceinline__ u64 wave_sum_u64(u64 v) {
     return v;
 }
 
-__global__ void __launch_bounds__(TAIL_THREADS) me_tail_kernel(PicParams p) {
+template <class PICS>
+__global__ void __launch_bounds__(TAIL_THREADS) me_tail_kernel(PICS pp, int n_b64) {
     __shared__ TailShared S;
+    const PicParams      &p    = pp[blockIdx.x / n_b64];
     const svtme_controls &k    = p.ctrl;
     const svtme_tail     &t    = p.tail;
     const int             lane = threadIdx.x;
-    const int             b64  = blockIdx.x;
+    const int             b64  = blockIdx.x % n_b64;
     const int             b64x = (b64 % p.b64_w) * 64, b64y = (b64 / p.b64_w) * 64;
     const uint32_t        block_w = (uint32_t)min(p.width - b64x, 64), block_h = (uint32_t)min(p.height - b64y, 64);
     // best SAD / MV of reference (l, r), partition n: one plane per reference of the picture, list 0 first
@@ -297,8 +299,9 @@ __global__ void __launch_bounds__(TAIL_THREADS) me_tail_kernel(PicParams p) {
     }
 }
 
-void launch_tail(const PicParams &p, hipStream_t s) {
-    hipLaunchKernelGGL(me_tail_kernel, dim3(p.b64_w * p.b64_h), dim3(TAIL_THREADS), 0, s, p);
+void launch_tail(const Batch &b, hipStream_t s) {
+    if (b.n == 1) hipLaunchKernelGGL(me_tail_kernel<OnePicture>, dim3(b.n_b64()), dim3(TAIL_THREADS), 0, s, OnePicture{b.host[0]}, b.n_b64());
+    else hipLaunchKernelGGL(me_tail_kernel<ManyPictures>, dim3(b.n_b64() * b.n), dim3(TAIL_THREADS), 0, s, ManyPictures{b.dev}, b.n_b64());
 }
 
 } // namespace svtme

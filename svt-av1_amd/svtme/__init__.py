@@ -116,7 +116,8 @@ EXPORTS = ("svtme_version", "svtme_derive_controls", "svtme_derive_tf_controls",
            "svtme_store_put", "svtme_store_release", "svtme_store_read", "svtme_picture_submit", "svtme_picture_wait",
            "svtme_picture_done", "svtme_picture_timing", "svtme_picture_ops", "svtme_unpack_b64",
            "svtme_picture_search_static", "svtme_store_put_pinned", "svtme_store_wait", "svtme_host_register",
-           "svtme_host_unregister", "svtme_host_alloc", "svtme_host_free")
+           "svtme_host_unregister", "svtme_host_alloc", "svtme_host_free", "svtme_pictures_submit")
+MAX_BATCH = 32
 STATIC_MAX_B64 = 2040
 
 
@@ -155,6 +156,7 @@ def load_library():
     lib.svtme_host_free.argtypes = [C.c_void_p, C.c_void_p]
     lib.svtme_store_read.argtypes = [C.c_void_p, C.c_uint64, C.c_int, C.c_void_p, C.c_size_t] + [C.POINTER(C.c_uint32)] * 4
     lib.svtme_picture_submit.argtypes = [C.c_void_p, C.POINTER(Picture), C.POINTER(C.c_uint64)]
+    lib.svtme_pictures_submit.argtypes = [C.c_void_p, C.POINTER(Picture), C.c_uint32, C.POINTER(C.c_uint64)]
     lib.svtme_picture_wait.argtypes = [C.c_void_p, C.c_uint64, C.POINTER(Results)]
     lib.svtme_picture_done.argtypes = [C.c_void_p, C.c_uint64]
     lib.svtme_picture_timing.argtypes = [C.c_void_p, C.c_uint64, C.POINTER(C.c_float * 8)]
@@ -317,6 +319,16 @@ class Engine:
         if rc:
             raise SvtmeError(rc, "svtme_picture_submit")
         return t.value
+
+    def submit_batch(self, pics):
+        """svtme_pictures_submit: the pictures share their kernel launches; returns their tickets."""
+        n = len(pics)
+        arr = (Picture * n)(*pics)
+        t = (C.c_uint64 * n)()
+        rc = self.lib.svtme_pictures_submit(self.h, arr, n, t)
+        if rc:
+            raise SvtmeError(rc, "svtme_pictures_submit")
+        return list(t)
 
     def wait(self, ticket, copy=True):
         """Returns a dict of numpy arrays shaped [n_b64, 2, 4, ...]."""

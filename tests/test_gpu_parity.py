@@ -493,6 +493,60 @@ def test_concurrent_puts_and_searches_from_several_threads():
             assert a["search_results"].tobytes() == b["search_results"].tobytes()
 
 
+@pytest.mark.parametrize("w,h,n,mode,structure,sc,with_tail", [
+    (320, 192, 17, 8, "ra", 0, False), (264, 136, 17, 3, "ra", 0, False), (256, 192, 17, 12, "ra", 0, False),
+    (256, 192, 9, 13, "ldb", 0, False), (192, 128, 9, 4, "ra", 1, False), (320, 192, 17, 8, "ra", 0, True),
+    (200, 136, 9, 6, "ldp", 0, True)])
+def test_batched_pictures_share_launches_and_give_the_same_results(w, h, n, mode, structure, sc, with_tail):
+    """svtme_pictures_submit: a whole mini-GOP (pictures with different reference lists, distances and layers) in one set
+    of launches, incl. the presets whose references depend on each other (two-phase HME launches) and the screen-content
+    rule (two-phase search launches), with and without the device tail: every array equals the one-by-one results."""
+    frames, pics, _ = support.make_job(w, h, n, mode, seed=77, structure=structure)
+    tail = None
+    if with_tail:
+        from svtme import gop
+        b0, b1, n0, n1 = gop.mrp_counts(mode)
+        l0, l1 = max(b0, n0), max(b1, n1)
+        tail = svtme.Tail(enable=1, enable_me_8x8=1, enable_me_16x16=1, max_refs=l0 + l1, max_cand=min(23, l0 + l1 + l0 * l1 + l0), max_l0=l0,
+                          input_resolution=svtme.input_resolution(w, h), gm_enabled=1, gm_use_distance_based_active_th=1)
+    want = support.run_engine_job(frames, pics, mode, sc, tail=tail)
+    eng = svtme.Engine(w, h, store_slots=n + 1, max_in_flight=len(pics))
+    try:
+        for i in range(n):
+            eng.store_put(i, i, frames[i])
+        ctrl = svtme.derive_controls(mode, w, h, sc)
+        descs = [eng.make_picture(w, h, p.poc, p.temporal_layer, p.is_ref, p.refs, ctrl, tail=tail) for p in pics]
+        for rep in range(2):  # the second round runs on the buffers the first one left
+            tickets = eng.submit_batch(descs)
+            assert len(set(tickets)) == len(descs)
+            got = []
+            for t in reversed(tickets):  # any order
+                got.append(eng.wait(t))
+                assert eng.timing(t)[7] == len(descs)
+                got[-1]["ops"] = eng.ops(t)
+            for t in tickets:
+                eng.done(t)
+            got.reverse()
+            for p, a, b in zip(pics, want, got):
+                assert sorted(k_ for k_ in a if k_ not in ("timing_ms",)) == sorted(b), p.poc
+                for f in b:
+                    if f == "search_results":
+                        assert a[f].tobytes() == b[f].tobytes(), (rep, p.poc, f)
+                    elif f == "ops":
+                        assert a[f] == b[f], (rep, p.poc, f)
+                    else:
+                        assert np.array_equal(a[f], b[f]), (rep, p.poc, f)
+        # pictures that do not go together are refused as a batch
+        ctrl2 = svtme.derive_controls(mode, w, h, sc)
+        ctrl2.me_sa.sa_max.height += 1
+        other = eng.make_picture(w, h, pics[0].poc, pics[0].temporal_layer, pics[0].is_ref, pics[0].refs, ctrl2, tail=tail)
+        with pytest.raises(svtme.SvtmeError) as ei:
+            eng.submit_batch([descs[0], other])
+        assert ei.value.code == svtme.ERR_BAD_ARG
+    finally:
+        eng.close()
+
+
 def test_pictures_in_flight_and_unpack():
     """Several pictures queued before the first wait give the same results as one at a time; svtme_unpack_b64
     copies the MeContext-shaped arrays of one block."""
