@@ -6,10 +6,16 @@
 
 A step = the ME of one mini-GOP (all its pictures x all their references) over synthetic pictures that are already
 resident in the device picture store when the timed region starts; results (best SAD / MV per partition, search
-centres) are copied back to pinned host memory inside the timed region. Pictures are independent, so every rank
-runs its own mini-GOPs (weak scaling, no data-path collective); rank 0 prints one JSON line. The K timed steps run
-back to back with at most --in-flight pictures outstanding (mini-GOPs follow each other without a pause, as in the
-encoder); all of them have been waited for when the clock stops.
+centres) are copied back to pinned host memory inside the timed region. The K timed steps run back to back with at
+most --in-flight pictures outstanding (mini-GOPs follow each other without a pause, as in the encoder); all of them
+have been waited for when the clock stops. Rank 0 prints one JSON line.
+
+N > 1 shards ONE sequence: every rank generates the same K mini-GOPs (same seed) and runs its share of their pictures.
+Pictures are independent (they read source pictures only), so there is no data-path collective; a picture goes to the
+rank with the least work so far (svtme.scheduler.assign_balanced over the pictures' operation counts, which every rank
+computes identically), `value` = all pictures of the sequence / the slowest rank's time ("strong" scaling: the
+sequence is fixed, the ranks split it). With --with-upload every rank also puts, inside the timed region, the sources
+its share of each mini-GOP reads; `sources_put_per_picture` then says how many GPUs a source travelled to.
 
 `value` comes from the timed region, in which the engine rotates pictures over three HIP streams (one picture's
 kernel tails overlap the other pictures' kernels). Kernel durations measured there include that sharing, so the
@@ -153,13 +159,14 @@ def main():
 
     import svtme
     wl = dict(WORKLOADS[args.workload], name=args.workload)
+    sharded = world > 1  # one sequence, split over the ranks
     if args.batch <= 0:
         args.batch = wl.get("batch", 1)
     args.batch = min(args.batch, svtme.MAX_BATCH)
     if args.in_flight <= 0:
         args.in_flight = max(6, 3 * args.batch)
     args.in_flight = max(args.in_flight, args.batch)
-    frames, pics = make_pictures(wl, seed=1000 + rank)
+    frames, pics = make_pictures(wl, seed=1000)  # every rank sees the same sequence
     n, h, w = frames.shape
     tf, fp = wl.get("tf"), wl.get("fp")
     ctrl = (svtme.derive_tf_controls(tf[0]) if tf else
@@ -210,24 +217,21 @@ def main():
         descs_alt = [[eng.make_picture(w, h, p.poc, p.temporal_layer, p.is_ref, p.refs, ctrl, tail=tail,
                                        tf_me_exit_th=tf[1] if tf else None, first_pass_bypass_zz=fp[0] if fp else None,
                                        key_of=lambda poc, ks=ks: 1000 * ks + poc) for p in pics] for ks in range(KEY_SETS)]
-        need_before = []  # per picture of the dispatch order: the sources no earlier picture of the step has needed
-        seen = set()
-        for p in pics:
-            srcs = [p.poc] + [r for lst in p.refs for r in lst]
-            need_before.append([k_ for k_ in dict.fromkeys(srcs) if k_ not in seen])
-            seen.update(srcs)
 
-    def put_sources(e, i, ks):
-        for k_ in need_before[i]:
-            view = pool[k_, 72:72 + h, 72:72 + w]
-            if args.upload_mode == "pinned":
-                e.store_put_pinned(1000 * ks + k_, k_, view)
-            else:
-                e.store_put(1000 * ks + k_, k_, view)
+    puts_made = [0]
 
-    def run_steps(k, collect, e=None, ds=None, upload=False):
+    def put_source(e, k_, ks):
+        view = pool[k_, 72:72 + h, 72:72 + w]
+        if args.upload_mode == "pinned":
+            e.store_put_pinned(1000 * ks + k_, k_, view)
+        else:
+            e.store_put(1000 * ks + k_, k_, view)
+        puts_made[0] += 1
+
+    def run_steps(k, collect, e=None, ds=None, upload=False, owners=None):
         """k steps back to back: at most --in-flight pictures outstanding, also across step boundaries (mini-GOPs follow
-        each other without a pause, as they do in the encoder); everything has been waited for on return."""
+        each other without a pause, as they do in the encoder); everything has been waited for on return. owners: the
+        rank of every picture of the k steps (this rank runs its own ones only)."""
         e, ds = e or eng, ds or descs
         tickets, group = [], []
 
@@ -239,9 +243,15 @@ def main():
 
         for step in range(k):
             ks = step % KEY_SETS
+            seen = set()  # sources this rank has put for this step
             for i, d in enumerate(descs_alt[ks] if upload else ds):
+                if owners is not None and owners[step * len(ds) + i] != rank:
+                    continue
                 if upload:
-                    put_sources(e, i, ks)
+                    for k_ in dict.fromkeys([pics[i].poc] + [r for lst in pics[i].refs for r in lst]):
+                        if k_ not in seen:
+                            seen.add(k_)
+                            put_source(e, k_, ks)
                 group.append(d)
                 if len(group) == args.batch:
                     flush()
@@ -263,17 +273,41 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    run_steps(args.warmup, None, upload=args.with_upload)
+    owners_warm = owners_timed = None
+    per_rank = [len(descs) * args.steps]
+    if sharded:
+        # what each picture of a mini-GOP costs: its operation count (exact, the same on every rank) plus a fixed share
+        # for the per-picture overheads; every rank runs the mini-GOP once to read the counters
+        cal = new_stats()
+        per_pic = []
+        for d in descs:
+            t = eng.submit(d)
+            eng.wait(t, copy=False)
+            per_pic.append(float(sum(eng.ops(t))))
+            eng.done(t)
+        fixed = 0.25 * sum(per_pic) / len(per_pic)
+        costs = [c + fixed for c in per_pic]
+        from svtme import scheduler
+        owners_warm = scheduler.assign_balanced(costs * max(1, args.warmup), world)
+        owners_timed = scheduler.assign_balanced(costs * args.steps, world)
+        per_rank = [owners_timed.count(r) for r in range(world)]
+    run_steps(args.warmup, None, upload=args.with_upload, owners=owners_warm)
     barrier()
+    puts_made[0] = 0
     t0 = time.perf_counter()
-    run_steps(args.steps, None, upload=args.with_upload)  # nothing but (put,) submit / wait / done per picture inside the timed region
+    # nothing but (put,) submit / wait / done per picture inside the timed region
+    run_steps(args.steps, None, upload=args.with_upload, owners=owners_timed)
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
     barrier()
+    puts_timed = puts_made[0]
     if use_dist:  # the slowest rank's time (before rank 0 goes on to its reporting passes, so that no rank waits in a collective)
         tt = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if rehearsal else "cuda")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
+        tp = torch.tensor([float(puts_timed)], dtype=torch.float64, device="cpu" if rehearsal else "cuda")
+        dist.all_reduce(tp, op=dist.ReduceOp.SUM)
+        puts_timed = int(tp.item())
     run_steps(min(args.steps, 4), stats)  # kernel spans while the streams share the GPU (reported beside the solo timings)
     # host -> device: what putting one new source picture into the store costs (pinned staging copy, H2D, the pad /
     # decimate kernels); every picture is put once and then read by its own search and by up to 7 later ones
@@ -296,7 +330,7 @@ def main():
         run_steps(args.kernel_steps, solo)
         torch.cuda.synchronize()
     if rank == 0:
-        pictures = len(descs) * args.steps * world
+        pictures = len(descs) * args.steps  # one sequence, whatever the number of ranks
         L = max(1, solo["launches"])
         ops = solo["ops"] / L  # per picture = per launch of each kernel
         ms = solo["ms"] / L  # per-kernel launch durations, HIP events on the kernels' stream, one search stream
@@ -329,13 +363,17 @@ def main():
         out = {
             "metric": "open-loop ME pictures/s", "value": pictures / elapsed, "unit": "pictures/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u8", "data": "synthetic",
+            "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "u8", "data": "synthetic",
             "config": {"workload": args.workload, "width": w, "height": h,
                        "preset": ("tf hme_me_level %d, me_exit_th %d" % tf if tf else
                                   "first pass, bypass_zz_check %d, reduce_me_search %d" % fp if fp else wl["enc_mode"]),
                        "pred_structure": wl["structure"], "pictures_per_step": len(descs),
                        "refs_per_picture": round(refs_per_pic, 2), "bit_depth": wl["bit_depth"],
-                       "parallelism": "pictures sharded over %d GPU(s), no data-path collective" % world},
+                       "parallelism": "the pictures of one sequence sharded over %d GPU(s) by least accumulated work, "
+                                      "no data-path collective" % world},
+            "sharding": {"pictures_per_rank": per_rank,
+                         "sources_put_per_picture": (puts_timed / float(pictures)) if args.with_upload else None,
+                         "sources_per_step": n},
             "roofline": {
                 "bound": "valu", "kernel": name, "achieved": achieved, "peak": PEAK_SAD_TOPS,
                 "unit": "T abs-diff-acc/s", "frac": achieved / PEAK_SAD_TOPS, "traffic": traffic,

@@ -373,6 +373,32 @@ int svtme_unpack_b64(const svtme_results *res, uint32_t b64_index, uint32_t *p_s
                      uint32_t *p_sb_best_mv, svtme_search_result *search_results, uint32_t *zz_sad,
                      uint32_t *reduce_me_sr_divisor);
 
+/*
+ * Several engines, one per GPU of a node, behind one handle: the picture-sharding scheduler. It has no counterpart in the
+ * reference (which has one address space); it sits where send_picture_out() posts the pictures of a mini-GOP back to back
+ * (EbPictureDecisionProcess.c:5031-5125, :6842-6874). Open-loop ME reads source pictures only, so those pictures are
+ * independent: picture i of the submit order runs on engine i mod N. svtme_group_store_put only announces a source (the
+ * buffer must stay valid and unchanged until svtme_group_store_release: true of the encoder's y8b buffers, which live as
+ * long as their PA reference object; `pinned` != 0 says it is page-locked, see svtme_store_put_pinned); the group uploads
+ * it to an engine the first time a picture that runs there reads it, so every source reaches exactly the GPUs that need
+ * it. Announcing an existing key again (the temporal filter rewrote the planes) makes every copy stale. Results come
+ * from each GPU to its own pinned host buffers: no exchange between GPUs, no collective. `cfg` applies to every engine
+ * (its `device` is replaced by devices[i]; the same device may appear more than once). Tickets of a group are only
+ * valid with the group's wait / done. svtme_group_stats: pictures submitted, sources announced, uploads made (uploads /
+ * sources = how many GPUs a source travels to on average).
+ */
+typedef struct svtme_group svtme_group;
+int      svtme_group_create(const int32_t *devices, uint32_t n_devices, const svtme_config *cfg, svtme_group **out);
+void     svtme_group_destroy(svtme_group *g);
+uint32_t svtme_group_size(const svtme_group *g);
+int svtme_group_store_put(svtme_group *g, uint64_t key, uint64_t picture_number, const uint8_t *luma, uint32_t stride,
+                          uint32_t width, uint32_t height, int pinned);
+int svtme_group_store_release(svtme_group *g, uint64_t key);
+int svtme_group_picture_submit(svtme_group *g, const svtme_picture *pic, svtme_ticket *ticket);
+int svtme_group_picture_wait(svtme_group *g, svtme_ticket ticket, svtme_results *out);
+int svtme_group_picture_done(svtme_group *g, svtme_ticket ticket);
+int svtme_group_stats(svtme_group *g, uint64_t *pictures, uint64_t *sources, uint64_t *uploads);
+
 const char *svtme_version(void);
 
 #ifdef __cplusplus

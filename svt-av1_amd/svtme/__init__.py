@@ -116,7 +116,9 @@ EXPORTS = ("svtme_version", "svtme_derive_controls", "svtme_derive_tf_controls",
            "svtme_store_put", "svtme_store_release", "svtme_store_read", "svtme_picture_submit", "svtme_picture_wait",
            "svtme_picture_done", "svtme_picture_timing", "svtme_picture_ops", "svtme_unpack_b64",
            "svtme_picture_search_static", "svtme_store_put_pinned", "svtme_store_wait", "svtme_host_register",
-           "svtme_host_unregister", "svtme_host_alloc", "svtme_host_free", "svtme_pictures_submit")
+           "svtme_host_unregister", "svtme_host_alloc", "svtme_host_free", "svtme_pictures_submit",
+           "svtme_group_create", "svtme_group_destroy", "svtme_group_size", "svtme_group_store_put", "svtme_group_store_release",
+           "svtme_group_picture_submit", "svtme_group_picture_wait", "svtme_group_picture_done", "svtme_group_stats")
 MAX_BATCH = 32
 STATIC_MAX_B64 = 2040
 
@@ -163,6 +165,17 @@ def load_library():
     lib.svtme_picture_ops.argtypes = [C.c_void_p, C.c_uint64, C.POINTER(C.c_uint64 * 6)]
     lib.svtme_unpack_b64.argtypes = [C.POINTER(Results), C.c_uint32] + [C.c_void_p] * 5
     lib.svtme_picture_search_static.argtypes = [C.c_void_p, C.POINTER(Picture), C.c_void_p, C.c_size_t, C.POINTER(Results)]
+    lib.svtme_group_create.argtypes = [C.POINTER(C.c_int32), C.c_uint32, C.POINTER(Config), C.POINTER(C.c_void_p)]
+    lib.svtme_group_destroy.argtypes = [C.c_void_p]
+    lib.svtme_group_destroy.restype = None
+    lib.svtme_group_size.argtypes = [C.c_void_p]
+    lib.svtme_group_size.restype = C.c_uint32
+    lib.svtme_group_store_put.argtypes = [C.c_void_p, C.c_uint64, C.c_uint64, C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_int]
+    lib.svtme_group_store_release.argtypes = [C.c_void_p, C.c_uint64]
+    lib.svtme_group_picture_submit.argtypes = [C.c_void_p, C.POINTER(Picture), C.POINTER(C.c_uint64)]
+    lib.svtme_group_picture_wait.argtypes = [C.c_void_p, C.c_uint64, C.POINTER(Results)]
+    lib.svtme_group_picture_done.argtypes = [C.c_void_p, C.c_uint64]
+    lib.svtme_group_stats.argtypes = [C.c_void_p] + [C.POINTER(C.c_uint64)] * 3
     _lib = lib
     return lib
 
@@ -196,6 +209,104 @@ def derive_first_pass_controls(width, height, frame_rate=30 << 16, reduce_me_sea
     if rc:
         raise SvtmeError(rc, "svtme_derive_first_pass_controls")
     return c
+
+
+def results_to_arrays(r, copy=True):
+    """A Results struct (filled by a wait call) as a dict of numpy arrays shaped [n_b64, 2, 4, ...]."""
+    n = r.n_b64
+    out = {}
+    if r.p_sb_best_sad and copy:  # NULL for pictures submitted with tail.enable == 2
+        # one [n_b64][85] plane per reference of the picture (list 0 first) -> MeContext's [list][ref][pu] order
+        n_ref = [int(r.n_ref[0]), int(r.n_ref[1])]
+        for name, ptr in (("best_sad", r.p_sb_best_sad), ("best_mv", r.p_sb_best_mv)):
+            planes = np.ctypeslib.as_array(ptr, (n_ref[0] + n_ref[1], n, 85))
+            full = np.zeros((n, 2, 4, 85), np.uint32)
+            for l in range(2):
+                for i in range(n_ref[l]):
+                    full[:, l, i] = planes[(n_ref[0] if l else 0) + i]
+            out[name] = full
+    out.update({
+        "zz_sad": np.ctypeslib.as_array(r.zz_sad, (n, 2, 4)),
+        "sr_divisor": np.ctypeslib.as_array(r.reduce_me_sr_divisor, (n, 2, 4)),
+    })
+    raw = np.frombuffer(C.string_at(r.search_results, n * 8 * C.sizeof(SearchResult)), SEARCH_RESULT_DTYPE).reshape(n, 2, 4)
+    sr = np.zeros(raw.shape, SEARCH_RESULT_FIELDS)  # the named fields only, without the C struct's padding bytes
+    for f in SEARCH_RESULT_FIELDS.names:
+        sr[f] = raw[f]
+    out["search_results"] = sr
+    if r.me_mv_array:  # the picture ran the host tail on the device
+        out["total_me_candidate_index"] = np.ctypeslib.as_array(r.total_me_candidate_index, (n, 85))
+        out["me_mv_array"] = np.ctypeslib.as_array(r.me_mv_array, (n, 85 * TAIL_MV_STRIDE))
+        out["me_candidate_array"] = np.ctypeslib.as_array(r.me_candidate_array, (n, 85 * TAIL_CAND_STRIDE))
+        out["me_distortion"] = np.ctypeslib.as_array(r.me_distortion, (n, 85))
+        out["b64_stats"] = np.ctypeslib.as_array(r.b64_stats, (n, 8))
+        out["final_do_ref"] = np.ctypeslib.as_array(r.final_do_ref, (n, 2, 4))
+        out["final_hme_sad"] = np.ctypeslib.as_array(r.final_hme_sad, (n, 2, 4))
+    if copy:
+        out = {k: np.array(v) for k, v in out.items()}
+    return out
+
+
+class Group:
+    """svtme_group: one engine per entry of `devices`; pictures go round robin, sources travel where they are read."""
+
+    def __init__(self, devices, max_width, max_height, store_slots=24, max_in_flight=4, search_streams=0, kernel_timing=0):
+        self.lib = load_library()
+        self.h = C.c_void_p()
+        cfg = Config(0, max_width, max_height, store_slots, max_in_flight, search_streams, kernel_timing, 0)
+        dev = (C.c_int32 * len(devices))(*devices)
+        rc = self.lib.svtme_group_create(dev, len(devices), C.byref(cfg), C.byref(self.h))
+        if rc:
+            raise SvtmeError(rc, "svtme_group_create")
+        self._keep = {}  # key -> the announced luma array (the group reads it when a GPU first needs it)
+
+    def close(self):
+        if self.h:
+            self.lib.svtme_group_destroy(self.h)
+            self.h = C.c_void_p()
+        self._keep.clear()
+
+    def store_put(self, key, picture_number, luma, pinned=0):
+        assert luma.dtype == np.uint8 and luma.strides[1] == 1
+        h, w = luma.shape
+        self._keep[key] = luma
+        rc = self.lib.svtme_group_store_put(self.h, key, picture_number, luma.ctypes.data, luma.strides[0], w, h, pinned)
+        if rc:
+            raise SvtmeError(rc, "svtme_group_store_put")
+
+    def store_release(self, key):
+        rc = self.lib.svtme_group_store_release(self.h, key)
+        self._keep.pop(key, None)
+        if rc:
+            raise SvtmeError(rc, "svtme_group_store_release")
+
+    make_picture = None  # set below: the same description builder as Engine's
+
+    def submit(self, pic):
+        t = C.c_uint64()
+        rc = self.lib.svtme_group_picture_submit(self.h, C.byref(pic), C.byref(t))
+        if rc:
+            raise SvtmeError(rc, "svtme_group_picture_submit")
+        return t.value
+
+    def wait(self, ticket, copy=True):
+        r = Results()
+        rc = self.lib.svtme_group_picture_wait(self.h, ticket, C.byref(r))
+        if rc:
+            raise SvtmeError(rc, "svtme_group_picture_wait")
+        return results_to_arrays(r, copy)
+
+    def done(self, ticket):
+        rc = self.lib.svtme_group_picture_done(self.h, ticket)
+        if rc:
+            raise SvtmeError(rc, "svtme_group_picture_done")
+
+    def stats(self):
+        v = [C.c_uint64() for _ in range(3)]
+        rc = self.lib.svtme_group_stats(self.h, *[C.byref(x) for x in v])
+        if rc:
+            raise SvtmeError(rc, "svtme_group_stats")
+        return dict(pictures=v[0].value, sources=v[1].value, uploads=v[2].value)
 
 
 class Engine:
@@ -327,7 +438,9 @@ class Engine:
         t = (C.c_uint64 * n)()
         rc = self.lib.svtme_pictures_submit(self.h, arr, n, t)
         if rc:
-            raise SvtmeError(rc, "svtme_pictures_submit")
+            raise SvtmeError(rc, "svtme_pictures_submit",
+           "svtme_group_create", "svtme_group_destroy", "svtme_group_size", "svtme_group_store_put", "svtme_group_store_release",
+           "svtme_group_picture_submit", "svtme_group_picture_wait", "svtme_group_picture_done", "svtme_group_stats")
         return list(t)
 
     def wait(self, ticket, copy=True):
@@ -336,38 +449,7 @@ class Engine:
         rc = self.lib.svtme_picture_wait(self.h, ticket, C.byref(r))
         if rc:
             raise SvtmeError(rc, "svtme_picture_wait")
-        n = r.n_b64
-        out = {}
-        if r.p_sb_best_sad and copy:  # NULL for pictures submitted with tail.enable == 2
-            # one [n_b64][85] plane per reference of the picture (list 0 first) -> MeContext's [list][ref][pu] order
-            n_ref = [int(r.n_ref[0]), int(r.n_ref[1])]
-            for name, ptr in (("best_sad", r.p_sb_best_sad), ("best_mv", r.p_sb_best_mv)):
-                planes = np.ctypeslib.as_array(ptr, (n_ref[0] + n_ref[1], n, 85))
-                full = np.zeros((n, 2, 4, 85), np.uint32)
-                for l in range(2):
-                    for i in range(n_ref[l]):
-                        full[:, l, i] = planes[(n_ref[0] if l else 0) + i]
-                out[name] = full
-        out.update({
-            "zz_sad": np.ctypeslib.as_array(r.zz_sad, (n, 2, 4)),
-            "sr_divisor": np.ctypeslib.as_array(r.reduce_me_sr_divisor, (n, 2, 4)),
-        })
-        raw = np.frombuffer(C.string_at(r.search_results, n * 8 * C.sizeof(SearchResult)), SEARCH_RESULT_DTYPE).reshape(n, 2, 4)
-        sr = np.zeros(raw.shape, SEARCH_RESULT_FIELDS)  # the named fields only, without the C struct's padding bytes
-        for f in SEARCH_RESULT_FIELDS.names:
-            sr[f] = raw[f]
-        out["search_results"] = sr
-        if r.me_mv_array:  # the picture ran the host tail on the device
-            out["total_me_candidate_index"] = np.ctypeslib.as_array(r.total_me_candidate_index, (n, 85))
-            out["me_mv_array"] = np.ctypeslib.as_array(r.me_mv_array, (n, 85 * TAIL_MV_STRIDE))
-            out["me_candidate_array"] = np.ctypeslib.as_array(r.me_candidate_array, (n, 85 * TAIL_CAND_STRIDE))
-            out["me_distortion"] = np.ctypeslib.as_array(r.me_distortion, (n, 85))
-            out["b64_stats"] = np.ctypeslib.as_array(r.b64_stats, (n, 8))
-            out["final_do_ref"] = np.ctypeslib.as_array(r.final_do_ref, (n, 2, 4))
-            out["final_hme_sad"] = np.ctypeslib.as_array(r.final_hme_sad, (n, 2, 4))
-        if copy:
-            out = {k: np.array(v) for k, v in out.items()}
-        return out
+        return results_to_arrays(r, copy)
 
     def search_static(self, pic, result_block, result_bytes):
         """svtme_picture_search_static: the picture's search without any allocation, results into caller-owned memory the
@@ -404,3 +486,6 @@ class Engine:
         out["ops"] = self.ops(t)
         self.done(t)
         return out
+
+
+Group.make_picture = Engine.make_picture

@@ -15,27 +15,43 @@ def owner(dispatch_index, world):
     return dispatch_index % world
 
 
-def owned(pics, rank, world):
-    """[(dispatch index, picture)] this rank runs, in dispatch order."""
+def owned(pics, rank, world, owners=None):
+    """[(dispatch index, picture)] this rank runs, in dispatch order. owners: a per-picture rank list from
+    assign_balanced instead of the round-robin rule."""
+    if owners is not None:
+        return [(i, p) for i, p in enumerate(pics) if owners[i] == rank]
     return [(i, p) for i, p in enumerate(pics) if owner(i, world) == rank]
 
 
-def needed_sources(pics, rank, world):
+def assign_balanced(costs, world):
+    """Owners for a dispatch order whose pictures cost differently (a base-layer picture searches up to 7 references far
+    away, a top-layer one 2 next to it): each picture goes to the rank with the least work so far, ties to the lowest
+    rank. Deterministic, so every rank computes the same list from the same costs without talking to the others."""
+    load = [0.0] * world
+    owners = []
+    for c in costs:
+        r = min(range(world), key=lambda k: (load[k], k))
+        owners.append(r)
+        load[r] += float(c)
+    return owners
+
+
+def needed_sources(pics, rank, world, owners=None):
     """Sorted picture numbers whose source planes this rank's store must hold: its pictures and their references."""
     need = set()
-    for _, p in owned(pics, rank, world):
+    for _, p in owned(pics, rank, world, owners):
         need.add(p.poc)
         for lst in p.refs:
             need.update(lst)
     return sorted(need)
 
 
-def last_use(pics, rank, world):
+def last_use(pics, rank, world, owners=None):
     """{picture number: dispatch index of the last picture of this rank that reads it}: the store slot of a source
     can be released after that picture was waited for (what release_pa_reference_objects does on the host,
     Source/Lib/Encoder/Codec/EbReferenceObject.c:298)."""
     last = {}
-    for i, p in owned(pics, rank, world):
+    for i, p in owned(pics, rank, world, owners):
         last[p.poc] = i
         for lst in p.refs:
             for r in lst:
@@ -43,14 +59,15 @@ def last_use(pics, rank, world):
     return last
 
 
-def run_sharded(engine, frames_by_poc, pics, ctrl, rank, world, in_flight=4, on_result=None):
+def run_sharded(engine, frames_by_poc, pics, ctrl, rank, world, in_flight=4, on_result=None, owners=None):
     """Runs this rank's share of `pics` on `engine` (an svtme.Engine or anything with its interface).
 
     frames_by_poc: {picture number: 2-D uint8 luma}. Sources are put into the store when first needed and released
     after their last reader; at most `in_flight` pictures are submitted ahead of the one being waited for.
+    owners: per-picture ranks (assign_balanced) instead of the round-robin rule.
     Returns {dispatch index: results dict}, or passes each (index, results) to on_result and returns {}."""
-    mine = owned(pics, rank, world)
-    last = last_use(pics, rank, world)
+    mine = owned(pics, rank, world, owners)
+    last = last_use(pics, rank, world, owners)
     resident, results, queue = set(), {}, []
 
     def put(poc):

@@ -20,7 +20,8 @@ def check_line(d, expect_cpu_baseline):
         assert k in d and isinstance(d[k], t), k
     assert "vs_baseline" in d and d["vs_baseline"] is None  # no published number exists for this metric
     assert d["metric"] == "open-loop ME pictures/s" and d["unit"] == "pictures/s"
-    assert d["higher_is_better"] is True and d["scaling"] == "weak" and d["dtype"] == "u8" and d["data"] == "synthetic"
+    # round 1's lines were replicas per rank ("weak"); since then N ranks split one sequence ("strong")
+    assert d["higher_is_better"] is True and d["scaling"] in ("weak", "strong") and d["dtype"] == "u8" and d["data"] == "synthetic"
     assert isinstance(d["config"].get("workload"), str) and "model" not in d["config"]
     assert d["value"] > 0 and d["ms_per_step"] > 0
     r = d["roofline"]
@@ -56,3 +57,28 @@ def test_live_bench_line_keeps_the_contract():
     d = json.loads(lines[0])
     check_line(d, expect_cpu_baseline=True)
     assert d["n_gpus"] == 1 and d["steps"] == 6 and d["warmup"] == 2 and d["config"]["workload"] == "1080p_ra_m8"
+
+
+@pytest.mark.gpu
+def test_two_ranks_split_one_sequence_on_this_box():
+    """The N > 1 path of bench.py, rehearsed with two ranks on the one GPU of this box (process group over gloo, both
+    ranks on device 0): one sequence, every picture run by exactly one rank, sources put where they are read."""
+    import socket
+    with socket.socket() as s_:
+        s_.bind(("127.0.0.1", 0))
+        port = s_.getsockname()[1]
+    env = dict(os.environ, SVTME_BENCH_REHEARSAL="1")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                        "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "4", "--warmup", "1",
+                        "--workload", "1080p_ra_m8", "--kernel-steps", "0", "--no-cpu-baseline", "--with-upload"],
+                       capture_output=True, text=True, timeout=600, env=env)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["scaling"] == "strong" and d["value"] > 0
+    sh = d["sharding"]
+    assert sum(sh["pictures_per_rank"]) == 4 * d["config"]["pictures_per_step"] and min(sh["pictures_per_rank"]) > 0
+    # every source goes to at least one and at most two GPUs
+    per_source = sh["sources_put_per_picture"] * d["config"]["pictures_per_step"] / sh["sources_per_step"]
+    assert 1.0 <= per_source <= 2.0

@@ -850,3 +850,54 @@ def test_two_ranks_share_a_sequence_without_any_exchange():
     for i, p in enumerate(pics):
         msgs += support.compare_picture(got[i], recs[i], p, "poc %d" % p.poc)
     assert not msgs, "\n".join(msgs[:10])
+
+
+def test_engine_group_shards_one_sequence_and_moves_sources_only_where_they_are_read():
+    """svtme_group (the in-process multi-GPU path of the C ABI) with two engines on the one GPU of this box: pictures go
+    round robin, every source is uploaded once per engine that reads it, results equal the oracle's; a key announced
+    again (the temporal filter's rewrite) reaches the engines afresh."""
+    frames, pics, rc = support.make_job(256, 128, 17, 8, seed=9)
+    recs = support.oracle_handover(frames, pics, 8, rc)
+    ctrl = svtme.derive_controls(8, 256, 128)
+    grp = svtme.Group([0, 0], 256, 128, store_slots=20, max_in_flight=4)
+    try:
+        assert grp.lib.svtme_group_size(grp.h) == 2
+        for i in range(len(frames)):
+            grp.store_put(i, i, frames[i])
+        tickets, got = [], {}
+        for i, p in enumerate(pics):
+            if len(tickets) == 6:
+                j, t = tickets.pop(0)
+                got[j] = grp.wait(t)
+                grp.done(t)
+            tickets.append((i, grp.submit(grp.make_picture(256, 128, p.poc, p.temporal_layer, p.is_ref, p.refs, ctrl))))
+        for j, t in tickets:
+            got[j] = grp.wait(t)
+            grp.done(t)
+        assert [t >> 56 for _, t in tickets[-2:]] in ([0, 1], [1, 0])  # the engine index rides in the ticket
+        msgs = []
+        for i, p in enumerate(pics):
+            msgs += support.compare_picture(got[i], recs[i], p, "poc %d" % p.poc)
+        assert not msgs, "\n".join(msgs[:10])
+        st = grp.stats()
+        assert st["pictures"] == len(pics) and st["sources"] == len(frames)
+        # what each engine needs by the round-robin rule, exactly
+        need = [set(), set()]
+        for i, p in enumerate(pics):
+            need[i % 2].update([p.poc] + [r for lst in p.refs for r in lst])
+        assert st["uploads"] == len(need[0]) + len(need[1])
+        # a rewritten source: announced again, uploaded again where the next picture reads it
+        changed = frames[pics[0].refs[0][0]].copy()
+        changed[:64, :64] = 255 - changed[:64, :64]
+        grp.store_put(pics[0].refs[0][0], pics[0].refs[0][0], changed)
+        t = grp.submit(grp.make_picture(256, 128, pics[0].poc, pics[0].temporal_layer, pics[0].is_ref, pics[0].refs, ctrl))
+        again = grp.wait(t)
+        grp.done(t)
+        assert grp.stats()["uploads"] == st["uploads"] + 1
+        assert not np.array_equal(again["best_sad"], got[0]["best_sad"])
+        grp.store_release(0)
+        with pytest.raises(svtme.SvtmeError) as ei:
+            grp.store_release(0)
+        assert ei.value.code == svtme.ERR_NOT_FOUND
+    finally:
+        grp.close()

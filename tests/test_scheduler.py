@@ -23,6 +23,23 @@ def test_every_picture_has_exactly_one_owner():
         assert max(sizes) - min(sizes) <= 1
 
 
+def test_balanced_assignment_evens_out_unequal_pictures():
+    # a mini-GOP whose base-layer picture costs eight times a top-layer one, repeated
+    costs = ([8.0, 4.0, 3.0, 2.0] + [1.0] * 12) * 6
+    for world in (2, 4, 8):
+        owners = scheduler.assign_balanced(costs, world)
+        assert len(owners) == len(costs) and set(owners) == set(range(world))
+        load = [sum(c for c, o in zip(costs, owners) if o == r) for r in range(world)]
+        assert max(load) - min(load) <= max(costs)
+        rr = [sum(c for i, c in enumerate(costs) if i % world == r) for r in range(world)]
+        assert max(load) <= max(rr)  # never worse than round robin, which always hands rank 0 the expensive picture
+        assert owners == scheduler.assign_balanced(costs, world)  # every rank computes the same list
+    pics = gop.random_access(17, 3)
+    owners = scheduler.assign_balanced([1.0] * len(pics), 2)
+    seen = [i for r in range(2) for i, _ in scheduler.owned(pics, r, 2, owners)]
+    assert sorted(seen) == list(range(len(pics)))
+
+
 def test_needed_sources_cover_the_references_and_nothing_else():
     pics = gop.random_access(17, 3)
     for world in (1, 2, 4):
