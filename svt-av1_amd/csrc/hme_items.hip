@@ -40,8 +40,9 @@ struct L0Shared {
 // Level-0 vector of region (0,0) of list 0 / reference 0 (record `o`) as hme_level0_b64 leaves it (:1967-1999): the
 // region's own result unless it is the worst of the regions and a pre-HME result beats it; zero on the zero-MV early exit
 // (:1916).
-__device__ void first_ref_l0_centre(const PicParams &p, const HmeRefOut &o, int &mvx, int &mvy) {
-    const svtme_controls &k = p.ctrl;
+template <class P>
+__device__ void first_ref_l0_centre(const P &p, const HmeRefOut &o, int &mvx, int &mvy) {
+    const auto &k = p.ctrl;
     mvx = mvy = 0;
     if (!k.enable_hme_level0_flag || (k.me_early_exit_th && o.zz_sad < (k.me_early_exit_th >> 2))) return;
     mvx = o.raw_x[0];
@@ -65,9 +66,12 @@ __device__ void first_ref_l0_centre(const PicParams &p, const HmeRefOut &o, int 
 
 // get_hme_l0_search_area :1827-1894. With p.dep_l0 every reference but the first reads the first one's level-0
 // vector (`first`: the record of list 0 / reference 0, complete by then).
-__device__ void l0_area(const PicParams &p, const HmeRefOut &first, int l, int r, int16_t &sa_w, int16_t &sa_h) {
-    const svtme_controls &k  = p.ctrl;
-    svtme_sa_minmax       sa = k.hme_l0_sa;
+template <class P>
+__device__ void l0_area(const P &p, const HmeRefOut &first, int l, int r, int16_t &sa_w, int16_t &sa_h) {
+    const auto &k = p.ctrl;
+    svtme_sa_minmax sa;
+    sa.sa_min.width = k.hme_l0_sa.sa_min.width, sa.sa_min.height = k.hme_l0_sa.sa_min.height;
+    sa.sa_max.width = k.hme_l0_sa.sa_max.width, sa.sa_max.height = k.hme_l0_sa.sa_max.height;
     if (k.enable_me_sr_adjustment && k.distance_based_hme_resizing) {
         int is_hor = 1, is_ver = 1, is_still = 0;
         if (k.reduce_hme_l0_sr_th_min && k.reduce_hme_l0_sr_th_max && (l || r)) {
@@ -273,8 +277,8 @@ __device__ __forceinline__ u64 l0_search(L0Shared &S, uint32_t *win, int zero, c
 // test it; also the per-reference header fields. One wave per (b64, reference).
 template <class PICS>
 __global__ void __launch_bounds__(HI_THREADS) hme_zz_kernel(PICS pp, int n_b64) {
-    const PicParams &p   = pp[blockIdx.x / n_b64];
-    const int        b64 = blockIdx.x % n_b64;
+    const auto &p   = pp[blockIdx.x / n_b64];
+    const int   b64 = blockIdx.x % n_b64;
     const int b64x = (b64 % p.b64_w) * 64, b64y = (b64 / p.b64_w) * 64;
     const int block_w = min(p.width - b64x, 64), block_h = min(p.height - b64y, 64);
     int       l = 0, r = (int)blockIdx.y;
@@ -285,7 +289,7 @@ __global__ void __launch_bounds__(HI_THREADS) hme_zz_kernel(PICS pp, int n_b64) 
     }
     const bool searched = ref_searched(p, l);
     uint32_t   zz = ~0u;
-    if (searched) zz = wave_block_sad_sub2(p.cur.lvl[2], p.ref[l][r].lvl[2], b64x, b64y, 0, 0, block_w, block_h >> 1) << 1;
+    if (searched) zz = wave_block_sad_sub2(load_plane(p.cur.lvl[2]), load_plane(p.ref[l][r].lvl[2]), b64x, b64y, 0, 0, block_w, block_h >> 1) << 1;
     if (threadIdx.x == 0) {
         HmeRefOut *out = &p.hme_out[(b64 * SVTME_MAX_LISTS + l) * SVTME_MAX_REFS + r];
         if (searched) count_ops(p, 0, (unsigned long long)(block_h >> 1) * block_w);
@@ -298,13 +302,13 @@ __global__ void __launch_bounds__(HI_THREADS) hme_zz_kernel(PICS pp, int n_b64) 
 // whole wave. `rec` is the reference's record (global or LDS), `first` the record of list 0 / reference 0 and `same0`
 // the record of list 0 / reference r: both are only read when the picture's controls make references depend on each
 // other (p.dep_l0, p.dep_pre), and are complete by then. zz: the zero-MV SAD of the reference (~0 when not computed).
-template <bool FS>
-__device__ __forceinline__ void l0_item(const PicParams &p, L0Shared &S, uint32_t *win, int b64x, int b64y, int block_w, int block_h, int l, int r,
+template <bool FS, class P>
+__device__ __forceinline__ void l0_item(const P &p, L0Shared &S, uint32_t *win, int b64x, int b64y, int block_w, int block_h, int l, int r,
                                         int sub, uint32_t zz, HmeRefOut *rec, const HmeRefOut *first, const HmeRefOut *same0) {
-    const svtme_controls &k    = p.ctrl;
-    const int             lane = threadIdx.x & 63;
-    const DevPlane       &cur  = p.cur.lvl[0];
-    const DevPlane       &ref  = p.ref[l][r].lvl[0];
+    const auto    &k    = p.ctrl;
+    const int      lane = threadIdx.x & 63;
+    const DevPlane cur  = load_plane(p.cur.lvl[0]);
+    const DevPlane ref  = load_plane(p.ref[l][r].lvl[0]);
     const int             ox = b64x >> 2, oy = b64y >> 2;
     const int             bw = block_w >> 2, bh = block_h >> 2;
     const int             rows = FS ? bh : bh >> 1;
@@ -331,7 +335,7 @@ __device__ __forceinline__ void l0_item(const PicParams &p, L0Shared &S, uint32_
                 return;
             }
         }
-        const svtme_sa_minmax &cfg    = k.prehme_sa_cfg[sub];
+        const auto            &cfg    = k.prehme_sa_cfg[sub];
         const int              factor = scaled_dist(p.dist[l][r]);
         w     = (int16_t)(uint16_t)min((uint32_t)cfg.sa_min.width * factor, (uint32_t)cfg.sa_max.width);
         h     = (int16_t)(uint16_t)min((uint32_t)cfg.sa_min.height * factor, (uint32_t)cfg.sa_max.height);
@@ -374,9 +378,9 @@ template <bool FS, class PICS>
 __global__ void __launch_bounds__(HI_THREADS, 3) hme_l0_kernel(PICS pp, int n_b64, int hme_phase) {
     __shared__ L0Shared               S;
     __shared__ __align__(16) uint32_t win[HI_WIN_BYTES / 4 + 64];
-    const PicParams      &p   = pp[blockIdx.x / n_b64];
-    const svtme_controls &k   = p.ctrl;
-    const int             b64 = blockIdx.x % n_b64;
+    const auto &p   = pp[blockIdx.x / n_b64];
+    const auto &k   = p.ctrl;
+    const int   b64 = blockIdx.x % n_b64;
     const int             b64x = (b64 % p.b64_w) * 64, b64y = (b64 / p.b64_w) * 64;
     const int             block_w = min(p.width - b64x, 64), block_h = min(p.height - b64y, 64);
     // references in reverse order: the closest references (smallest areas, cheapest items) are dispatched last and keep
@@ -695,12 +699,12 @@ __device__ u64 quick_search(const uint32_t *src, uint32_t *win, const DevPlane &
 // to the better pre-HME result when it is the worst region (:1967-1999), then level 1 around the level-0 vector and
 // level 2 around the level-1 vector. `rec`: the reference's record with zz_sad, pre_* and raw_* complete (global or LDS);
 // src1 / src2: the sampled rows of the block at quarter / full resolution, staged by the caller.
-template <bool FS>
-__device__ __forceinline__ void l12_region(const PicParams &p, const uint32_t *src1, const uint32_t *src2, uint32_t *win, int b64x, int b64y,
+template <bool FS, class P>
+__device__ __forceinline__ void l12_region(const P &p, const uint32_t *src1, const uint32_t *src2, uint32_t *win, int b64x, int b64y,
                                            int block_w, int block_h, int l, int r, int q, HmeRefOut *rec) {
-    const svtme_controls &k    = p.ctrl;
-    const int             lane = threadIdx.x & 63;
-    const int             nw = k.num_hme_sa_w, nh = k.num_hme_sa_h;
+    const auto &k    = p.ctrl;
+    const int   lane = threadIdx.x & 63;
+    const int   nw = k.num_hme_sa_w, nh = k.num_hme_sa_h;
     const int             sw = q % nw, sh = q / nw, i = sw * 2 + sh;
     const bool            early = k.me_early_exit_th && rec->zz_sad < (k.me_early_exit_th >> 2);
 
@@ -740,14 +744,14 @@ __device__ __forceinline__ void l12_region(const PicParams &p, const uint32_t *s
             cx = cy = 0;
             continue;
         }
-        const DevPlane &ref   = p.ref[l][r].lvl[level];
+        const DevPlane  ref   = load_plane(p.ref[l][r].lvl[level]);
         const int       shift = 2 - level;
         const int       ox = b64x >> shift, oy = b64y >> shift;
         const int       bw = block_w >> shift, bh = block_h >> shift;
         const int       rows = FS ? bh : bh >> 1;
         const int       pad  = level == 2 ? 63 : ref.pad - 1;
-        const svtme_sa &sa   = level == 1 ? k.hme_l1_sa : k.hme_l2_sa;
-        int16_t         w = (int16_t)(((int16_t)sa.width + 7) & ~0x07), h = (int16_t)sa.height;
+        const int       sa_width = level == 1 ? k.hme_l1_sa.width : k.hme_l2_sa.width, sa_height = level == 1 ? k.hme_l1_sa.height : k.hme_l2_sa.height;
+        int16_t         w = (int16_t)(((int16_t)sa_width + 7) & ~0x07), h = (int16_t)sa_height;
         if (level == 1) {
             cx = (int16_t)(cx >> 1);
             cy = (int16_t)(cy >> 1);
@@ -786,15 +790,15 @@ __device__ __forceinline__ void l12_region(const PicParams &p, const uint32_t *s
 }
 
 // Both levels' source blocks of a 64x64 block: sampled rows of the quarter- and the full-resolution block, one wave.
-template <bool FS>
-__device__ __forceinline__ void stage_l12_blocks(const PicParams &p, L12Shared<FS> &S, int b64x, int b64y, int block_w, int block_h) {
-    const svtme_controls &k = p.ctrl;
+template <bool FS, class P>
+__device__ __forceinline__ void stage_l12_blocks(const P &p, L12Shared<FS> &S, int b64x, int b64y, int block_w, int block_h) {
+    const auto &k = p.ctrl;
     if constexpr (FS) {
-        if (k.enable_hme_level1_flag) stage_block<8, 1>(S.src1, p.cur.lvl[1], b64x >> 1, b64y >> 1, block_w >> 1, block_h >> 1);
-        if (k.enable_hme_level2_flag) stage_block<16, 1>(S.src2, p.cur.lvl[2], b64x, b64y, block_w, block_h);
+        if (k.enable_hme_level1_flag) stage_block<8, 1>(S.src1, load_plane(p.cur.lvl[1]), b64x >> 1, b64y >> 1, block_w >> 1, block_h >> 1);
+        if (k.enable_hme_level2_flag) stage_block<16, 1>(S.src2, load_plane(p.cur.lvl[2]), b64x, b64y, block_w, block_h);
     } else {
-        if (k.enable_hme_level1_flag) stage_block(S.src1, p.cur.lvl[1], b64x >> 1, b64y >> 1, block_w >> 1, block_h >> 2);
-        if (k.enable_hme_level2_flag) stage_block(S.src2, p.cur.lvl[2], b64x, b64y, block_w, block_h >> 1);
+        if (k.enable_hme_level1_flag) stage_block(S.src1, load_plane(p.cur.lvl[1]), b64x >> 1, b64y >> 1, block_w >> 1, block_h >> 2);
+        if (k.enable_hme_level2_flag) stage_block(S.src2, load_plane(p.cur.lvl[2]), b64x, b64y, block_w, block_h >> 1);
     }
 }
 
@@ -802,8 +806,8 @@ template <bool FS, class PICS>
 __global__ void __launch_bounds__(FS ? HI_THREADS_FS : HI_THREADS) hme_l12_kernel(PICS pp) {
     __shared__ L12Shared<FS>          S;
     __shared__ __align__(16) uint32_t win[(FS ? HI_WIN2_BYTES_FS : HI_WIN2_BYTES) / 4 + 64];
-    const PicParams      &p   = pp[blockIdx.y];
-    const svtme_controls &k   = p.ctrl;
+    const auto &p   = pp[blockIdx.y];
+    const auto &k   = p.ctrl;
     const int             nw = k.num_hme_sa_w, nh = k.num_hme_sa_h;
     const int             n_refs = p.n_ref[0] + (p.n_list == 2 ? p.n_ref[1] : 0);
     int                   b64, item;

@@ -497,8 +497,14 @@ void launch_hme(const Batch &b, hipStream_t s, hipEvent_t marks[2]) {
     bool dep = p.serial_refs != 0;
     for (int i = 0; i < b.n; ++i) dep = dep || b.host[i].dep_pre || b.host[i].dep_l0;
     dim3 grid(b.n_b64() * b.n, dep ? 1 : b.max_refs());
-    if (b.n == 1) hipLaunchKernelGGL(hme_kernel<OnePicture>, grid, dim3(HME_THREADS), HME_WIN_BYTES + 64, s, OnePicture{b.host[0]}, b.n_b64());
-    else hipLaunchKernelGGL(hme_kernel<ManyPictures>, grid, dim3(HME_THREADS), HME_WIN_BYTES + 64, s, ManyPictures{b.dev}, b.n_b64());
+    // (the serial kernel is a diagnostic: it takes the pictures of a batch one launch at a time)
+    (void)grid;
+    for (int i = 0; i < b.n; ++i) {
+        const PicParams &q = b.host[i];
+        const bool       dep_i = q.serial_refs || q.dep_pre || q.dep_l0;
+        hipLaunchKernelGGL(hme_kernel<OnePicture>, dim3(b.n_b64(), dep_i ? 1 : q.n_ref[0] + (q.n_list == 2 ? q.n_ref[1] : 0)), dim3(HME_THREADS),
+                           HME_WIN_BYTES + 64, s, OnePicture{q}, b.n_b64());
+    }
     if (marks[0]) (void)hipEventRecord(marks[0], s);
     if (marks[1]) (void)hipEventRecord(marks[1], s);
 }

@@ -76,8 +76,8 @@ __device__ __forceinline__ int me_item_count(int w, int h) { return ((w + ME_TIL
 template <class PICS>
 __global__ void __launch_bounds__(ME_THREADS) me_plan_kernel(PICS pp, int n_b64, int me_ref0) {
     __shared__ MeShared S;
-    const PicParams      &p   = pp[blockIdx.x / n_b64];
-    const svtme_controls &k   = p.ctrl;
+    const auto &p   = pp[blockIdx.x / n_b64];
+    const auto &k   = p.ctrl;
     const int             tid = threadIdx.x;
     const int             b64 = blockIdx.x % n_b64;
     const int             b64x = (b64 % p.b64_w) * 64, b64y = (b64 / p.b64_w) * 64;
@@ -205,8 +205,8 @@ __global__ void __launch_bounds__(ME_THREADS) me_plan_kernel(PICS pp, int n_b64,
     }
 
     // ---- integer_search_b64 for (my_l, my_r)
-    const DevPlane &cur = p.cur.lvl[2];
-    const DevPlane &ref = p.ref[my_l][my_r].lvl[2];
+    const DevPlane  cur = load_plane(p.cur.lvl[2]);
+    const DevPlane  ref = load_plane(p.ref[my_l][my_r].lvl[2]);
     int16_t         cx = S.sc_x[my], cy = S.sc_y[my];
     // the growth of the area with the distance is slowed down, except for the temporal filter (:1338-1341)
     const int       dist = p.me_type == SVTME_ME_MCTF ? p.dist[my_l][my_r] : scaled_dist(p.dist[my_l][my_r]);
@@ -294,7 +294,7 @@ template <class PICS>
 __global__ void __launch_bounds__(ME_THREADS, 2) me_search_kernel(PICS pp, int n_b64, int ref_first, int ref_last) {
     __shared__ MeShared               S;
     __shared__ __align__(16) uint32_t win[ME_WIN_BYTES / 4];
-    const PicParams &p = pp[blockIdx.x / n_b64];
+    const auto &p = pp[blockIdx.x / n_b64];
     const int tid = threadIdx.x;
     const int b64 = blockIdx.x % n_b64;
     const int b64x = (b64 % p.b64_w) * 64, b64y = (b64 / p.b64_w) * 64;
@@ -319,8 +319,8 @@ __global__ void __launch_bounds__(ME_THREADS, 2) me_search_kernel(PICS pp, int n
     const int ty0 = yg0 * 8, rows = min(h - ty0, 8); // search rows staged for this item
     const int r0 = 0, r1 = n_xg;
 
-    const DevPlane &cur = p.cur.lvl[2];
-    const DevPlane &ref = p.ref[my_l][my_r].lvl[2];
+    const DevPlane cur = load_plane(p.cur.lvl[2]);
+    const DevPlane ref = load_plane(p.ref[my_l][my_r].lvl[2]);
     // ---- open_loop_me_fullpel_search_sblock
     for (int i = tid; i < SVTME_PU_COUNT; i += ME_THREADS) S.best[i] = ~0ull;
     {
@@ -446,9 +446,10 @@ __global__ void __launch_bounds__(ME_THREADS, 2) me_search_kernel(PICS pp, int n
                             constexpr int t = decltype(t_c)::value;
                             constexpr int m = s - t; // sampled source row (source row 2m) of position t at this step
                             if constexpr (m >= 0 && m <= 31) {
-                                acc0[t] = __builtin_amdgcn_qsad_pk_u16_u8(p01, sw[m & 3][0], acc0[t]);
+                                // (the first row of an 8x8 block row starts its sums from the constant 0: no registers to clear)
+                                acc0[t] = __builtin_amdgcn_qsad_pk_u16_u8(p01, sw[m & 3][0], (m & 3) == 0 ? (u64)0 : acc0[t]);
                                 acc0[t] = __builtin_amdgcn_qsad_pk_u16_u8(p12, sw[m & 3][1], acc0[t]);
-                                acc1[t] = __builtin_amdgcn_qsad_pk_u16_u8(p23, sw[m & 3][2], acc1[t]);
+                                acc1[t] = __builtin_amdgcn_qsad_pk_u16_u8(p23, sw[m & 3][2], (m & 3) == 0 ? (u64)0 : acc1[t]);
                                 acc1[t] = __builtin_amdgcn_qsad_pk_u16_u8(p34, sw[m & 3][3], acc1[t]);
                                 if constexpr ((m & 3) == 3) {
                                     // an 8x8 block row of position t is complete (SAD <= 8160: the shifted key fits its 16 bits)
@@ -459,7 +460,6 @@ __global__ void __launch_bounds__(ME_THREADS, 2) me_search_kernel(PICS pp, int n
                                     b8[by][0][1] = pk_min_u16(b8[by][0][1], (h0 << 3) | ypk[t]);
                                     b8[by][1][0] = pk_min_u16(b8[by][1][0], (l1 << 3) | ypk[t]);
                                     b8[by][1][1] = pk_min_u16(b8[by][1][1], (h1 << 3) | ypk[t]);
-                                    acc0[t] = acc1[t] = 0;
                                     if constexpr ((by & 1) == 0) {
                                         t16[t][0] = pk_add_u16(l0, l1);
                                         t16[t][1] = pk_add_u16(h0, h1);
@@ -578,7 +578,7 @@ __global__ void __launch_bounds__(ME_THREADS, 2) me_search_kernel(PICS pp, int n
 // row: x2 (:248-305). References that were not searched (pruned) read as zero.
 template <class PICS>
 __global__ void __launch_bounds__(256) me_finish_kernel(PICS pp) {
-    const PicParams &p = pp[blockIdx.y];
+    const auto &p = pp[blockIdx.y];
     const int n_b64 = p.b64_w * p.b64_h, per_plane = n_b64 * SVTME_PU_COUNT;
     const int n = (p.n_ref[0] + p.n_ref[1]) * per_plane;
     const int i = blockIdx.x * 256 + threadIdx.x;
@@ -617,11 +617,12 @@ __global__ void __launch_bounds__(256) me_finish_kernel(PICS pp) {
     p.best_mv[i]  = mv;
 }
 
-// The parameter records of a batch go to device memory as kernel arguments of a one-workgroup kernel, three per launch:
+// The parameter records of a batch go to device memory as kernel arguments of a one-workgroup kernel, four per launch:
 // a copy engine in the middle of a stream of kernels costs the stream tens of microseconds of hand-over each way, a kernel
 // in front of kernels costs a launch.
+constexpr int PARAMS_PER_LAUNCH = 4;
 struct ParamsArg {
-    PicParams p[3];
+    PicParams p[PARAMS_PER_LAUNCH];
 };
 static_assert(sizeof(ParamsArg) + 16 <= 4096, "kernel arguments are limited to 4 KB");
 __global__ void __launch_bounds__(256) params_write_kernel(ParamsArg a, PicParams *dst, int n) {
@@ -631,10 +632,10 @@ __global__ void __launch_bounds__(256) params_write_kernel(ParamsArg a, PicParam
 }
 
 void launch_params_write(const PicParams *host, PicParams *dev, int n, hipStream_t s) {
-    for (int i = 0; i < n; i += 3) {
+    for (int i = 0; i < n; i += PARAMS_PER_LAUNCH) {
         ParamsArg a;
-        const int m = n - i < 3 ? n - i : 3;
-        for (int j = 0; j < 3; ++j) a.p[j] = host[i + (j < m ? j : 0)];
+        const int m = n - i < PARAMS_PER_LAUNCH ? n - i : PARAMS_PER_LAUNCH;
+        for (int j = 0; j < PARAMS_PER_LAUNCH; ++j) a.p[j] = host[i + (j < m ? j : 0)];
         hipLaunchKernelGGL(params_write_kernel, dim3(1), dim3(256), 0, s, a, dev + i, m);
     }
 }

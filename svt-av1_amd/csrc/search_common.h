@@ -23,7 +23,8 @@ __device__ __forceinline__ int scaled_dist(int dist) { return (uint16_t)(((dist 
 
 // A reference takes part in zz-SAD / pre-HME / HME unless it is a list-1 reference of a base-layer picture
 // (`temporal_layer_index > 0 || list_index == 0`, :1786, :1936, :2024, :2087, :2148, :2325).
-__device__ __forceinline__ bool ref_searched(const PicParams &p, int l) { return p.temporal_layer > 0 || l == 0; }
+template <class P>
+__device__ __forceinline__ bool ref_searched(const P &p, int l) { return p.temporal_layer > 0 || l == 0; }
 
 // The per-axis window correction all stages share (:875-907, :976-1009, :1077-1105, :1441-1460, :1502-1520,
 // :1638-1682): a window starting below `lo` is shifted, not shrunk (the size correction is computed from the
@@ -76,7 +77,8 @@ __device__ __forceinline__ bool b64_band_item(int wg, int n_b64, int items_per_b
 }
 
 // Adds n to operation counter k of this workgroup's partial-sum slot.
-__device__ __forceinline__ void count_ops(const PicParams &p, int k, unsigned long long n) {
+template <class P>
+__device__ __forceinline__ void count_ops(const P &p, int k, unsigned long long n) {
     atomicAdd(&p.ops[((blockIdx.x + 5 * blockIdx.y) & (SVTME_OPS_SLOTS - 1)) * 8 + k], n);
 }
 

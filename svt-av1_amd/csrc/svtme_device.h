@@ -106,10 +106,25 @@ struct OnePicture {
     PicParams p;
     __device__ __forceinline__ const PicParams &operator[](int) const { return p; }
 };
+// The records of a batch were written by an earlier kernel and do not change while the search kernels run: they are read
+// through the constant address space, so that the compiler may fetch a field again (as it does with kernel arguments)
+// instead of keeping hundreds of bytes of plane descriptors alive in registers and spilling them.
+typedef const PicParams __attribute__((address_space(4))) ConstPicParams;
 struct ManyPictures {
-    const PicParams *__restrict__ pp;
-    __device__ __forceinline__ const PicParams &operator[](int i) const { return pp[i]; }
+    const PicParams *pp;
+    __device__ __forceinline__ ConstPicParams &operator[](int i) const { return ((ConstPicParams *)pp)[i]; }
 };
+// A plane descriptor out of a record in either address space, as a value.
+template <class T>
+__device__ __forceinline__ DevPlane load_plane(const T &src) {
+    DevPlane d;
+    d.pix    = src.pix;
+    d.stride = src.stride;
+    d.width  = src.width;
+    d.height = src.height;
+    d.pad    = src.pad;
+    return d;
+}
 
 // The pictures one set of launches covers.
 struct Batch {

@@ -44,9 +44,9 @@ __device__ __forceinline__ u64 wave_sum_u64(u64 v) {
 template <class PICS>
 __global__ void __launch_bounds__(TAIL_THREADS) me_tail_kernel(PICS pp, int n_b64) {
     __shared__ TailShared S;
-    const PicParams      &p    = pp[blockIdx.x / n_b64];
-    const svtme_controls &k    = p.ctrl;
-    const svtme_tail     &t    = p.tail;
+    const auto &p    = pp[blockIdx.x / n_b64];
+    const auto &k    = p.ctrl;
+    const auto &t    = p.tail;
     const int             lane = threadIdx.x;
     const int             b64  = blockIdx.x % n_b64;
     const int             b64x = (b64 % p.b64_w) * 64, b64y = (b64 / p.b64_w) * 64;

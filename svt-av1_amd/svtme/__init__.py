@@ -438,9 +438,7 @@ class Engine:
         t = (C.c_uint64 * n)()
         rc = self.lib.svtme_pictures_submit(self.h, arr, n, t)
         if rc:
-            raise SvtmeError(rc, "svtme_pictures_submit",
-           "svtme_group_create", "svtme_group_destroy", "svtme_group_size", "svtme_group_store_put", "svtme_group_store_release",
-           "svtme_group_picture_submit", "svtme_group_picture_wait", "svtme_group_picture_done", "svtme_group_stats")
+            raise SvtmeError(rc, "svtme_pictures_submit")
         return list(t)
 
     def wait(self, ticket, copy=True):

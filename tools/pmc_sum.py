@@ -4,7 +4,9 @@ import collections, csv, glob, os, sys
 tot, n = collections.defaultdict(float), collections.defaultdict(set)
 for f in glob.glob(os.path.join(sys.argv[1], "**", "*counter_collection.csv"), recursive=True):
     for r in csv.DictReader(open(f)):
-        k = (r["Kernel_Name"].split("(")[0][:60], r["Counter_Name"])
+        # 'void svtme::me_search_kernel<svtme::OnePicture>(svtme::OnePicture, int, int, int)' -> 'svtme::me_search_kernel'
+        name = r["Kernel_Name"].split("(")[0].replace("void ", "").split("<")[0].strip()
+        k = (name[:60], r["Counter_Name"])
         tot[k] += float(r["Counter_Value"])
         n[k].add(r["Dispatch_Id"])
 rows = ["kernel,counter,dispatches,sum,per_dispatch"]
