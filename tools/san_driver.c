@@ -2,7 +2,9 @@
  * san_driver.c - drives the C ABI through its host-side paths so that a host-sanitized build of the library
  * (tools/run_sanitized.sh: AddressSanitizer + UndefinedBehaviorSanitizer on the host code only) sees them: engines of
  * several sizes, pictures in flight on a small store, slot overwrite and release with readers in flight, every
- * me_type, the device tail in both forms, argument errors, and destroy with work outstanding.
+ * me_type, the device tail in both forms, batches of pictures that share their launches, zero-copy puts from
+ * page-locked buffers, the allocation-free search, a group of two engines, argument errors, and destroy with work
+ * outstanding.
  * Prints "ok <checksum>"; the sanitizers abort on their own findings.
  */
 #include <stdint.h>
@@ -217,9 +219,145 @@ static uint64_t run_size(uint32_t w, uint32_t h, uint32_t max_w, uint32_t max_h,
     return hsh;
 }
 
+/* batches, page-locked puts, the allocation-free search and the engine group */
+static uint64_t run_extras(uint32_t w, uint32_t h, uint32_t seed, uint64_t hsh) {
+    enum { N = 5 };
+    const uint32_t stride = w + 144; /* the encoder's padded input buffers */
+    svtme_config   cfg;
+    memset(&cfg, 0, sizeof(cfg));
+    cfg.max_width = w, cfg.max_height = h, cfg.store_slots = N + 1, cfg.max_in_flight = 4;
+    svtme_engine *eng = NULL;
+    CHECK(svtme_create(&cfg, &eng));
+    /* page-locked source buffers; a pageable one goes the same way (the runtime stages it) */
+    uint8_t *pool = NULL, *plain = (uint8_t *)malloc((size_t)stride * h);
+    CHECK(svtme_host_alloc(eng, (size_t)N * stride * h, (void **)&pool));
+    EXPECT(svtme_host_alloc(eng, 0, (void **)&pool), SVTME_ERR_BAD_ARG);
+    for (int k = 0; k < N; ++k) {
+        uint8_t *src = make_luma(h, stride, k, &seed);
+        memcpy(pool + (size_t)k * stride * h, src, (size_t)stride * h);
+        if (k == 1) memcpy(plain, src, (size_t)stride * h);
+        free(src);
+    }
+    for (int k = 0; k < N; ++k)
+        CHECK(svtme_store_put_pinned(eng, 100 + (uint64_t)k, (uint64_t)k, k == 1 ? plain : pool + (size_t)k * stride * h, stride, w, h));
+    CHECK(svtme_store_wait(eng, 101));
+    EXPECT(svtme_store_wait(eng, 999), SVTME_ERR_NOT_FOUND);
+    {
+        const int rc = svtme_host_register(eng, plain, (size_t)stride * h); /* works, or says this machine cannot lock user pages */
+        if (rc == SVTME_OK) CHECK(svtme_host_unregister(eng, plain));
+        else if (rc != SVTME_ERR_UNSUPPORTED) EXPECT(rc, SVTME_OK);
+    }
+    /* three pictures with different reference lists as one batch; the same one by one must give the same bytes */
+    svtme_preset_key key = {8, 0, svtme_input_resolution(w, h), 0, 30u << 16};
+    svtme_picture    pic[3];
+    base_picture(&pic[0], w, h, 102, 2);
+    add_ref(&pic[0], 0, 100, 0), add_ref(&pic[0], 0, 101, 1), add_ref(&pic[0], 1, 104, 4);
+    base_picture(&pic[1], w, h, 101, 1);
+    add_ref(&pic[1], 0, 100, 0), add_ref(&pic[1], 1, 102, 2);
+    pic[1].temporal_layer_index = 2;
+    base_picture(&pic[2], w, h, 103, 3);
+    add_ref(&pic[2], 0, 102, 2);
+    for (int i = 0; i < 3; ++i) CHECK(svtme_derive_controls(&key, &pic[i].ctrl));
+    svtme_ticket  t[3];
+    svtme_results res;
+    uint64_t      one = 0, batch = 0;
+    for (int i = 0; i < 3; ++i) {
+        CHECK(svtme_picture_submit(eng, &pic[i], &t[0]));
+        CHECK(svtme_picture_wait(eng, t[0], &res));
+        one = hash_results(&res, &pic[i], one);
+        CHECK(svtme_picture_done(eng, t[0]));
+    }
+    CHECK(svtme_pictures_submit(eng, pic, 3, t));
+    for (int i = 0; i < 3; ++i) {
+        float ms[8];
+        CHECK(svtme_picture_wait(eng, t[i], &res));
+        CHECK(svtme_picture_timing(eng, t[i], ms));
+        if (ms[7] != 3.f) EXPECT(-100, SVTME_OK);
+        batch = hash_results(&res, &pic[i], batch);
+    }
+    for (int i = 2; i >= 0; --i) CHECK(svtme_picture_done(eng, t[i]));
+    if (one != batch) {
+        fprintf(stderr, "a batch and its pictures one by one differ\n");
+        exit(1);
+    }
+    hsh = fnv(hsh, &batch, sizeof(batch));
+    EXPECT(svtme_pictures_submit(eng, pic, 0, t), SVTME_ERR_BAD_ARG);
+    EXPECT(svtme_pictures_submit(eng, pic, SVTME_MAX_BATCH + 1, t), SVTME_ERR_BAD_ARG);
+    {
+        svtme_picture two[2] = {pic[0], pic[1]};
+        two[1].ctrl.me_sa.sa_max.height++; /* other controls: not one batch */
+        EXPECT(svtme_pictures_submit(eng, two, 2, t), SVTME_ERR_BAD_ARG);
+        svtme_picture five[5] = {pic[0], pic[1], pic[2], pic[0], pic[1]}; /* more than the engine keeps in flight */
+        EXPECT(svtme_pictures_submit(eng, five, 5, t), SVTME_ERR_NO_RESOURCES);
+    }
+    /* the same picture through the entry point that allocates nothing, results in page-locked memory of ours */
+    {
+        const size_t n_b64 = (size_t)((w + 63) / 64) * ((h + 63) / 64), bytes = SVTME_STATIC_RESULT_BYTES(n_b64, 3);
+        uint8_t     *block = NULL;
+        CHECK(svtme_host_alloc(eng, bytes, (void **)&block));
+        svtme_results st;
+        CHECK(svtme_picture_search_static(eng, &pic[0], block, bytes, &st));
+        uint64_t a = hash_results(&st, &pic[0], 0), b = 0;
+        CHECK(svtme_picture_submit(eng, &pic[0], &t[0]));
+        CHECK(svtme_picture_wait(eng, t[0], &res));
+        b = hash_results(&res, &pic[0], 0);
+        CHECK(svtme_picture_done(eng, t[0]));
+        if (a != b) {
+            fprintf(stderr, "svtme_picture_search_static and submit / wait differ\n");
+            exit(1);
+        }
+        EXPECT(svtme_picture_search_static(eng, &pic[0], block, bytes - 1, &st), SVTME_ERR_BAD_ARG);
+        EXPECT(svtme_picture_search_static(eng, &pic[0], block + 8, bytes, &st), SVTME_ERR_BAD_ARG);
+        CHECK(svtme_host_free(eng, block));
+        hsh = fnv(hsh, &a, sizeof(a));
+    }
+    svtme_destroy(eng);
+    /* two engines on this device behind one handle: pictures round robin, sources where they are read */
+    {
+        const int32_t devices[2] = {0, 0};
+        svtme_group  *grp = NULL;
+        EXPECT(svtme_group_create(devices, 0, &cfg, &grp), SVTME_ERR_BAD_ARG);
+        CHECK(svtme_group_create(devices, 2, &cfg, &grp));
+        if (svtme_group_size(grp) != 2) EXPECT(-101, SVTME_OK);
+        for (int k = 0; k < N; ++k)
+            CHECK(svtme_group_store_put(grp, 100 + (uint64_t)k, (uint64_t)k, pool + (size_t)k * stride * h, stride, w, h, k != 1));
+        uint64_t g = 0;
+        svtme_ticket gt[3];
+        for (int i = 0; i < 3; ++i) CHECK(svtme_group_picture_submit(grp, &pic[i], &gt[i]));
+        for (int i = 0; i < 3; ++i) {
+            CHECK(svtme_group_picture_wait(grp, gt[i], &res));
+            g = hash_results(&res, &pic[i], g);
+            CHECK(svtme_group_picture_done(grp, gt[i]));
+        }
+        /* (buffer 1 of the pool holds the same pixels as `plain`, which the single engine searched) */
+        if (g != one) {
+            fprintf(stderr, "the group and a single engine differ\n");
+            exit(1);
+        }
+        uint64_t np = 0, ns = 0, nu = 0;
+        CHECK(svtme_group_stats(grp, &np, &ns, &nu));
+        if (np != 3 || ns != N || nu < 4 || nu > 2 * N) EXPECT(-102, SVTME_OK);
+        EXPECT(svtme_group_picture_wait(grp, (svtme_ticket)7 << 56, &res), SVTME_ERR_NOT_FOUND);
+        CHECK(svtme_group_store_release(grp, 100));
+        EXPECT(svtme_group_store_release(grp, 100), SVTME_ERR_NOT_FOUND);
+        EXPECT(svtme_group_picture_submit(grp, &pic[0], &gt[0]), SVTME_ERR_NOT_FOUND); /* its reference is gone */
+        svtme_group_destroy(grp);
+    }
+    /* the pool outlives the engines that read from it */
+    {
+        svtme_engine *e2 = NULL;
+        CHECK(svtme_create(&cfg, &e2));
+        CHECK(svtme_host_free(e2, pool));
+        svtme_destroy(e2);
+    }
+    free(plain);
+    return hsh;
+}
+
 int main(void) {
     uint64_t h = 1469598103934665603ull;
     EXPECT(svtme_create(NULL, NULL), SVTME_ERR_BAD_ARG);
+    h = run_extras(320, 192, 5, h);
     h = run_size(192, 136, 192, 136, 8, 1, h);
     h = run_size(128, 64, 256, 192, 3, 2, h); /* smaller pictures than the engine was sized for */
     h = run_size(328, 200, 328, 200, 12, 3, h);
