@@ -162,6 +162,8 @@ def main():
     sharded = world > 1  # one sequence, split over the ranks
     if args.batch <= 0:
         args.batch = wl.get("batch", 1)
+        if args.with_upload:  # a batch waits for the puts of all its pictures: shorter batches overlap better with the uploads
+            args.batch = min(args.batch, 4)
     args.batch = min(args.batch, svtme.MAX_BATCH)
     if args.in_flight <= 0:
         args.in_flight = max(6, 3 * args.batch)

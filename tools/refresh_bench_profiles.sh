@@ -1,13 +1,13 @@
 #!/bin/bash
 # Re-runs bench.py for every workload and writes the JSON lines under profiles/ (run on the GPU box from the repository root).
 set -e
-R=${1:-r01}
+R=${1:-r02}
 run() { # name, args...
     local name=$1; shift
     timeout -k 10 600 python3 bench.py "$@" > "profiles/${R}_bench_${name}.json.tmp" 2> "gpurun_out/refresh_${name}.err"
     tail -1 "profiles/${R}_bench_${name}.json.tmp" > "profiles/${R}_bench_${name}.json"
     rm "profiles/${R}_bench_${name}.json.tmp"
-    python3 -c "import json,sys; d=json.load(open(sys.argv[1])); print(sys.argv[2], round(d['value']), round(d['roofline']['frac'],3), (d.get('cpu_baseline') or {}).get('value'))" "profiles/${R}_bench_${name}.json" "$name"
+    python3 -c "import json,sys; d=json.load(open(sys.argv[1])); print(sys.argv[2], round(d['value']), d['roofline']['kernel'], round(d['roofline']['frac'],3), round(d['roofline']['all_kernels']['achieved'],1), (d.get('cpu_baseline') or {}).get('value'))" "profiles/${R}_bench_${name}.json" "$name"
 }
 mkdir -p gpurun_out
 run 1080p_ra_m3
@@ -20,4 +20,10 @@ run 1080p_tf_l0 --workload 1080p_tf_l0
 run 1080p_tf_l2 --workload 1080p_tf_l2
 run 1080p_first_pass --workload 1080p_first_pass
 run 8k_ra_m2 --workload 8k_ra_m2 --steps 10 --warmup 2 --kernel-steps 2
+# the same with every source picture put into the device store inside the timed region (zero-copy puts from page-locked
+# buffers with the encoder's stride); these lines carry no CPU baseline
+run 1080p_ra_m3_with_upload --with-upload --no-cpu-baseline
+run 1080p_ra_m8_with_upload --workload 1080p_ra_m8 --with-upload --no-cpu-baseline
+run 4k_ra_m8_with_upload --workload 4k_ra_m8 --with-upload --no-cpu-baseline
+run 720p_ld_m12_with_upload --workload 720p_ld_m12 --with-upload --no-cpu-baseline
 mkdir -p gpurun_out/profiles && cp profiles/${R}_bench_*.json gpurun_out/profiles/
