@@ -399,6 +399,47 @@ int svtme_group_picture_wait(svtme_group *g, svtme_ticket ticket, svtme_results 
 int svtme_group_picture_done(svtme_group *g, svtme_ticket ticket);
 int svtme_group_stats(svtme_group *g, uint64_t *pictures, uint64_t *sources, uint64_t *uploads);
 
+/* ---- Global-motion estimation: the data-parallel stages of compute_global_motion
+ * (Source/Lib/Encoder/Codec/EbGlobalMotionEstimation.c:155-301) on the planes the store already holds. The encoder keeps
+ * its own RANSAC (ransac.c), refinement loop (svt_av1_refine_integerized_param, global_motion.c:135-263), shear derivation
+ * and parameter costs; it calls the engine where it called these four functions:
+ *
+ *   svtme_gm_corners          <- svt_av1_fast_corner_detect (corner_detect.c:19-32): FAST-9, barrier 18, non-maximum
+ *                                suppression, the first max_points corners in raster order as (x, y) pairs
+ *   svtme_gm_correspondences  <- svt_av1_fast_corner_detect of the reference picture + svt_av1_determine_correspondence
+ *                                (corner_match.c:153-214; global_motion.c:294-309): corners of both pictures (at most
+ *                                SVTME_GM_MAX_CORNERS each), best match by normalised cross-correlation of 13x13 patches
+ *                                within max(w, h) / 16 pixels, then the two 9x9 refinements; (x, y, rx, ry) per match
+ *   svtme_gm_warp_error       <- svt_av1_warp_error (EbEncWarpedMotion.c:229-267) for 8 bit after svt_get_shear_params
+ *                                succeeded (the caller passes the shear it derived; when that function fails the
+ *                                reference returns 1 without looking at the pictures, and so does the caller): the
+ *                                reference picture warped in 32x32 blocks and compared with the current picture through
+ *                                the error table; as in the reference the sum stops at the first block, in raster order,
+ *                                that takes it above best_error
+ *   svtme_gm_frame_error      <- svt_av1_frame_error (EbEncWarpedMotion.c:215-227) for 8 bit: the same measure, no warp
+ *
+ * downsample_level is pcs->gm_ctrls.downsample_level (GM_FULL 0, GM_DOWN 1, GM_DOWN16 2, EbDefinitions.h:155-159) and
+ * selects the full, quarter or sixteenth plane of both pictures (EbGlobalMotionEstimation.c:109-122). The calls are
+ * synchronous and take turns on one engine; the keys must stay in the store and must not be put again while a call that
+ * reads them runs.
+ *
+ * svtme_gm_set_tables: the warp filter (eb_warped_filter[193][8], EbWarpedMotion.h:44) and the error table
+ * (error_measure_lut[512], EbWarpedMotion.h:45) of the AV1 specification are not part of this library; the encoder hands
+ * over its own once per engine, before the first error call (SVTME_ERR_BAD_ARG until then).
+ */
+#define SVTME_GM_MAX_CORNERS 4096 /* MAX_CORNERS, global_motion.h:35 */
+typedef struct svtme_gm_warp { /* the fields of EbWarpedMotionParams (EbDefinitions.h:1969-1975) the warp reads */
+    int32_t wmmat[6];
+    int16_t alpha, beta, gamma, delta;
+} svtme_gm_warp;
+int svtme_gm_set_tables(svtme_engine *e, const int16_t *warped_filter, const int32_t *error_measure_lut);
+int svtme_gm_corners(svtme_engine *e, uint64_t key, int downsample_level, int32_t *points, int32_t max_points, int32_t *num_points);
+int svtme_gm_correspondences(svtme_engine *e, uint64_t cur_key, uint64_t ref_key, int downsample_level,
+                             int32_t *correspondences /* [4 * SVTME_GM_MAX_CORNERS] */, int32_t *num_correspondences);
+int svtme_gm_warp_error(svtme_engine *e, uint64_t cur_key, uint64_t ref_key, int downsample_level, const svtme_gm_warp *wm,
+                        int64_t best_error, int64_t *error);
+int svtme_gm_frame_error(svtme_engine *e, uint64_t cur_key, uint64_t ref_key, int downsample_level, int64_t *error);
+
 const char *svtme_version(void);
 
 #ifdef __cplusplus

@@ -43,7 +43,8 @@ struct Slot {
     bool       uploaded = false; // `ready` has been recorded at least once (an upload from host_stage may be in flight)
     bool       release_pending = false;
     uint64_t   key = 0, picture_number = 0;
-    int        readers = 0; // submitted pictures that have not been waited for yet
+    uint64_t   gen = 0; // number of the put that built the planes: tells a cached by-product (corner lists) from a stale one
+    int        readers = 0; // submitted pictures that have not been waited for yet (and global-motion calls that are running)
     uint32_t   width = 0, height = 0;
     DevPicture pic{};
     uint8_t   *mem = nullptr; // device
@@ -110,6 +111,28 @@ struct BatchRec {
     hipEvent_t ev[7] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
 };
 
+// Global-motion estimation: buffers shared by the svtme_gm_* calls of one engine (allocated by the first of them).
+struct GmState {
+    std::mutex mu; // one call at a time
+    bool       ready = false, tables = false;
+    uint8_t   *d_score = nullptr, *d_keep = nullptr; // FAST score map and the flags that survive non-maximum suppression
+    int       *d_rows = nullptr; // corners kept per row
+    int       *d_corners[2] = {nullptr, nullptr}; // two corner lists: count, pad, (x, y) pairs
+    int       *d_match = nullptr; // [SVTME_GM_MAX_CORNERS][5]
+    uint32_t  *d_block_err = nullptr; // per 32x32 block
+    long long *d_result = nullptr;
+    int16_t   *d_filter = nullptr; // the caller's warp filter [193][8]
+    int32_t   *d_lut = nullptr; // and error table [512]
+    int       *h_buf = nullptr; // pinned: what a call brings back
+    struct Cached {
+        bool     valid = false;
+        uint64_t key = 0, gen = 0;
+        int      level = 0;
+    } cached[2]; // whose corners d_corners[i] holds
+    int last_used = 1;
+};
+constexpr size_t kGmCornerInts = 2 + 2 * (size_t)SVTME_GM_MAX_CORNERS, kGmMatchInts = 5 * (size_t)SVTME_GM_MAX_CORNERS;
+
 } // namespace
 
 // ---- scratch of svtme_picture_search_static(): the search kernels' intermediates (HME records, operation counters,
@@ -164,6 +187,8 @@ struct svtme_engine {
     size_t              slot_bytes = 0, max_b64 = 0;
     uint8_t            *d_upload[2] = {nullptr, nullptr}; // un-padded luma of the pictures being put (a store stream orders the reuse of its buffer)
     size_t              upload_bytes = 0;
+    GmState             gm;
+    uint64_t            put_gen = 0;
 };
 
 namespace {
@@ -323,6 +348,13 @@ extern "C" void svtme_destroy(svtme_engine *e) {
             if (ev) (void)hipEventDestroy(ev);
     if (e->d_params) (void)hipFree(e->d_params);
     if (e->h_params) (void)hipHostFree(e->h_params);
+    {
+        GmState &g = e->gm;
+        void    *dev[] = {g.d_score, g.d_keep, g.d_rows, g.d_corners[0], g.d_corners[1], g.d_match, g.d_block_err, g.d_result, g.d_filter, g.d_lut};
+        for (void *d : dev)
+            if (d) (void)hipFree(d);
+        if (g.h_buf) (void)hipHostFree(g.h_buf);
+    }
     for (auto sm : e->s_me)
         if (sm) (void)hipStreamDestroy(sm);
     for (auto ss : e->s_store)
@@ -399,6 +431,7 @@ static int store_put_impl(svtme_engine *e, uint64_t key, uint64_t picture_number
     s.picture_number = picture_number;
     s.width          = width;
     s.height         = height;
+    s.gen = ++e->put_gen;
     size_t plane_bytes;
     layout_planes(s.mem, width, height, &s.pic, &plane_bytes);
     if (err == hipSuccess) err = hipMemcpyAsync(e->d_upload[ring], src, bytes, hipMemcpyHostToDevice, ss);
@@ -969,6 +1002,202 @@ extern "C" int svtme_unpack_b64(const svtme_results *res, uint32_t b64_index, ui
     if (zz_sad) memcpy(zz_sad, res->zz_sad + (size_t)b64_index * n, n * 4);
     if (reduce_me_sr_divisor) memcpy(reduce_me_sr_divisor, res->reduce_me_sr_divisor + (size_t)b64_index * n, n * 4);
     return SVTME_OK;
+}
+
+// ------------------------------------------------------------------------------------------------ global-motion estimation
+namespace {
+
+int gm_init(svtme_engine *e) { // e->gm.mu held, device current
+    GmState &g = e->gm;
+    if (g.ready) return SVTME_OK;
+    const size_t px = (size_t)e->cfg.max_width * e->cfg.max_height;
+    const size_t blocks = (size_t)((e->cfg.max_width + 31) / 32) * ((e->cfg.max_height + 31) / 32);
+    if (hipMalloc((void **)&g.d_score, px) != hipSuccess || hipMalloc((void **)&g.d_keep, px) != hipSuccess ||
+        hipMalloc((void **)&g.d_rows, (size_t)e->cfg.max_height * sizeof(int)) != hipSuccess ||
+        hipMalloc((void **)&g.d_corners[0], kGmCornerInts * sizeof(int)) != hipSuccess ||
+        hipMalloc((void **)&g.d_corners[1], kGmCornerInts * sizeof(int)) != hipSuccess ||
+        hipMalloc((void **)&g.d_match, kGmMatchInts * sizeof(int)) != hipSuccess ||
+        hipMalloc((void **)&g.d_block_err, blocks * sizeof(uint32_t)) != hipSuccess ||
+        hipMalloc((void **)&g.d_result, sizeof(long long)) != hipSuccess || hipMalloc((void **)&g.d_filter, 193 * 8 * sizeof(int16_t)) != hipSuccess ||
+        hipMalloc((void **)&g.d_lut, 512 * sizeof(int32_t)) != hipSuccess ||
+        hipHostMalloc((void **)&g.h_buf, (kGmCornerInts + kGmMatchInts + 4) * sizeof(int), hipHostMallocDefault) != hipSuccess) {
+        (void)hipGetLastError();
+        return SVTME_ERR_NO_RESOURCES; // (what was allocated is freed with the engine)
+    }
+    g.ready = true;
+    return SVTME_OK;
+}
+
+// The planes of `n` keys at a downsample level, held against release for the duration of a call.
+struct GmPlanes {
+    svtme_engine *e;
+    int           n = 0, slot[2] = {-1, -1};
+    DevPlane      plane[2];
+    hipEvent_t    ready[2];
+    uint64_t      gen[2];
+    explicit GmPlanes(svtme_engine *e_) : e(e_) {}
+    int take(const uint64_t *keys, int count, int level) {
+        std::lock_guard<std::mutex> lock(e->mu);
+        for (int i = 0; i < count; ++i) {
+            const int si = find_slot(e, keys[i]);
+            if (si < 0) {
+                drop_locked();
+                return SVTME_ERR_NOT_FOUND;
+            }
+            Slot &s = e->slots[si];
+            s.readers++;
+            slot[n]  = si;
+            plane[n] = s.pic.lvl[2 - level]; // GM_FULL 0 -> the full plane, GM_DOWN 1 -> quarter, GM_DOWN16 2 -> sixteenth
+            ready[n] = s.ready;
+            gen[n]   = s.gen;
+            ++n;
+        }
+        return SVTME_OK;
+    }
+    void drop_locked() {
+        for (int i = 0; i < n; ++i) {
+            Slot &s = e->slots[slot[i]];
+            if (--s.readers == 0 && s.release_pending) {
+                s.used            = false;
+                s.release_pending = false;
+            }
+        }
+        n = 0;
+    }
+    ~GmPlanes() {
+        if (n) {
+            std::lock_guard<std::mutex> lock(e->mu);
+            drop_locked();
+        }
+    }
+};
+
+// Index of the corner list that holds the corners of (key, level, gen), computing them (queued on `st`) if neither does;
+// `avoid`: a list that must survive (-1: none).
+int gm_corners_of(svtme_engine *e, uint64_t key, int level, uint64_t gen, const DevPlane &plane, int avoid, hipStream_t st) {
+    GmState &g = e->gm;
+    for (int i = 0; i < 2; ++i)
+        if (g.cached[i].valid && g.cached[i].key == key && g.cached[i].level == level && g.cached[i].gen == gen) {
+            g.last_used = i;
+            return i;
+        }
+    const int i = avoid >= 0 ? 1 - avoid : 1 - g.last_used;
+    launch_gm_corners(plane, g.d_score, g.d_keep, g.d_rows, SVTME_GM_MAX_CORNERS, g.d_corners[i], st);
+    g.cached[i].valid = true;
+    g.cached[i].key   = key;
+    g.cached[i].level = level;
+    g.cached[i].gen   = gen;
+    g.last_used       = i;
+    return i;
+}
+
+#define GM_TRY(expr)                                                                                      \
+    do {                                                                                                  \
+        hipError_t err__ = (expr);                                                                        \
+        if (err__ != hipSuccess) {                                                                        \
+            fprintf(stderr, "svtme: %s failed: %s (%s:%d)\n", #expr, hipGetErrorString(err__), __FILE__, __LINE__); \
+            e->gm.cached[0].valid = e->gm.cached[1].valid = false;                                        \
+            (void)hipStreamSynchronize(st);                                                               \
+            return SVTME_ERR_DEVICE;                                                                      \
+        }                                                                                                 \
+    } while (0)
+
+} // namespace
+
+extern "C" int svtme_gm_set_tables(svtme_engine *e, const int16_t *warped_filter, const int32_t *error_measure_lut) {
+    if (!e || !warped_filter || !error_measure_lut) return SVTME_ERR_BAD_ARG;
+    DEVICE_OR_FAIL(e->cfg.device);
+    std::lock_guard<std::mutex> gm_lock(e->gm.mu);
+    if (const int rc = gm_init(e)) return rc;
+    HIP_TRY(hipMemcpy(e->gm.d_filter, warped_filter, 193 * 8 * sizeof(int16_t), hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(e->gm.d_lut, error_measure_lut, 512 * sizeof(int32_t), hipMemcpyHostToDevice));
+    e->gm.tables = true;
+    return SVTME_OK;
+}
+
+extern "C" int svtme_gm_corners(svtme_engine *e, uint64_t key, int downsample_level, int32_t *points, int32_t max_points, int32_t *num_points) {
+    if (!e || !points || !num_points || max_points < 0 || downsample_level < 0 || downsample_level > 2) return SVTME_ERR_BAD_ARG;
+    DEVICE_OR_FAIL(e->cfg.device);
+    std::lock_guard<std::mutex> gm_lock(e->gm.mu);
+    if (const int rc = gm_init(e)) return rc;
+    GmPlanes pl(e);
+    if (const int rc = pl.take(&key, 1, downsample_level)) return rc;
+    const hipStream_t st = e->s_me[3];
+    GmState          &g = e->gm;
+    GM_TRY(hipStreamWaitEvent(st, pl.ready[0], 0));
+    const int i = gm_corners_of(e, key, downsample_level, pl.gen[0], pl.plane[0], -1, st);
+    GM_TRY(hipGetLastError());
+    GM_TRY(hipMemcpyAsync(g.h_buf, g.d_corners[i], kGmCornerInts * sizeof(int), hipMemcpyDeviceToHost, st));
+    GM_TRY(hipStreamSynchronize(st));
+    const int n = std::min<int>(g.h_buf[0], max_points); // the first max_points in raster order, as the reference cuts them
+    memcpy(points, g.h_buf + 2, sizeof(int32_t) * 2 * (size_t)n);
+    *num_points = n;
+    return SVTME_OK;
+}
+
+extern "C" int svtme_gm_correspondences(svtme_engine *e, uint64_t cur_key, uint64_t ref_key, int downsample_level, int32_t *correspondences,
+                                        int32_t *num_correspondences) {
+    if (!e || !correspondences || !num_correspondences || downsample_level < 0 || downsample_level > 2) return SVTME_ERR_BAD_ARG;
+    DEVICE_OR_FAIL(e->cfg.device);
+    std::lock_guard<std::mutex> gm_lock(e->gm.mu);
+    if (const int rc = gm_init(e)) return rc;
+    GmPlanes       pl(e);
+    const uint64_t keys[2] = {cur_key, ref_key};
+    if (const int rc = pl.take(keys, 2, downsample_level)) return rc;
+    if (pl.plane[0].width != pl.plane[1].width || pl.plane[0].height != pl.plane[1].height) return SVTME_ERR_BAD_ARG;
+    const hipStream_t st = e->s_me[3];
+    GmState          &g = e->gm;
+    GM_TRY(hipStreamWaitEvent(st, pl.ready[0], 0));
+    GM_TRY(hipStreamWaitEvent(st, pl.ready[1], 0));
+    const int ic = gm_corners_of(e, cur_key, downsample_level, pl.gen[0], pl.plane[0], -1, st);
+    const int ir = cur_key == ref_key ? ic : gm_corners_of(e, ref_key, downsample_level, pl.gen[1], pl.plane[1], ic, st);
+    launch_gm_match(pl.plane[0], pl.plane[1], g.d_corners[ic], g.d_corners[ir], SVTME_GM_MAX_CORNERS, g.d_match, st);
+    GM_TRY(hipGetLastError());
+    GM_TRY(hipMemcpyAsync(g.h_buf, g.d_corners[ic], 2 * sizeof(int), hipMemcpyDeviceToHost, st));
+    GM_TRY(hipMemcpyAsync(g.h_buf + 2, g.d_match, kGmMatchInts * sizeof(int), hipMemcpyDeviceToHost, st));
+    GM_TRY(hipStreamSynchronize(st));
+    const int n_frm = std::min<int>(g.h_buf[0], SVTME_GM_MAX_CORNERS);
+    int       n = 0;
+    for (int i = 0; i < n_frm; ++i) { // the matched corners, in the order of the current picture's corner list
+        const int *m = g.h_buf + 2 + 5 * i;
+        if (m[4]) memcpy(correspondences + 4 * n++, m, 4 * sizeof(int32_t));
+    }
+    *num_correspondences = n;
+    return SVTME_OK;
+}
+
+static int gm_error(svtme_engine *e, uint64_t cur_key, uint64_t ref_key, int downsample_level, const svtme_gm_warp *wm, int64_t best_error,
+                    int64_t *error) {
+    if (!e || !error || downsample_level < 0 || downsample_level > 2) return SVTME_ERR_BAD_ARG;
+    DEVICE_OR_FAIL(e->cfg.device);
+    std::lock_guard<std::mutex> gm_lock(e->gm.mu);
+    if (!e->gm.ready || !e->gm.tables) return SVTME_ERR_BAD_ARG; // svtme_gm_set_tables first
+    GmPlanes       pl(e);
+    const uint64_t keys[2] = {cur_key, ref_key};
+    if (const int rc = pl.take(keys, 2, downsample_level)) return rc;
+    if (pl.plane[0].width != pl.plane[1].width || pl.plane[0].height != pl.plane[1].height) return SVTME_ERR_BAD_ARG;
+    const hipStream_t st = e->s_me[3];
+    GmState          &g = e->gm;
+    GM_TRY(hipStreamWaitEvent(st, pl.ready[0], 0));
+    GM_TRY(hipStreamWaitEvent(st, pl.ready[1], 0));
+    launch_gm_error(pl.plane[0], pl.plane[1], wm, g.d_filter, g.d_lut, g.d_block_err, (long long)best_error, g.d_result, st);
+    GM_TRY(hipGetLastError());
+    GM_TRY(hipMemcpyAsync(g.h_buf, g.d_result, sizeof(long long), hipMemcpyDeviceToHost, st));
+    GM_TRY(hipStreamSynchronize(st));
+    long long r;
+    memcpy(&r, g.h_buf, sizeof(r));
+    *error = (int64_t)r;
+    return SVTME_OK;
+}
+
+extern "C" int svtme_gm_warp_error(svtme_engine *e, uint64_t cur_key, uint64_t ref_key, int downsample_level, const svtme_gm_warp *wm,
+                                   int64_t best_error, int64_t *error) {
+    if (!wm) return SVTME_ERR_BAD_ARG;
+    return gm_error(e, cur_key, ref_key, downsample_level, wm, best_error, error);
+}
+
+extern "C" int svtme_gm_frame_error(svtme_engine *e, uint64_t cur_key, uint64_t ref_key, int downsample_level, int64_t *error) {
+    return gm_error(e, cur_key, ref_key, downsample_level, nullptr, INT64_MAX, error);
 }
 
 // Diagnostic, not part of the public header: resident workgroups per CU of {hme_l0, hme_l12, me_search}.

@@ -153,6 +153,15 @@ void launch_hme_items(const Batch &b, hipStream_t s, hipEvent_t marks[2]);
 void launch_me(const Batch &b, hipStream_t s, hipEvent_t marks[3]);
 void launch_tail(const Batch &b, hipStream_t s); // after launch_me, when the pictures have a device tail
 
+// global-motion kernels (gm_kernels.hip). Corner lists: [0] = count, (x, y) pairs from [2] on.
+void launch_gm_corners(const DevPlane &pl, uint8_t *score, uint8_t *keep, int *row_count, int max_points, int *out, hipStream_t s);
+// one workgroup per possible corner (n_frm_max); out[i] = {x, y, rx, ry, matched} for the corners the list holds
+void launch_gm_match(const DevPlane &frm, const DevPlane &ref, const int *frm_corners, const int *ref_corners, int n_frm_max, int *out,
+                     hipStream_t s);
+// wm == nullptr: the frame error (no warp)
+void launch_gm_error(const DevPlane &frm, const DevPlane &ref, const svtme_gm_warp *wm, const int16_t *filter, const int32_t *lut,
+                     uint32_t *block_err, long long best_error, long long *result, hipStream_t s);
+
 int  occupancy_me_search();
 void occupancy_hme_items(int out[2]);
 

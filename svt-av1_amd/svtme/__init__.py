@@ -118,8 +118,14 @@ EXPORTS = ("svtme_version", "svtme_derive_controls", "svtme_derive_tf_controls",
            "svtme_picture_search_static", "svtme_store_put_pinned", "svtme_store_wait", "svtme_host_register",
            "svtme_host_unregister", "svtme_host_alloc", "svtme_host_free", "svtme_pictures_submit",
            "svtme_group_create", "svtme_group_destroy", "svtme_group_size", "svtme_group_store_put", "svtme_group_store_release",
-           "svtme_group_picture_submit", "svtme_group_picture_wait", "svtme_group_picture_done", "svtme_group_stats")
+           "svtme_group_picture_submit", "svtme_group_picture_wait", "svtme_group_picture_done", "svtme_group_stats",
+           "svtme_gm_set_tables", "svtme_gm_corners", "svtme_gm_correspondences", "svtme_gm_warp_error", "svtme_gm_frame_error")
 MAX_BATCH = 32
+GM_MAX_CORNERS = 4096
+
+
+class GmWarp(C.Structure):
+    _fields_ = [("wmmat", C.c_int32 * 6), ("alpha", C.c_int16), ("beta", C.c_int16), ("gamma", C.c_int16), ("delta", C.c_int16)]
 STATIC_MAX_B64 = 2040
 
 
@@ -176,6 +182,11 @@ def load_library():
     lib.svtme_group_picture_wait.argtypes = [C.c_void_p, C.c_uint64, C.POINTER(Results)]
     lib.svtme_group_picture_done.argtypes = [C.c_void_p, C.c_uint64]
     lib.svtme_group_stats.argtypes = [C.c_void_p] + [C.POINTER(C.c_uint64)] * 3
+    lib.svtme_gm_set_tables.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+    lib.svtme_gm_corners.argtypes = [C.c_void_p, C.c_uint64, C.c_int, C.c_void_p, C.c_int32, C.POINTER(C.c_int32)]
+    lib.svtme_gm_correspondences.argtypes = [C.c_void_p, C.c_uint64, C.c_uint64, C.c_int, C.c_void_p, C.POINTER(C.c_int32)]
+    lib.svtme_gm_warp_error.argtypes = [C.c_void_p, C.c_uint64, C.c_uint64, C.c_int, C.POINTER(GmWarp), C.c_int64, C.POINTER(C.c_int64)]
+    lib.svtme_gm_frame_error.argtypes = [C.c_void_p, C.c_uint64, C.c_uint64, C.c_int, C.POINTER(C.c_int64)]
     _lib = lib
     return lib
 
@@ -457,6 +468,47 @@ class Engine:
         if rc:
             raise SvtmeError(rc, "svtme_picture_search_static")
         return r
+
+    # ---- global-motion estimation (svtme_gm_*): downsample level 0 / 1 / 2 = full / quarter / sixteenth plane
+    def gm_set_tables(self, warped_filter, error_lut):
+        wf = np.ascontiguousarray(warped_filter, np.int16)
+        lut = np.ascontiguousarray(error_lut, np.int32)
+        if wf.size != 193 * 8 or lut.size != 512:
+            raise ValueError("warp filter [193, 8] int16 and error table [512] int32 expected")
+        rc = self.lib.svtme_gm_set_tables(self.h, wf.ctypes.data, lut.ctypes.data)
+        if rc:
+            raise SvtmeError(rc, "svtme_gm_set_tables")
+
+    def gm_corners(self, key, level=0, max_points=GM_MAX_CORNERS):
+        pts = np.zeros((max(max_points, 1), 2), np.int32)
+        n = C.c_int32(0)
+        rc = self.lib.svtme_gm_corners(self.h, key, level, pts.ctypes.data, max_points, C.byref(n))
+        if rc:
+            raise SvtmeError(rc, "svtme_gm_corners")
+        return pts[:n.value].copy()
+
+    def gm_correspondences(self, cur_key, ref_key, level=0):
+        out = np.zeros((GM_MAX_CORNERS, 4), np.int32)
+        n = C.c_int32(0)
+        rc = self.lib.svtme_gm_correspondences(self.h, cur_key, ref_key, level, out.ctypes.data, C.byref(n))
+        if rc:
+            raise SvtmeError(rc, "svtme_gm_correspondences")
+        return out[:n.value].copy()
+
+    def gm_warp_error(self, cur_key, ref_key, level, mat, shear, best_error=(1 << 63) - 1):
+        w = GmWarp((C.c_int32 * 6)(*[int(v) for v in mat]), *[int(v) for v in shear])
+        err = C.c_int64(0)
+        rc = self.lib.svtme_gm_warp_error(self.h, cur_key, ref_key, level, C.byref(w), int(best_error), C.byref(err))
+        if rc:
+            raise SvtmeError(rc, "svtme_gm_warp_error")
+        return err.value
+
+    def gm_frame_error(self, cur_key, ref_key, level=0):
+        err = C.c_int64(0)
+        rc = self.lib.svtme_gm_frame_error(self.h, cur_key, ref_key, level, C.byref(err))
+        if rc:
+            raise SvtmeError(rc, "svtme_gm_frame_error")
+        return err.value
 
     def timing(self, ticket):
         ms = (C.c_float * 8)()

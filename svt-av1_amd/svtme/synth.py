@@ -38,17 +38,21 @@ def _octave(seed, hh, ww, scale):
     return _box(up, scale)
 
 
+def _canvas(seed, hh, ww):
+    canvas = (_octave(seed * 7 + 1, hh, ww, 64) * 2 + _octave(seed * 7 + 2, hh, ww, 16) * 3 +
+              _octave(seed * 7 + 3, hh, ww, 4) * 2 + _raw_bytes(seed * 7 + 4, hh * ww).reshape(hh, ww)) // 8
+    canvas = canvas.astype(np.int32)
+    # contrast stretch around the mean so that SADs are not tiny
+    return np.clip((canvas - 128) * 3 + 128, 0, 255)
+
+
 def synth_sequence(width, height, n_frames, seed=1, motion=(3, -2), noise=2, bit_depth=8,
                    n_objects=6):
     """Returns uint8 array [n_frames, height, width]: the 8-bit luma planes the ME sees."""
     dx, dy = int(motion[0]), int(motion[1])
     m = 8 + max(abs(dx), abs(dy)) * max(n_frames, 1)
     hh, ww = height + 2 * m, width + 2 * m
-    canvas = (_octave(seed * 7 + 1, hh, ww, 64) * 2 + _octave(seed * 7 + 2, hh, ww, 16) * 3 +
-              _octave(seed * 7 + 3, hh, ww, 4) * 2 + _raw_bytes(seed * 7 + 4, hh * ww).reshape(hh, ww)) // 8
-    canvas = canvas.astype(np.int32)
-    # contrast stretch around the mean so that SADs are not tiny
-    canvas = np.clip((canvas - 128) * 3 + 128, 0, 255)
+    canvas = _canvas(seed, hh, ww)
     par = _raw_bytes(seed * 7 + 5, 16 * max(n_objects, 1)).astype(np.int32).reshape(-1, 16)
     frames = np.empty((n_frames, height, width), np.uint8)
     scale10 = 4 if bit_depth == 10 else 1
@@ -97,3 +101,44 @@ def extreme_sequence(width, height, n_frames, kind, seed=1):
     if kind == "flat":
         return np.full((n_frames, height, width), 128, np.uint8)
     raise ValueError(kind)
+
+
+def warped_sequence(width, height, n_frames, seed=1, rot=(40, 0), zoom=(200, 0), shift=(2, -1), noise=1, detail=4):
+    """Frames of one textured scene under a global motion that grows with the frame index, for the global-motion
+    estimation: frame k samples the canvas at A_k * (x - centre) + centre + k * shift with
+        A_k = [[1 + k * zoom[0] / 65536, k * (rot[1] - rot[0]) / 65536], [k * rot[0] / 65536, 1 + k * (zoom[0] + zoom[1]) / 65536]]
+    i.e. per frame a turn by rot[0] / 65536 radians (small-angle form), a zoom by zoom[0] / 65536 and a move by `shift` pixels;
+    rot[1] and zoom[1] add shear and anisotropy, which make the motion affine rather than a rotation-zoom. Bilinear
+    resampling in 16.16 / 8-bit fixed point, integer arithmetic only (the same bytes on every machine). `detail` blurs the
+    canvas first (box of that size), so that corners survive the resampling. Returns uint8 [n_frames, height, width]."""
+    m = 32 + int((abs(rot[0]) + abs(rot[1]) + abs(zoom[0]) + abs(zoom[1])) * n_frames * max(width, height) / 65536 / 2) + \
+        (abs(shift[0]) + abs(shift[1])) * n_frames
+    hh, ww = height + 2 * m, width + 2 * m
+    canvas = _canvas(seed, hh, ww).astype(np.int64)
+    if detail > 1:
+        canvas = _box(canvas, detail).astype(np.int64)
+        canvas = np.clip((canvas - 128) * 2 + 128, 0, 255)
+    ys, xs = np.mgrid[0:height, 0:width].astype(np.int64)
+    cx, cy = xs - width // 2, ys - height // 2
+    frames = np.empty((n_frames, height, width), np.uint8)
+    for k in range(n_frames):
+        a = 65536 + k * zoom[0]
+        b = -k * rot[0] + k * rot[1]
+        c = k * rot[0]
+        d = 65536 + k * zoom[0] + k * zoom[1]
+        u = a * cx + b * cy + ((width // 2 + m + k * shift[0]) << 16)
+        v = c * cx + d * cy + ((height // 2 + m + k * shift[1]) << 16)
+        ui, vi = u >> 16, v >> 16
+        fu, fv = (u >> 8) & 255, (v >> 8) & 255
+        ui = np.clip(ui, 0, ww - 2)
+        vi = np.clip(vi, 0, hh - 2)
+        p00, p01 = canvas[vi, ui], canvas[vi, ui + 1]
+        p10, p11 = canvas[vi + 1, ui], canvas[vi + 1, ui + 1]
+        top = p00 * (256 - fu) + p01 * fu
+        bot = p10 * (256 - fu) + p11 * fu
+        f = (top * (256 - fv) + bot * fv + 32768) >> 16
+        if noise:
+            nz = _raw_bytes(seed * 1000003 + k + 4711, height * width).reshape(height, width).astype(np.int64)
+            f = f + (nz % (2 * noise + 1)) - noise
+        frames[k] = np.clip(f, 0, 255).astype(np.uint8)
+    return frames

@@ -1,0 +1,65 @@
+"""The CPU restatement of the global-motion stages (oracle/gm_oracle.c) against the fixtures the real reference produced
+(tests/golden/gm_*.npz): FAST-9 corners, correspondences, and - with the warp filter and error tables taken from the
+reference build at run time, they are not kept in this repository - every warp / frame error call of the recorded runs."""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+for _p in ("svt-av1_amd", "oracle", "tests"):
+    sys.path.insert(0, os.path.join(ROOT, _p))
+import gm_cases  # noqa: E402
+import gmio  # noqa: E402
+
+LIGHT = [n for n in gm_cases.CASES if n not in gm_cases.HEAVY]
+
+
+@pytest.mark.parametrize("name", LIGHT)
+def test_corners_and_correspondences_match_the_reference(name):
+    case = gm_cases.CASES[name]
+    frames = gm_cases.frames_of(case)
+    for job, g in zip(case["jobs"], gm_cases.golden_of(name)):
+        frm = gmio.plane_of(frames[job["cur"]], job["level"])
+        ref = gmio.plane_of(frames[job["ref"]], job["level"])
+        cf, cr = gmio.oracle_corners(frm), gmio.oracle_corners(ref)
+        assert np.array_equal(cf, g["corners_frm"]) and np.array_equal(cr, g["corners_ref"])
+        assert np.array_equal(gmio.oracle_correspondences(frm, cf, ref, cr), g["correspondences"])
+
+
+def test_corner_list_is_cut_in_raster_order():
+    frames = gm_cases.frames_of(gm_cases.CASES["noise_640x360"])
+    full = gmio.oracle_corners(frames[0], max_points=1 << 20)
+    assert len(full) > gmio.MAX_CORNERS
+    assert np.array_equal(gmio.oracle_corners(frames[0]), full[:gmio.MAX_CORNERS])
+    order = full[:, 1].astype(np.int64) * 4096 + full[:, 0]
+    assert np.all(np.diff(order) > 0)
+
+
+@pytest.mark.skipif(not gmio.have_reference(), reason="the tables come from oracle/_ref/ref_gm, built where the reference sources are")
+@pytest.mark.parametrize("name", LIGHT)
+def test_every_recorded_error_call_is_reproduced(name):
+    tables = gmio.reference_tables()
+    case = gm_cases.CASES[name]
+    frames = gm_cases.frames_of(case)
+    for job, g in zip(case["jobs"], gm_cases.golden_of(name)):
+        frm = gmio.plane_of(frames[job["cur"]], job["level"])
+        ref = gmio.plane_of(frames[job["ref"]], job["level"])
+        for c in g["warp_calls"]:
+            c = dict(zip(gmio.WARP_FIELDS, (int(v) for v in c)))
+            got = gmio.oracle_warp_error(tables, [c["m%d" % i] for i in range(6)], [c["alpha"], c["beta"], c["gamma"], c["delta"]], ref, frm,
+                                         c["best_error"])
+            assert got == c["error"], (name, c, got)
+        for e in g["frame_errors"]:
+            assert gmio.oracle_frame_error(tables, ref, frm) == int(e)
+
+
+@pytest.mark.skipif(not gmio.have_reference(), reason="needs oracle/_ref/ref_gm")
+def test_fixtures_are_what_the_reference_gives_today():
+    name = "rotzoom_320x192"
+    case = gm_cases.CASES[name]
+    recs = gmio.run_reference(gm_cases.frames_of(case), case["jobs"])
+    for r, g in zip(recs, gm_cases.golden_of(name)):
+        assert np.array_equal(r["corners_frm"], g["corners_frm"]) and np.array_equal(r["correspondences"], g["correspondences"])
+        assert [r["final"][f] for f in gmio.FINAL_FIELDS] == [int(v) for v in g["final"]]
