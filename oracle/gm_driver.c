@@ -35,6 +35,15 @@
 #include "ref_common.h"
 
 void setup_common_rtcd_internal(CPU_FLAGS flags);
+/* AVX2 kernels of the reference, compiled stand-alone (oracle/Makefile); prototypes as in common_dsp_rtcd.h:2208 and
+ * aom_dsp_rtcd.h:908, which show them on x86 builds only */
+#ifdef REF_HAVE_AVX2
+void    svt_av1_warp_affine_avx2(const int32_t *mat, const uint8_t *ref, int width, int height, int stride, uint8_t *pred, int p_col,
+                                 int p_row, int p_width, int p_height, int p_stride, int subsampling_x, int subsampling_y,
+                                 ConvolveParams *conv_params, int16_t alpha, int16_t beta, int16_t gamma, int16_t delta);
+int64_t svt_av1_calc_frame_error_avx2(const uint8_t *const ref, int stride, const uint8_t *const dst, int p_width, int p_height,
+                                      int p_stride);
+#endif
 
 #define GM_JOB_MAGIC "SVTGMJ01"
 #define GM_OUT_MAGIC "SVTGMO01"
@@ -45,7 +54,9 @@ typedef struct gm_job_header {
     uint32_t width, height; /* full-resolution luma, multiples of 8 */
     uint32_t n_frames; /* followed by n_frames * width * height luma bytes */
     uint32_t n_jobs; /* then n_jobs gm_job */
-    uint32_t mode; /* 0: the reference alone; 1: the four seam functions on the GPU engine */
+    uint32_t mode; /* 0: the reference alone; 1: the four seam functions on the GPU engine; +2: the reference's AVX2 kernels
+                      for the warp filter and the frame error (as setup_rtcd_internal binds them on an
+                      AVX2 machine, aom_dsp_rtcd.c / common_dsp_rtcd.c), for the CPU side of a timing comparison */
 } gm_job_header;
 typedef struct gm_job {
     uint32_t cur_frame, ref_frame;
@@ -217,10 +228,16 @@ int main(int argc, char **argv) {
 
     setup_common_rtcd_internal(0);
     setup_rtcd_internal(0);
+#ifdef REF_HAVE_AVX2
+    if ((hdr.mode & 2) && __builtin_cpu_supports("avx2")) {
+        svt_av1_warp_affine               = svt_av1_warp_affine_avx2;
+        svt_av1_calc_frame_error          = svt_av1_calc_frame_error_avx2;
+    }
+#endif
     Planes *planes = (Planes *)calloc(hdr.n_frames, sizeof(Planes));
     for (uint32_t i = 0; i < hdr.n_frames; ++i) build_planes(&planes[i], frames + fsz * i, w, h);
 
-    g_use_engine = hdr.mode == 1;
+    g_use_engine = hdr.mode & 1;
     if (g_use_engine) {
         if (argc < 4) die("mode 1 needs the path of libsvtme.so as third argument");
         g_shim.lib = dlopen(argv[3], RTLD_NOW | RTLD_LOCAL);

@@ -68,12 +68,13 @@ def read_records(path, n_jobs):
     return out
 
 
-def run_reference(frames, jobs, library=None, timeout=1200):
+def run_reference(frames, jobs, library=None, timeout=1200, use_avx2=False):
     """Runs compute_global_motion of the real reference per job; with `library` (path of libsvtme.so) its four data-parallel
-    functions go to the GPU engine instead (the reference-side binding end to end)."""
+    functions go to the GPU engine instead (the reference-side binding end to end). use_avx2: the reference's AVX2 kernels
+    instead of its C ones for the warp filter and the frame error."""
     with tempfile.TemporaryDirectory() as d:
         jp, op = os.path.join(d, "job.bin"), os.path.join(d, "out.bin")
-        write_job(jp, frames, jobs, mode=1 if library else 0)
+        write_job(jp, frames, jobs, mode=(1 if library else 0) | (2 if use_avx2 else 0))
         cmd = [REF_GM, jp, op] + ([library] if library else [])
         r = subprocess.run(cmd, capture_output=True, text=True, timeout=timeout)
         if r.returncode != 0:

@@ -63,3 +63,17 @@ def test_fixtures_are_what_the_reference_gives_today():
     for r, g in zip(recs, gm_cases.golden_of(name)):
         assert np.array_equal(r["corners_frm"], g["corners_frm"]) and np.array_equal(r["correspondences"], g["correspondences"])
         assert [r["final"][f] for f in gmio.FINAL_FIELDS] == [int(v) for v in g["final"]]
+
+
+@pytest.mark.skipif(not gmio.have_reference(), reason="needs oracle/_ref/ref_gm")
+def test_reference_avx2_kernels_give_the_same_record():
+    """The fixtures come from the reference's C kernels; its AVX2 warp filter and frame error (what an AVX2
+    machine runs for them) leave the same corners, correspondences, error values and final models."""
+    for name in ("rotzoom_320x192", "affine_392x264"):
+        case = gm_cases.CASES[name]
+        recs = gmio.run_reference(gm_cases.frames_of(case), case["jobs"], use_avx2=True)
+        for r, g in zip(recs, gm_cases.golden_of(name)):
+            assert np.array_equal(r["correspondences"], g["correspondences"])
+            warps = np.array([[c[f] for f in gmio.WARP_FIELDS] for k, c in r["calls"] if k == "warp"], np.int64).reshape(-1, len(gmio.WARP_FIELDS))
+            assert np.array_equal(warps, g["warp_calls"])
+            assert [r["final"][f] for f in gmio.FINAL_FIELDS] == [int(v) for v in g["final"]]
