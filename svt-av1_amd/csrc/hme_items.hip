@@ -417,18 +417,23 @@ __global__ void __launch_bounds__(HI_THREADS, 3) hme_l0_kernel(PICS pp, int n_b6
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
+// Dwords between the staged rows of a source block. 20 for the sub-sampled searches: quick_search gives neighbouring lanes
+// neighbouring block rows, and 20 k mod 32 (k = 0..7) are eight different multiples of 4, so the 16-byte row reads of the
+// eight lanes fall into different banks (with 16 they all start in bank 0).
+template <bool FS>
+constexpr int kSrcPitch = FS ? 16 : 20;
 template <bool FS>
 struct L12Shared {
-    uint32_t src1[(FS ? 32 : 16) * 16]; // sampled rows of the quarter-resolution 32x32 block, 16 dwords apart
-    uint32_t src2[(FS ? 64 : 32) * 16]; // sampled rows of the full-resolution 64x64 block
+    uint32_t src1[(FS ? 32 : 16) * kSrcPitch<FS>]; // sampled rows of the quarter-resolution 32x32 block
+    uint32_t src2[(FS ? 64 : 32) * kSrcPitch<FS>]; // sampled rows of the full-resolution 64x64 block
 };
 
 // Exhaustive search of a small window with a large block whose sampled rows are staged at `src` (16 dwords per row):
 // position quads x block-row chunks over the lanes. bw: block width in pixels (multiple of 4 at these levels),
 // rows: sampled rows, 2 plane rows apart.
-// Sampled rows (STEP plane rows apart, at most 4 K of them) of the bw x rows block at (ox, oy) -> dst, 16 dwords per
+// Sampled rows (STEP plane rows apart, at most 4 K of them) of the bw x rows block at (ox, oy) -> dst, PITCH dwords per
 // row. Issues its loads and stores without waiting: the caller's next barrier orders them.
-template <int K = 8, int STEP = 2>
+template <int K = 8, int STEP = 2, int PITCH = 16>
 __device__ __forceinline__ void stage_block(uint32_t *dst, const DevPlane &cur, int ox, int oy, int bw, int rows) {
     const int bwd = bw >> 2, lane = threadIdx.x & 63, d = lane & 15; // one wave fetches
     if (d >= bwd) return;
@@ -441,7 +446,7 @@ __device__ __forceinline__ void stage_block(uint32_t *dst, const DevPlane &cur, 
 #pragma unroll
     for (int k = 0; k < K; ++k) {
         const int r = (lane >> 4) + 4 * k;
-        if (r < rows) dst[r * 16 + d] = v[k];
+        if (r < rows) dst[r * PITCH + d] = v[k];
     }
 }
 
@@ -493,7 +498,7 @@ __device__ u64 small_search(const uint32_t *src, uint32_t *win, const DevPlane &
                     int       px  = 0;
                     for (int j = j0; j < j1; ++j) {
                         const uint32_t *rr = win + (yl + STEP * j) * pd + xg;
-                        const uint32_t *ss = &src[j * 16];
+                        const uint32_t *ss = &src[j * kSrcPitch<FS>];
                         if (px + bw > 256) { // keep the packed 16-bit sums below 65536
 #pragma unroll
                             for (int i = 0; i < 4; ++i) a32[i] += (uint32_t)(a16 >> (16 * i)) & 0xFFFFu;
@@ -628,7 +633,9 @@ __device__ u64 strip_search_fs(const uint32_t *src, uint32_t *win, int zero, con
 // small_search for the shapes the presets use at these levels - 8 x (1..MAXH) positions (3 rows in the pre-analysis ME, 8 in
 // the first pass), full-width block of BWD dwords (8: the 32-pixel quarter-resolution block, 16: the 64-pixel
 // full-resolution block) - with everything unrolled: lane = (position quad: 2 per row x 4 rows) x (8 chunks of BWD / 4
-// sampled block rows), 4 search rows per trip; window staged in one memory round trip.
+// sampled block rows: rows chunk, chunk + 8, .., so that the eight lanes of a position quad read eight neighbouring rows
+// of the block and of the window at a time - different banks, see kSrcPitch), 4 search rows per trip; window staged in one
+// memory round trip.
 template <int BWD, int MAXH>
 __device__ u64 quick_search(const uint32_t *src, uint32_t *win, const DevPlane &ref, int rows, int wx, int wy, int sa_h) {
     constexpr int PD  = BWD + 2; // dwords per staged row: 8 positions + the block width - 1 more pixels, rounded up
@@ -661,10 +668,10 @@ __device__ u64 quick_search(const uint32_t *src, uint32_t *win, const DevPlane &
         if (active) {
 #pragma unroll
             for (int jj = 0; jj < RPC; ++jj) {
-                const int j = chunk * RPC + jj;
+                const int j = jj * 8 + chunk;
                 if (j < rows) {
                     const uint32_t *rr = win + (yl + 2 * j) * PD + xg;
-                    const uint32_t *ss = src + j * 16;
+                    const uint32_t *ss = src + j * kSrcPitch<false>;
                     uint32_t        rv[BWD + 1], sv[BWD];
 #pragma unroll
                     for (int d = 0; d <= BWD; ++d) rv[d] = rr[d];
@@ -797,8 +804,9 @@ __device__ __forceinline__ void stage_l12_blocks(const P &p, L12Shared<FS> &S, i
         if (k.enable_hme_level1_flag) stage_block<8, 1>(S.src1, load_plane(p.cur.lvl[1]), b64x >> 1, b64y >> 1, block_w >> 1, block_h >> 1);
         if (k.enable_hme_level2_flag) stage_block<16, 1>(S.src2, load_plane(p.cur.lvl[2]), b64x, b64y, block_w, block_h);
     } else {
-        if (k.enable_hme_level1_flag) stage_block(S.src1, load_plane(p.cur.lvl[1]), b64x >> 1, b64y >> 1, block_w >> 1, block_h >> 2);
-        if (k.enable_hme_level2_flag) stage_block(S.src2, load_plane(p.cur.lvl[2]), b64x, b64y, block_w, block_h >> 1);
+        if (k.enable_hme_level1_flag)
+            stage_block<8, 2, kSrcPitch<false>>(S.src1, load_plane(p.cur.lvl[1]), b64x >> 1, b64y >> 1, block_w >> 1, block_h >> 2);
+        if (k.enable_hme_level2_flag) stage_block<8, 2, kSrcPitch<false>>(S.src2, load_plane(p.cur.lvl[2]), b64x, b64y, block_w, block_h >> 1);
     }
 }
 
