@@ -21,6 +21,7 @@
 // Both kernels exist in two forms: SUB_SAD_SEARCH (every other block row, SAD x2: every preset of the pre-analysis ME)
 // and FULL_SAD_SEARCH (all block rows: the temporal filter's searches, EbTemporalFiltering.c:331). The template
 // parameter FS selects the form; the sub-sampled form's code and resources do not depend on the other's.
+#include <type_traits>
 #include "search_common.h"
 
 namespace svtme {
@@ -135,7 +136,9 @@ __device__ uint32_t slow_sad(const DevPlane &cur, const DevPlane &ref, int ox, i
 
 // The T search rows (STEP apart: same parity for a block sampled every other row, consecutive for a block sampled on
 // every row) x 4 columns of every unit of a staged window band, for a 16-pixel-wide block of `rows` sampled rows held in
-// src (wave-uniform); FULL: rows == NR. Folds each lane's best (SAD, raster index) into `best`.
+// src (wave-uniform); FULL: rows == NR. Folds each lane's best (SAD, raster index) into `best`. The window was staged with one
+// empty 16-byte piece in front of every (STEP T)-th row (stage_window's gap_shift): units STEP T rows apart start 4 banks
+// apart instead of in the same one.
 template <int T, bool FULL, int NR = 8, int STEP = 2>
 __device__ __forceinline__ void strip_units(const uint32_t *win, int pd, int n_xg, int brows, bool skip_even, const uint32_t (&src)[NR][4],
                                             int rows, int zero, int y_abs0, int x_abs0, int sa_w, u64 &best) {
@@ -154,25 +157,30 @@ __device__ __forceinline__ void strip_units(const uint32_t *win, int pd, int n_x
         const int  n_pos  = valid ? min(T, max(0, (brows - yfirst + STEP - 1) / STEP)) : 0;
         // the four 8-byte operands of a step overlap by a dword; the odd pairs are read through a second pointer the
         // compiler cannot prove equal to the first, so every pair comes from LDS in its own aligned register pair
-        const uint32_t *rr = win + yfirst * pd + xg;
+        const uint32_t *rr = win + yfirst * pd + 4 * yg + xg; // (yfirst / (STEP T) == yg)
         const uint32_t *rq = rr + 1 + zero;
         u64             acc[T];
 #pragma unroll
         for (int t = 0; t < T; ++t) acc[t] = 0;
         // row loads run one step ahead of the arithmetic (sched_barrier keeps them there)
         uint32_t n01[2], n12[2], n23[2], n34[2];
-        auto     fetch = [&]() {
+        auto     fetch = [&](auto sn_c) { // the window row of step sn: STEP sn rows below the unit's first, past sn / T gaps
+            constexpr int sn = decltype(sn_c)::value;
+            if constexpr (sn > 0 && sn % T == 0) {
+                rr += 4;
+                rq += 4;
+            }
             n01[0] = rr[0], n01[1] = rr[1], n23[0] = rr[2], n23[1] = rr[3];
             n12[0] = rq[0], n12[1] = rq[1], n34[0] = rq[2], n34[1] = rq[3];
             rr += STEP * pd;
             rq += STEP * pd;
         };
-        fetch();
+        fetch(std::integral_constant<int, 0>{});
         static_for<0, T + NR - 1>([&](auto s_c) {
             constexpr int s   = decltype(s_c)::value;
             const u64     p01 = ((u64)n01[1] << 32) | n01[0], p12 = ((u64)n12[1] << 32) | n12[0];
             const u64     p23 = ((u64)n23[1] << 32) | n23[0], p34 = ((u64)n34[1] << 32) | n34[0];
-            if constexpr (s + 1 < T + NR - 1) fetch();
+            if constexpr (s + 1 < T + NR - 1) fetch(std::integral_constant<int, s + 1>{});
             __builtin_amdgcn_sched_barrier(0);
             static_for<0, T>([&](auto t_c) {
                 constexpr int t = decltype(t_c)::value;
@@ -245,17 +253,20 @@ __device__ __forceinline__ u64 l0_search(L0Shared &S, uint32_t *win, int zero, c
             // rows the LDS budget holds: a band's search rows + the (NR - 1) STEP rows under the last one + the staggered
             // walk's overrun (rows that are addressed but never used)
             constexpr int under = (NR - 1) * STEP;
-            const int     cap   = (int)magic_div(HI_WIN_BYTES / 4, (uint32_t)pd, div_magic((uint32_t)pd));
+            // (a row costs up to 4 / (2 STEP) dwords more: the gap pieces, one per STEP T >= 2 STEP rows)
+            const int     pdg   = pd + 2 / STEP;
+            const int     cap   = (int)magic_div(HI_WIN_BYTES / 4, (uint32_t)pdg, div_magic((uint32_t)pdg));
             int           band  = cap - under - 16;
             band           = band >= 16 ? band & ~15 : max(band, 1);
             for (int y0 = 0; y0 < sa_h; y0 += band) {
                 const int brows = min(band, sa_h - y0);
-                wave_sync();
-                stage_window<5>(win, ref.pix + (ptrdiff_t)(wy + y0) * ref.stride + wx + x0, ref.stride, pd, brows + under);
-                wave_sync();
                 // rows per unit: as many as still give every lane a unit
                 const int cells = n_xg * ((brows + STEP - 1) / STEP); // position quads x rows of one walk direction
                 const int t = brows > 8 && cells >= 8 * HI_THREADS ? 8 : (brows > 4 && cells >= 4 * HI_THREADS ? 4 : 2);
+                wave_sync();
+                stage_window<5>(win, ref.pix + (ptrdiff_t)(wy + y0) * ref.stride + wx + x0, ref.stride, pd, brows + under,
+                                (STEP == 2 ? 1 : 0) + (t == 8 ? 3 : (t == 4 ? 2 : 1)));
+                wave_sync();
                 if (rows == NR) {
                     if (t == 8) strip_units<8, true, NR, STEP>(win, pd, n_xg, brows, skip_even, src, rows, zero, y0, x0, sa_w, best);
                     else if (t == 4) strip_units<4, true, NR, STEP>(win, pd, n_xg, brows, skip_even, src, rows, zero, y0, x0, sa_w, best);

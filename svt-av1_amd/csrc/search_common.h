@@ -112,20 +112,25 @@ __device__ __forceinline__ uint32_t magic_div(uint32_t i, uint32_t d, uint32_t m
 // goes to piece i of the window; indices past the end repeat the last piece (same value into the same slot), so
 // nothing branches. NB loads are in flight per lane before the first is stored: a window of up to 1 KiB x NB costs one
 // memory round trip. Reads pd * 4 bytes per row. NT > 64: the NT threads of the workgroup share the pieces.
+// gap_shift: one empty 16-byte piece goes in front of every 2^gap_shift-th row (row r starts at dword
+// r * pd + 4 * (r >> gap_shift)), so that lanes which walk row groups 2^gap_shift rows apart do not all start in the same
+// bank when 2^gap_shift * pd is a multiple of 32 dwords; 31: none.
 template <int NB, int NT = 64>
-__device__ __forceinline__ void stage_window(uint32_t *win, const uint8_t *g, int stride, int pd, int n_row) {
+__device__ __forceinline__ void stage_window(uint32_t *win, const uint8_t *g, int stride, int pd, int n_row, int gap_shift = 31) {
     const int      pr = pd >> 2, n = n_row * pr, lane = NT == 64 ? (threadIdx.x & 63) : (int)threadIdx.x;
     const uint32_t magic = div_magic((uint32_t)pr);
     uint4         *dst = reinterpret_cast<uint4 *>(win);
     for (int base = lane; base < n; base += NT * NB) {
-        uint4 v[NB];
+        uint4    v[NB];
+        uint32_t at[NB];
 #pragma unroll
         for (int k = 0; k < NB; ++k) {
             const uint32_t i = (uint32_t)min(base + NT * k, n - 1), r = magic_div(i, (uint32_t)pr, magic), d = i - r * (uint32_t)pr;
             __builtin_memcpy(&v[k], g + (ptrdiff_t)(int)r * stride + 16 * d, 16);
+            at[k] = i + (r >> gap_shift);
         }
 #pragma unroll
-        for (int k = 0; k < NB; ++k) dst[min(base + NT * k, n - 1)] = v[k];
+        for (int k = 0; k < NB; ++k) dst[at[k]] = v[k];
     }
 }
 
