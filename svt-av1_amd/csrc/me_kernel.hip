@@ -36,7 +36,6 @@ constexpr int ME_WIN_BYTES = ME_WIN_ROWS * ME_PD * 4;
 
 struct MeShared {
     __align__(16) uint32_t src[32 * 16]; // rows 0,2,..,62 of the source block, 16 dwords each
-    u64                    best[SVTME_PU_COUNT];
     u64                    hsad[8]; // per (list, ref): search centre, HME SAD, do_ref, search-range divisor
     uint32_t               div[8];
     int16_t                sc_x[8], sc_y[8];
@@ -68,6 +67,13 @@ __device__ __forceinline__ void min4(const uint32_t (&k)[4], uint32_t &best, uin
             best = k[i];
             idx  = i;
         }
+}
+
+// Minimum over the lanes of a row of 16 that share lane % 4 (the four quads of the row), for lanes 12..15 of the row.
+__device__ __forceinline__ uint32_t row_quads_min(uint32_t v) {
+    v = min(v, (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x114 /* row_shr:4 */, 0xF, 0xF, false));
+    v = min(v, (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x118 /* row_shr:8 */, 0xF, 0xF, false));
+    return v;
 }
 
 // Work items of a w x h window: one per (64-position column chunk, group of 8 rows).
@@ -322,7 +328,6 @@ __global__ void __launch_bounds__(ME_THREADS, 2) me_search_kernel(PICS pp, int n
     const DevPlane cur = load_plane(p.cur.lvl[2]);
     const DevPlane ref = load_plane(p.ref[my_l][my_r].lvl[2]);
     // ---- open_loop_me_fullpel_search_sblock
-    for (int i = tid; i < SVTME_PU_COUNT; i += ME_THREADS) S.best[i] = ~0ull;
     {
         uint4 v[2];
 #pragma unroll
@@ -370,8 +375,8 @@ __global__ void __launch_bounds__(ME_THREADS, 2) me_search_kernel(PICS pp, int n
                 const int  xg    = run;
                 const int  ya = 0, yb = rows;
                 // running minima of this lane. 8x8: packed 16-bit keys SAD * 8 + row-in-run, two positions per dword;
-                // 16x16: SAD << 16 | row; larger: SAD << 3 | row. A position that does not exist carries an all-ones row
-                // mask, which makes its keys all ones.
+                // 16x16: SAD << 16 | row << 6; larger: SAD << 9 | row << 6. A position that does not exist carries an
+                // all-ones row mask, which makes its keys all ones.
                 uint32_t b8[8][2][2];
                 uint32_t b16[4][4], b32[2][4], b64k[4];
 #pragma unroll
@@ -399,7 +404,7 @@ __global__ void __launch_bounds__(ME_THREADS, 2) me_search_kernel(PICS pp, int n
                     for (int t = 0; t < 4; ++t) {
                         const uint32_t yr = (uint32_t)(par + 2 * t);
                         ypk[t]            = t < n_pos ? yr * 0x10001u : 0xFFFFFFFFu;
-                        yrk[t]            = t < n_pos ? yr : 0xFFFFFFFFu;
+                        yrk[t]            = t < n_pos ? yr << 6 : 0xFFFFFFFFu; // (bits 0..5 take the column at the merge)
                     }
                     u64      acc0[4], acc1[4];
                     uint32_t t16[4][2], half[4][2], topv[4][2], sw[4][4];
@@ -492,9 +497,9 @@ __global__ void __launch_bounds__(ME_THREADS, 2) me_search_kernel(PICS pp, int n
                                                 bt += quad_xor1(bt);
                                                 uint32_t all = tp + bt;
                                                 all += quad_xor2(all);
-                                                b32[0][i] = min(b32[0][i], (tp << 3) | yrk[t]);
-                                                b32[1][i] = min(b32[1][i], (bt << 3) | yrk[t]);
-                                                b64k[i]   = min(b64k[i], (all << 3) | yrk[t]);
+                                                b32[0][i] = min(b32[0][i], (tp << 9) | yrk[t]);
+                                                b32[1][i] = min(b32[1][i], (bt << 9) | yrk[t]);
+                                                b64k[i]   = min(b64k[i], (all << 9) | yrk[t]);
                                             }
                                         }
                                     }
@@ -503,74 +508,64 @@ __global__ void __launch_bounds__(ME_THREADS, 2) me_search_kernel(PICS pp, int n
                         });
                     });
                 }
-                // merge this lane's minima into the workgroup keys: (SAD << 32) | (y << 16) | x, window-relative.
-                // Within the lane the 4 positions differ in x only, so the first minimum wins ties.
-                if (valid && ya + par0 < yb) { // (a quad that was given only the odd rows of a one-row group has nothing)
-                    const uint32_t ybase = (uint32_t)(ty0 + ya), xbase = (uint32_t)(tx0 + xg * 4);
-                    // 8x8: min over the 4 columns of key16 << 2 | column (first column wins ties); windows narrower
-                    // than 8 have columns past their right edge, which must not win
+                // ---- merge. Every key gets the position's column within the tile (6 bits) under its row: (SAD, row, column)
+                // then orders like the reference's raster scan. 8x8: SAD << 9 | row << 6 | column; 16x16: SAD << 16 | row << 6
+                // | column; larger: SAD << 9 | row << 6 | column. In the lane the minimum over its 4 columns; over the four
+                // quads of a row of 16 lanes through DPP (row_quads_min: no LDS, no atomics); the four rows' results meet in
+                // LDS, where the lane that owns a partition reads them. Lanes without a unit and columns past the right edge
+                // of a window narrower than 8 carry all-ones keys.
+                {
+                    const uint32_t xbase = (uint32_t)(xg * 4);
                     const bool     narrow = w < 8;
-                    uint32_t       xoff[4];
+                    uint32_t       xlab[4];
 #pragma unroll
-                    for (int i = 0; i < 4; ++i) xoff[i] = narrow && (int)(xbase + i) >= w ? 0xFFFFFFFFu : 0u;
+                    for (int i = 0; i < 4; ++i) xlab[i] = (narrow && (int)(tx0 + xbase + i) >= w) ? 0xFFFFFFFFu : xbase + i;
+                    const bool     writer = (tid & 12) == 12; // lanes 12..15 of a row hold the row's minima
+                    // (the staged window has served: the four rows' keys, [4][85] dwords, take its place)
+                    wave_sync();
+                    uint32_t      *part   = win + (tid >> 4) * SVTME_PU_COUNT;
 #pragma unroll
                     for (int by = 0; by < 8; ++by)
 #pragma unroll
                         for (int c = 0; c < 2; ++c) {
                             const uint32_t d0 = b8[by][c][0], d1 = b8[by][c][1];
-                            uint32_t       k0 = (d0 & 0xFFFFu) << 2, k1 = ((d0 >> 16) << 2) | 1u;
-                            uint32_t       k2 = ((d1 & 0xFFFFu) << 2) | 2u, k3 = ((d1 >> 16) << 2) | 3u;
-                            if (narrow) {
-                                k0 |= xoff[0];
-                                k1 |= xoff[1];
-                                k2 |= xoff[2];
-                                k3 |= xoff[3];
-                            }
-                            const uint32_t best = min(min(k0, k1), min(k2, k3));
-                            const u64 key = ((u64)(best >> 5) << 32) | ((ybase + ((best >> 2) & 7)) << 16) | (xbase + (best & 3));
-                            const int bx8 = col * 2 + c; // 8x8 block column
-                            const int pu  = 21 + z16(by >> 1, bx8 >> 1) * 4 + ((by & 1) << 1) + (bx8 & 1);
-                            atomicMin(&S.best[pu], key);
+                            const uint32_t k0 = ((d0 & 0xFFFFu) << 6) | xlab[0], k1 = ((d0 >> 16) << 6) | xlab[1];
+                            const uint32_t k2 = ((d1 & 0xFFFFu) << 6) | xlab[2], k3 = ((d1 >> 16) << 6) | xlab[3];
+                            const uint32_t k  = row_quads_min(min(min(k0, k1), min(k2, k3)));
+                            const int      bx8 = col * 2 + c; // 8x8 block column
+                            const int      pu  = 21 + z16(by >> 1, bx8 >> 1) * 4 + ((by & 1) << 1) + (bx8 & 1);
+                            if (writer) part[pu] = k;
                         }
 #pragma unroll
                     for (int a = 0; a < 4; ++a) {
-                        uint32_t kk[4], best, idx;
-#pragma unroll
-                        for (int i = 0; i < 4; ++i) kk[i] = b16[a][i] | xoff[i];
-                        min4(kk, best, idx);
-                        const u64 key = ((u64)(best >> 16) << 32) | ((ybase + (best & 7)) << 16) | (xbase + idx);
-                        atomicMin(&S.best[5 + z16(a, col)], key);
+                        const uint32_t k = row_quads_min(min(min(b16[a][0] | xlab[0], b16[a][1] | xlab[1]), min(b16[a][2] | xlab[2], b16[a][3] | xlab[3])));
+                        if (writer) part[5 + z16(a, col)] = k;
                     }
-                    if ((col & 1) == 0) {
 #pragma unroll
-                        for (int a = 0; a < 2; ++a) {
-                            uint32_t kk[4], best, idx;
-#pragma unroll
-                            for (int i = 0; i < 4; ++i) kk[i] = b32[a][i] | xoff[i];
-                            min4(kk, best, idx);
-                            const u64 key = ((u64)(best >> 3) << 32) | ((ybase + (best & 7)) << 16) | (xbase + idx);
-                            atomicMin(&S.best[1 + a * 2 + (col >> 1)], key);
-                        }
+                    for (int a = 0; a < 2; ++a) {
+                        const uint32_t k = row_quads_min(min(min(b32[a][0] | xlab[0], b32[a][1] | xlab[1]), min(b32[a][2] | xlab[2], b32[a][3] | xlab[3])));
+                        if (writer && (col & 1) == 0) part[1 + a * 2 + (col >> 1)] = k;
                     }
-                    if (col == 0) {
-                        uint32_t kk[4], best, idx;
-#pragma unroll
-                        for (int i = 0; i < 4; ++i) kk[i] = b64k[i] | xoff[i];
-                        min4(kk, best, idx);
-                        const u64 key = ((u64)(best >> 3) << 32) | ((ybase + (best & 7)) << 16) | (xbase + idx);
-                        atomicMin(&S.best[0], key);
+                    {
+                        const uint32_t k = row_quads_min(min(min(b64k[0] | xlab[0], b64k[1] | xlab[1]), min(b64k[2] | xlab[2], b64k[3] | xlab[3])));
+                        if (writer && col == 0) part[0] = k;
                     }
                 }
             }
         }
     }
     __syncthreads();
-    // ---- this item's minima join the window's
+    // ---- this item's minima join the window's: (SAD << 32) | (y << 16) | x, window-relative
     // (keys only ever decrease, so a plain - possibly stale - read that is already no larger settles it without an atomic)
     for (int pu = tid; pu < SVTME_PU_COUNT; pu += ME_THREADS) {
-        const u64 key = S.best[pu];
+        const uint32_t k = min(min(win[pu], win[SVTME_PU_COUNT + pu]), min(win[2 * SVTME_PU_COUNT + pu], win[3 * SVTME_PU_COUNT + pu]));
+        const int      sh = pu >= 5 && pu < 21 ? 16 : 9;
+        const uint32_t sad = k >> sh;
+        // a key that no position produced (cannot happen for an item the plan made): all-ones fields exceed the largest SAD
+        if (sad > (pu >= 21 ? 8u * 4u : pu >= 5 ? 16u * 8u : pu >= 1 ? 32u * 16u : 64u * 32u) * 255u) continue;
+        const u64 key = ((u64)sad << 32) | ((uint32_t)(ty0 + (int)((k >> 6) & 7)) << 16) | (uint32_t)(tx0 + (int)(k & 63));
         u64      *g   = &p.me_keys[(size_t)(b64 * 8 + my) * SVTME_PU_COUNT + pu];
-        if (key != ~0ull && key < *g) atomicMin(g, key);
+        if (key < *g) atomicMin(g, key);
     }
 }
 
