@@ -239,14 +239,19 @@ __device__ __forceinline__ u64 l0_search(L0Shared &S, uint32_t *win, int zero, c
             best        = k < best ? k : best;
         }
     } else {
-        if (lane < rows * 4)
-            S.src[lane] = *reinterpret_cast<const uint32_t *>(cur.pix + (ptrdiff_t)(oy + STEP * (lane >> 2)) * cur.stride + ox + 4 * (lane & 3));
-        wave_sync();
+        // the block's sampled rows are the same for every lane: they come through the scalar (constant) path straight into
+        // scalar registers (16-byte aligned: the block's x is a multiple of 16, the plane's origin 8-byte aligned and ... see
+        // layout_planes), in flight together with the first window band's loads; nothing goes through LDS
         uint32_t src[NR][4];
+        {
+            typedef const uint32_t __attribute__((address_space(4))) ConstU32;
 #pragma unroll
-        for (int m = 0; m < NR; ++m)
+            for (int m = 0; m < NR; ++m) {
+                ConstU32 *row = (ConstU32 *)(cur.pix + (ptrdiff_t)(oy + STEP * (m < rows ? m : 0)) * cur.stride + ox);
 #pragma unroll
-            for (int j = 0; j < 4; ++j) src[m][j] = (uint32_t)__builtin_amdgcn_readfirstlane((int)S.src[(m < rows ? m : 0) * 4 + j]);
+                for (int j = 0; j < 4; ++j) src[m][j] = row[j];
+            }
+        }
         for (int x0 = 0; x0 < sa_w; x0 += HI_XCHUNK) {
             const int n_xg = (min(HI_XCHUNK, sa_w - x0) + 3) >> 2;
             const int pd   = (n_xg + 4 + 3) & ~3; // dwords per staged row: the positions + 15 more pixels, in 16-byte pieces
