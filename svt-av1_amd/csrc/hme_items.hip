@@ -21,6 +21,7 @@
 // Both kernels exist in two forms: SUB_SAD_SEARCH (every other block row, SAD x2: every preset of the pre-analysis ME)
 // and FULL_SAD_SEARCH (all block rows: the temporal filter's searches, EbTemporalFiltering.c:331). The template
 // parameter FS selects the form; the sub-sampled form's code and resources do not depend on the other's.
+#include <stdlib.h>
 #include <type_traits>
 #include "search_common.h"
 
@@ -139,9 +140,11 @@ __device__ uint32_t slow_sad(const DevPlane &cur, const DevPlane &ref, int ox, i
 // src (wave-uniform); FULL: rows == NR. Folds each lane's best (SAD, raster index) into `best`. The window was staged with one
 // empty 16-byte piece in front of every (STEP T)-th row (stage_window's gap_shift): units STEP T rows apart start 4 banks
 // apart instead of in the same one.
-template <int T, bool FULL, int NR = 8, int STEP = 2>
+// PAIR: the window is two regions of w_reg columns side by side (w_reg a multiple of 4, so a unit lies in one of them);
+// each keeps its own minimum, with positions counted inside the region: `best` the left one's, `best1` the right one's.
+template <int T, bool FULL, int NR = 8, int STEP = 2, bool PAIR = false>
 __device__ __forceinline__ void strip_units(const uint32_t *win, int pd, int n_xg, int brows, bool skip_even, const uint32_t (&src)[NR][4],
-                                            int rows, int zero, int y_abs0, int x_abs0, int sa_w, u64 &best) {
+                                            int rows, int zero, int y_abs0, int x_abs0, int sa_w, u64 &best, int w_reg, u64 &best1) {
     const int lane   = threadIdx.x & 63;
     const int n_yg   = (brows + STEP * T - 1) / (STEP * T);
     const int n_unit = n_xg * n_yg * ((skip_even || STEP == 1) ? 1 : 2);
@@ -207,29 +210,35 @@ __device__ __forceinline__ void strip_units(const uint32_t *win, int pd, int n_x
             col[3] = min(col[3], ((hi >> 16) << 4) | tk);
         }
         // raster order: row first, then column
-        u64 ubest = ~0ull;
+        u64        ubest  = ~0ull;
+        const bool second = PAIR && x_abs0 + xg * 4 >= w_reg;
+        const int  pitch = PAIR ? w_reg : sa_w, xo = second ? w_reg : 0;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const int x = x_abs0 + xg * 4 + i;
             if (col[i] != ~0u && x < sa_w) {
                 const int y = y_abs0 + yfirst + STEP * (int)(col[i] & 15);
-                const u64 k = ((u64)(col[i] >> 4) << 32) | (uint32_t)(y * sa_w + x);
+                const u64 k = ((u64)(col[i] >> 4) << 32) | (uint32_t)(y * pitch + x - xo);
                 ubest       = k < ubest ? k : ubest;
             }
         }
-        best = ubest < best ? ubest : best;
+        if (second) best1 = ubest < best1 ? ubest : best1;
+        else best = ubest < best ? ubest : best;
     }
 }
 
 // Exhaustive search of the (bw x rows sampled rows, STEP = FS ? 1 : 2 plane rows apart) block of `cur` at (ox, oy) over
 // the sa_w x sa_h window of `ref` whose first position is plane pixel (wx, wy). Returns min (SAD << 32 | y * sa_w + x),
 // ~0 when no position was evaluated (skip_even with a single row). Whole wave. skip_even needs FS == false.
-template <bool FS>
+// PAIR (bw == 16 only): the window is two regions of w_reg = sa_w / 2 columns side by side; returns the left region's
+// minimum and leaves the right one's in key1, both with positions counted inside the region (y * w_reg + x).
+template <bool FS, bool PAIR = false>
 __device__ __forceinline__ u64 l0_search(L0Shared &S, uint32_t *win, int zero, const DevPlane &cur, const DevPlane &ref, int ox, int oy, int bw,
-                                         int rows, int wx, int wy, int sa_w, int sa_h, bool skip_even) {
+                                         int rows, int wx, int wy, int sa_w, int sa_h, bool skip_even, int w_reg, u64 &key1) {
     constexpr int NR = FS ? 16 : 8, STEP = FS ? 1 : 2;
     const int lane = threadIdx.x & 63;
-    u64       best = ~0ull;
+    u64       best = ~0ull, best1 = ~0ull;
+    key1           = ~0ull;
     if (sa_w <= 0 || sa_h <= 0 || rows <= 0) return best;
     if (bw != 16) {
         for (int i = lane; i < sa_w * sa_h; i += HI_THREADS) {
@@ -240,8 +249,7 @@ __device__ __forceinline__ u64 l0_search(L0Shared &S, uint32_t *win, int zero, c
         }
     } else {
         // the block's sampled rows are the same for every lane: they come through the scalar (constant) path straight into
-        // scalar registers (16-byte aligned: the block's x is a multiple of 16, the plane's origin 8-byte aligned and ... see
-        // layout_planes), in flight together with the first window band's loads; nothing goes through LDS
+        // scalar registers, in flight together with the first window band's loads; nothing goes through LDS
         uint32_t src[NR][4];
         {
             typedef const uint32_t __attribute__((address_space(4))) ConstU32;
@@ -273,18 +281,19 @@ __device__ __forceinline__ u64 l0_search(L0Shared &S, uint32_t *win, int zero, c
                                 (STEP == 2 ? 1 : 0) + (t == 8 ? 3 : (t == 4 ? 2 : 1)));
                 wave_sync();
                 if (rows == NR) {
-                    if (t == 8) strip_units<8, true, NR, STEP>(win, pd, n_xg, brows, skip_even, src, rows, zero, y0, x0, sa_w, best);
-                    else if (t == 4) strip_units<4, true, NR, STEP>(win, pd, n_xg, brows, skip_even, src, rows, zero, y0, x0, sa_w, best);
-                    else strip_units<2, true, NR, STEP>(win, pd, n_xg, brows, skip_even, src, rows, zero, y0, x0, sa_w, best);
+                    if (t == 8) strip_units<8, true, NR, STEP, PAIR>(win, pd, n_xg, brows, skip_even, src, rows, zero, y0, x0, sa_w, best, w_reg, best1);
+                    else if (t == 4) strip_units<4, true, NR, STEP, PAIR>(win, pd, n_xg, brows, skip_even, src, rows, zero, y0, x0, sa_w, best, w_reg, best1);
+                    else strip_units<2, true, NR, STEP, PAIR>(win, pd, n_xg, brows, skip_even, src, rows, zero, y0, x0, sa_w, best, w_reg, best1);
                 } else { // blocks of the picture's bottom edge
-                    if (t == 8) strip_units<8, false, NR, STEP>(win, pd, n_xg, brows, skip_even, src, rows, zero, y0, x0, sa_w, best);
-                    else if (t == 4) strip_units<4, false, NR, STEP>(win, pd, n_xg, brows, skip_even, src, rows, zero, y0, x0, sa_w, best);
-                    else strip_units<2, false, NR, STEP>(win, pd, n_xg, brows, skip_even, src, rows, zero, y0, x0, sa_w, best);
+                    if (t == 8) strip_units<8, false, NR, STEP, PAIR>(win, pd, n_xg, brows, skip_even, src, rows, zero, y0, x0, sa_w, best, w_reg, best1);
+                    else if (t == 4) strip_units<4, false, NR, STEP, PAIR>(win, pd, n_xg, brows, skip_even, src, rows, zero, y0, x0, sa_w, best, w_reg, best1);
+                    else strip_units<2, false, NR, STEP, PAIR>(win, pd, n_xg, brows, skip_even, src, rows, zero, y0, x0, sa_w, best, w_reg, best1);
                 }
             }
         }
     }
     wave_sync(); // the window and the block rows may be rewritten by this wave's next search
+    if (PAIR) key1 = wave_min_u64(best1);
     return wave_min_u64(best);
 }
 
@@ -320,7 +329,7 @@ __global__ void __launch_bounds__(HI_THREADS) hme_zz_kernel(PICS pp, int n_b64) 
 // other (p.dep_l0, p.dep_pre), and are complete by then. zz: the zero-MV SAD of the reference (~0 when not computed).
 template <bool FS, class P>
 __device__ __forceinline__ void l0_item(const P &p, L0Shared &S, uint32_t *win, int b64x, int b64y, int block_w, int block_h, int l, int r,
-                                        int sub, uint32_t zz, HmeRefOut *rec, const HmeRefOut *first, const HmeRefOut *same0) {
+                                        int sub, uint32_t zz, HmeRefOut *rec, const HmeRefOut *first, const HmeRefOut *same0, bool all_regions) {
     const auto    &k    = p.ctrl;
     const int      lane = threadIdx.x & 63;
     const DevPlane cur  = load_plane(p.cur.lvl[0]);
@@ -370,28 +379,67 @@ __device__ __forceinline__ void l0_item(const P &p, L0Shared &S, uint32_t *win, 
         const int q = sub - 2, nw = k.num_hme_sa_w, nh = k.num_hme_sa_h;
         if (!k.enable_hme_flag || !k.enable_hme_level0_flag || q >= nw * nh) return;
         if (k.me_early_exit_th && zz < (k.me_early_exit_th >> 2)) return;
-        const int sw = q % nw, sh = q / nw, i = sw * 2 + sh;
         int16_t   sa_w = 0, sa_h = 0;
         l0_area(p, *first, l, r, sa_w, sa_h);
-        w     = (int16_t)((sa_w + 7) & ~0x07);
-        h     = sa_h;
-        org_x = (int16_t)(-(int16_t)((w * nw) >> 1) + (int16_t)(w * sw));
-        org_y = (int16_t)(-(int16_t)((h * nh) >> 1) + (int16_t)(h * sh));
-        clip_axis(ox, org_x, w, -(ref.pad - 1), ref.width);
-        w = (int16_t)(w < 8 ? w : (w & ~0x07));
-        clip_axis(oy, org_y, h, -(ref.pad - 1), ref.height);
+        // the window of region q_
+        auto region = [&](int q_, int16_t &w_, int16_t &h_, int16_t &x_, int16_t &y_) {
+            const int sw = q_ % nw, sh = q_ / nw;
+            w_ = (int16_t)((sa_w + 7) & ~0x07);
+            h_ = sa_h;
+            x_ = (int16_t)(-(int16_t)((w_ * nw) >> 1) + (int16_t)(w_ * sw));
+            y_ = (int16_t)(-(int16_t)((h_ * nh) >> 1) + (int16_t)(h_ * sh));
+            clip_axis(ox, x_, w_, -(ref.pad - 1), ref.width);
+            w_ = (int16_t)(w_ < 8 ? w_ : (w_ & ~0x07));
+            clip_axis(oy, y_, h_, -(ref.pad - 1), ref.height);
+        };
+        if (all_regions) {
+            // This wave runs every region of the reference. Where the 2 x 2 regions tile one rectangle (no region was
+            // clipped at the picture's edge) the two regions of a row are searched as one window, each keeping its own
+            // minimum: the item's fixed part (geometry, the block's rows, staging, reductions) is paid once per pair
+            // and the lanes are twice as well filled, which is what counts for the small windows of the fast presets.
+            int16_t rw[4] = {0, 0, 0, 0}, rh[4] = {0, 0, 0, 0}, rx[4] = {0, 0, 0, 0}, ry[4] = {0, 0, 0, 0};
+            for (int q_ = 0; q_ < nw * nh; ++q_) region(q_, rw[q_], rh[q_], rx[q_], ry[q_]);
+            const bool tiled = nw == 2 && nh == 2 && bw == 16 && rw[0] >= 8 && rh[0] >= 1 && rw[1] == rw[0] && rw[2] == rw[0] && rw[3] == rw[0] &&
+                rh[1] == rh[0] && rh[2] == rh[0] && rh[3] == rh[0] && rx[1] == rx[0] + rw[0] && rx[2] == rx[0] && rx[3] == rx[1] &&
+                ry[1] == ry[0] && ry[2] == ry[0] + rh[0] && ry[3] == ry[2];
+            unsigned long long ops = 0;
+            for (int q_ = 0; q_ < nw * nh; ++q_) ops += (unsigned long long)max((int)rh[q_], 0) * max((int)rw[q_], 0) * rows * bw;
+            if (lane == 0) count_ops(p, 2, ops);
+            if (tiled) {
+                for (int sh = 0; sh < 2; ++sh) {
+                    u64       k1;
+                    const u64 k0 = l0_search<FS, true>(S, win, p.zero, cur, ref, ox, oy, bw, rows, ox + rx[0], oy + ry[2 * sh], 2 * rw[0], rh[0], false,
+                                                       rw[0], k1);
+                    if (lane == 0) {
+                        decode_key(k0, rw[0], rx[0], ry[2 * sh], 4, rec->raw_x[sh], rec->raw_y[sh], rec->raw_sad[sh], !FS);
+                        decode_key(k1, rw[0], rx[1], ry[2 * sh], 4, rec->raw_x[2 + sh], rec->raw_y[2 + sh], rec->raw_sad[2 + sh], !FS);
+                    }
+                }
+            } else {
+                for (int q_ = 0; q_ < nw * nh; ++q_) {
+                    u64       none;
+                    const int i   = (q_ % nw) * 2 + q_ / nw;
+                    const u64 key = l0_search<FS>(S, win, p.zero, cur, ref, ox, oy, bw, rows, ox + rx[q_], oy + ry[q_], rw[q_], rh[q_], false, 0, none);
+                    if (lane == 0) decode_key(key, rw[q_], rx[q_], ry[q_], 4, rec->raw_x[i], rec->raw_y[i], rec->raw_sad[i], !FS);
+                }
+            }
+            return;
+        }
+        region(q, w, h, org_x, org_y);
+        const int i = (q % nw) * 2 + q / nw;
         res_x   = &rec->raw_x[i];
         res_y   = &rec->raw_y[i];
         res_sad = &rec->raw_sad[i];
         ops_k   = 2;
     }
     if (lane == 0) count_ops(p, ops_k, (unsigned long long)max(skip ? h >> 1 : (int)h, 0) * max((int)w, 0) * rows * bw);
-    const u64 key = l0_search<FS>(S, win, p.zero, cur, ref, ox, oy, bw, rows, ox + org_x, oy + org_y, w, h, skip);
+    u64       none;
+    const u64 key = l0_search<FS>(S, win, p.zero, cur, ref, ox, oy, bw, rows, ox + org_x, oy + org_y, w, h, skip, 0, none);
     if (lane == 0) decode_key(key, w, org_x, org_y, 4, *res_x, *res_y, *res_sad, !FS);
 }
 
 template <bool FS, class PICS>
-__global__ void __launch_bounds__(HI_THREADS, 3) hme_l0_kernel(PICS pp, int n_b64, int hme_phase) {
+__global__ void __launch_bounds__(HI_THREADS, 3) hme_l0_kernel(PICS pp, int n_b64, int hme_phase, int all_regions) {
     __shared__ L0Shared               S;
     __shared__ __align__(16) uint32_t win[HI_WIN_BYTES / 4 + 64];
     const auto &p   = pp[blockIdx.x / n_b64];
@@ -429,7 +477,7 @@ __global__ void __launch_bounds__(HI_THREADS, 3) hme_l0_kernel(PICS pp, int n_b6
         out->valid  = searched ? 1u : 0u;
     }
     if (!searched) return;
-    l0_item<FS>(p, S, win, b64x, b64y, block_w, block_h, l, r, sub, zz, out, b64_out, &b64_out[r]);
+    l0_item<FS>(p, S, win, b64x, b64y, block_w, block_h, l, r, sub, zz, out, b64_out, &b64_out[r], all_regions != 0);
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -857,15 +905,19 @@ static void launch_hme_items_as(const Batch &b, PICS pics, hipStream_t s, hipEve
     const int n_refs = b.max_refs(), n_b64 = b.n_b64();
     const int n_reg  = p0.ctrl.num_hme_sa_w * p0.ctrl.num_hme_sa_h;
     const bool fs = p0.ctrl.hme_search_method == 1; // FULL_SAD_SEARCH
-    const dim3 g0(n_b64 * b.n, 2 + max(n_reg, 1), n_refs), g12((n_b64 + 7) / 8 * 8 * n_refs * n_reg, b.n);
+    // Small level-0 areas (the fast presets: 16 x 16 positions and up over the 2 x 2 regions): one work item runs all regions
+    // of a reference, the two of a row as one window; large ones keep a work item per region (shorter items, shorter tail).
+    static const int all_env = getenv("SVTME_L0_ALL_REGIONS") ? atoi(getenv("SVTME_L0_ALL_REGIONS")) : -1; // diagnostic override
+    const bool all_regions = !fs && n_reg == 4 && (all_env >= 0 ? all_env != 0 : p0.ctrl.hme_l0_sa.sa_min.width <= 16);
+    const dim3 g0(n_b64 * b.n, all_regions ? 3 : 2 + max(n_reg, 1), n_refs), g12((n_b64 + 7) / 8 * 8 * n_refs * n_reg, b.n);
     bool       deps = false;
     for (int i = 0; i < b.n; ++i) deps = deps || b.host[i].dep_pre || b.host[i].dep_l0;
     const int n_phase = deps ? 2 : 1;
     if (p0.ctrl.me_early_exit_th) hipLaunchKernelGGL(hme_zz_kernel<PICS>, dim3(n_b64 * b.n, n_refs), dim3(HI_THREADS), 0, s, pics, n_b64);
     for (int phase = 1; phase <= n_phase; ++phase) {
         const int hme_phase = n_phase == 1 ? 0 : phase;
-        if (fs) hipLaunchKernelGGL((hme_l0_kernel<true, PICS>), g0, dim3(HI_THREADS), 0, s, pics, n_b64, hme_phase);
-        else hipLaunchKernelGGL((hme_l0_kernel<false, PICS>), g0, dim3(HI_THREADS), 0, s, pics, n_b64, hme_phase);
+        if (fs) hipLaunchKernelGGL((hme_l0_kernel<true, PICS>), g0, dim3(HI_THREADS), 0, s, pics, n_b64, hme_phase, 0);
+        else hipLaunchKernelGGL((hme_l0_kernel<false, PICS>), g0, dim3(HI_THREADS), 0, s, pics, n_b64, hme_phase, all_regions ? 1 : 0);
     }
     if (marks[0]) (void)hipEventRecord(marks[0], s);
     if (p0.ctrl.enable_hme_flag) {
