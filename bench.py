@@ -17,10 +17,11 @@ computes identically), `value` = all pictures of the sequence / the slowest rank
 sequence is fixed, the ranks split it). With --with-upload every rank also puts, inside the timed region, the sources
 its share of each mini-GOP reads; `sources_put_per_picture` then says how many GPUs a source travelled to.
 
-`value` comes from the timed region, in which the engine rotates pictures over three HIP streams (one picture's
-kernel tails overlap the other pictures' kernels). Kernel durations measured there include that sharing, so the
-roofline figures come from a second pass over the same pictures with one search stream (each kernel alone on the
-GPU), timed with the same HIP events on the kernels' stream; the overlapped durations are reported beside them.
+`value` comes from the timed region. Batches (the default) go down one HIP stream, one kernel at a time on the GPU, and
+the roofline figures are the per-kernel HIP events of that same region. With pictures submitted singly (--batch 1) the
+engine rotates them over three streams (one picture's kernel tails overlap the other pictures' kernels); kernel durations
+measured there include that sharing, so the roofline figures then come from a second pass over the same pictures with one
+search stream, timed with the same HIP events on the kernels' stream; the overlapped durations are reported beside them.
 """
 import argparse
 import json
@@ -123,7 +124,8 @@ def main():
     ap.add_argument("--in-flight", type=int, default=0, help="pictures outstanding at most (default: 6, or 3 batches)")
     ap.add_argument("--batch", type=int, default=0,
                     help="pictures per svtme_pictures_submit call (they share their kernel launches); 0 = the workload's default")
-    ap.add_argument("--search-streams", type=int, default=3, choices=[1, 2, 3])
+    ap.add_argument("--search-streams", type=int, default=0, choices=[0, 1, 2, 3],
+                    help="0 = the engine's default: one stream for batches, three for pictures submitted singly")
     ap.add_argument("--kernel-steps", type=int, default=8, help="steps of the one-stream pass that times the kernels")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--with-upload", action="store_true",
@@ -205,7 +207,8 @@ def main():
                                   first_pass_bypass_zz=fp[0] if fp else None) for p in pics]
 
     # per-kernel events only where they are needed: with one search stream they are the roofline timings
-    eng, descs = make_engine(args.search_streams, 1 if args.search_streams == 1 else 0)
+    streams = args.search_streams or (1 if args.batch > 1 else 3)  # what the engine makes of 0
+    eng, descs = make_engine(args.search_streams, 1 if streams == 1 else 0)
     new_stats = lambda: {"ms": np.zeros(8, np.float64), "launches": 0, "ops": np.zeros(6, np.float64)}  # noqa: E731
     stats = new_stats()
 
@@ -263,7 +266,7 @@ def main():
             finish(e, tickets.pop(0), collect)
 
     def finish(e, t, collect):
-        e.wait(t, copy=False)
+        e.wait_raw(t)  # the picture's results have landed in pinned host memory (no conversion to numpy in the timed loop)
         if collect is not None:
             collect["ms"] += np.array(e.timing(t), np.float64)
             collect["launches"] += 1
@@ -324,7 +327,7 @@ def main():
         upload_pps = 4 * n / max(1e-9, time.perf_counter() - t1)
     # kernels alone on the GPU: same pictures, one search stream (rank 0 reports them)
     solo = stats
-    if rank == 0 and args.search_streams != 1 and args.kernel_steps > 0:
+    if rank == 0 and streams != 1 and args.kernel_steps > 0:
         eng.close()
         eng, descs = make_engine(1, 1)
         solo = new_stats()
@@ -404,7 +407,7 @@ def main():
             "kernels": {k_: {"avg_ms": v[1], "ops_per_launch": v[0], "tops": v[0] / (v[1] * 1e-3) / 1e12 if v[1] > 0 else 0.0}
                         for k_, v in kernels.items()},
             "picture_kernels_ms_in_timed_region": float(ms_shared[5]),  # first kernel start to last kernel end
-            "search_streams": args.search_streams, "pictures_per_submit": args.batch, "in_flight": args.in_flight, "device_tail": (2 if args.device_tail_only else 1) if tail is not None else 0,
+            "search_streams": streams, "pictures_per_submit": args.batch, "in_flight": args.in_flight, "device_tail": (2 if args.device_tail_only else 1) if tail is not None else 0,
             "store_put_pictures_per_s": upload_pps,
             "with_upload": ({"mode": args.upload_mode, "sources_put_per_step": n,
                              "note": "every source picture of a step is put into the device store once inside the timed region"}

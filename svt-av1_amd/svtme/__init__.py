@@ -460,6 +460,15 @@ class Engine:
             raise SvtmeError(rc, "svtme_picture_wait")
         return results_to_arrays(r, copy)
 
+    def wait_raw(self, ticket):
+        """svtme_picture_wait without the conversion to numpy: the Results struct, whose pointers lie in the engine's pinned
+        host buffers (valid until done()). What a C caller gets; for loops that only need the results to have landed."""
+        r = Results()
+        rc = self.lib.svtme_picture_wait(self.h, ticket, C.byref(r))
+        if rc:
+            raise SvtmeError(rc, "svtme_picture_wait")
+        return r
+
     def search_static(self, pic, result_block, result_bytes):
         """svtme_picture_search_static: the picture's search without any allocation, results into caller-owned memory the
         device can write (`result_block`: an address). Returns the Results struct, whose pointers lie inside the block."""
