@@ -40,21 +40,22 @@ import numpy as np  # noqa: E402
 # BASELINE.json configs -> shapes. "1080p_ra_m3" is configs[2]: 1080p random access, mini-GOP 16, HME L0/L1/L2 + full-pel
 # search, up to 4+3 references (preset 3 = MRP level 3), the single-GPU 1080p configuration the metric is quoted on.
 WORKLOADS = {
-    "1080p_ra_m3": dict(width=1920, height=1080, enc_mode=3, structure="ra", n_frames=17, bit_depth=8, batch=4),
-    # "batch": pictures per svtme_pictures_submit call. The fast presets are bound by per-launch costs, which a mini-GOP
-    # submitted at once pays once; the others gain nothing from it (measured: profiles/r02_batch_sweep.txt)
+    "1080p_ra_m3": dict(width=1920, height=1080, enc_mode=3, structure="ra", n_frames=17, bit_depth=8, batch=8),
+    # "batch": pictures per svtme_pictures_submit call (the pictures of a mini-GOP are posted back to back,
+    # EbPictureDecisionProcess.c:6842-6874). The fast presets are bound by per-launch costs, which a mini-GOP submitted at
+    # once pays once; the slow ones gain the shorter kernel tails (measured: profiles/r02_batch_sweep.txt)
     "1080p_ra_m8": dict(width=1920, height=1080, enc_mode=8, structure="ra", n_frames=17, bit_depth=8, batch=16),
     "720p_ld_m12": dict(width=1280, height=720, enc_mode=12, structure="ldp", n_frames=17, bit_depth=8, batch=16),
-    "4k_ra_m8": dict(width=3840, height=2160, enc_mode=8, structure="ra", n_frames=17, bit_depth=10, batch=4),
-    "8k_ra_m2": dict(width=7680, height=4320, enc_mode=2, structure="ra", n_frames=17, bit_depth=8),
+    "4k_ra_m8": dict(width=3840, height=2160, enc_mode=8, structure="ra", n_frames=17, bit_depth=10, batch=8),
+    "8k_ra_m2": dict(width=7680, height=4320, enc_mode=2, structure="ra", n_frames=17, bit_depth=8, batch=2),
     # temporal-filter searches (ME_MCTF): a 7-frame window, the centre frame searched in each of its 6 neighbours; one
     # "picture" = one (centre, neighbour) pair. tf = (tf_ctrls.hme_me_level, tf_ctrls.me_exit_th): level 0 is what presets
     # up to M5 use, level 2 with the 16x16 exit threshold what the fast presets use (EbEncHandle.c:2556-2876).
     "1080p_tf_l0": dict(width=1920, height=1080, enc_mode=0, structure="tf", n_frames=7, bit_depth=8, tf=(0, 0), batch=4),
-    "1080p_tf_l2": dict(width=1920, height=1080, enc_mode=8, structure="tf", n_frames=7, bit_depth=8, tf=(2, 256)),
+    "1080p_tf_l2": dict(width=1920, height=1080, enc_mode=8, structure="tf", n_frames=7, bit_depth=8, tf=(2, 256), batch=6),
     # first-pass ME of a two-pass encode (ME_FIRST_PASS): every frame searches the previous and the first frame;
     # fp = (ipp_pass_ctrls.bypass_zz_check, ipp_pass_ctrls.reduce_me_search)
-    "1080p_first_pass": dict(width=1920, height=1080, enc_mode=8, structure="fp", n_frames=17, bit_depth=8, fp=(0, 0)),
+    "1080p_first_pass": dict(width=1920, height=1080, enc_mode=8, structure="fp", n_frames=17, bit_depth=8, fp=(0, 0), batch=16),
 }
 STAGES = ["zz_centre", "prehme", "hme_l0", "hme_l1", "hme_l2", "integer_search"]
 # Packed-SAD peak of gfx950: 256 CUs x 4 SIMDs x 16 lanes/clk (v_sad_u8 / v_qsad_pk_u16_u8 issue at a quarter of the
@@ -368,8 +369,9 @@ def main():
                     traffic_note = "%s was measured on other kernel sources: not reported" % os.path.basename(path)
                     continue
                 t = doc["kernels"]["svtme::" + name]
-                traffic = (2.0 * t["fetch_kib"] + t["write_kib"]) * 1024.0
-                traffic_note = "%s (2 x FETCH_SIZE + WRITE_SIZE per launch, measured on these kernel sources)" % os.path.basename(path)
+                # (the counters are per launch of a whole batch; the figures here are per picture)
+                traffic = (2.0 * t["fetch_kib"] + t["write_kib"]) * 1024.0 / max(1, int(doc.get("pictures_per_launch", 1)))
+                traffic_note = "%s (2 x FETCH_SIZE + WRITE_SIZE per picture of a launch, measured on these kernel sources)" % os.path.basename(path)
                 break
         except (OSError, KeyError, ValueError):
             pass
@@ -395,6 +397,8 @@ def main():
             "roofline": {
                 "bound": "valu", "kernel": name, "achieved": achieved, "peak": PEAK_SAD_TOPS,
                 "unit": "T abs-diff-acc/s", "frac": achieved / PEAK_SAD_TOPS, "traffic": traffic, "traffic_source": traffic_note,
+                # a launch covers the `pictures_per_submit` pictures of a batch: operations, duration and traffic are the
+                # launch's divided by that number, i.e. per picture
                 "ops_per_launch": dom_ops, "avg_launch_ms": dom_ms,
                 "measured": "HIP events on the kernels' stream, %d-step pass with one search stream after the timed region"
                             % args.kernel_steps if solo is not stats else "HIP events on the kernels' stream, timed region",
