@@ -297,17 +297,19 @@ __global__ void __launch_bounds__(ME_THREADS) me_plan_kernel(PICS pp, int n_b64,
 }
 
 template <class PICS>
-__global__ void __launch_bounds__(ME_THREADS, 2) me_search_kernel(PICS pp, int n_b64, int ref_first, int ref_last) {
+__global__ void __launch_bounds__(ME_THREADS, 2) me_search_kernel(PICS pp, int grid_refs, int ref_first, int ref_last) {
     __shared__ MeShared               S;
     __shared__ __align__(16) uint32_t win[ME_WIN_BYTES / 4];
-    const auto &p = pp[blockIdx.x / n_b64];
+    // the grid's slowest dimension is (picture, reference): the work items of one picture are dispatched together, so that
+    // the workgroups in flight read a picture or two's planes rather than the whole batch's (what L2 holds)
+    const auto &p = pp[blockIdx.z / grid_refs];
     const int tid = threadIdx.x;
-    const int b64 = blockIdx.x % n_b64;
+    const int b64 = blockIdx.x;
     const int b64x = (b64 % p.b64_w) * 64, b64y = (b64 / p.b64_w) * 64;
     // references in reverse order: the closest references (smallest windows, cheapest items) are dispatched last and
     // keep the kernel's tail short. The grid covers the batch's longest reference list; the launch covers references
     // ref_first .. ref_last (list-0 references first, then list 1).
-    int       my_l = 0, my_r = p.n_ref[0] + (p.n_list == 2 ? p.n_ref[1] : 0) - 1 - (int)blockIdx.z;
+    int       my_l = 0, my_r = p.n_ref[0] + (p.n_list == 2 ? p.n_ref[1] : 0) - 1 - (int)(blockIdx.z % grid_refs);
     if (my_r < ref_first || my_r > ref_last) return;
     if (my_r >= p.n_ref[0]) {
         my_r -= p.n_ref[0];
@@ -648,13 +650,13 @@ static void launch_me_as(const Batch &b, PICS pics, hipStream_t s, hipEvent_t ma
     int        me_ref0 = 0;
     if (two_phase) {
         hipLaunchKernelGGL(me_plan_kernel<PICS>, dim3(n_b64 * b.n, 1), dim3(ME_THREADS), 0, s, pics, n_b64, 0);
-        hipLaunchKernelGGL(me_search_kernel<PICS>, dim3(n_b64 * b.n, p.me_max_items, n_refs), dim3(ME_THREADS), 0, s, pics, n_b64, 0, 0);
+        hipLaunchKernelGGL(me_search_kernel<PICS>, dim3(n_b64, p.me_max_items, n_refs * b.n), dim3(ME_THREADS), 0, s, pics, n_refs, 0, 0);
         me_ref0 = 1;
     }
     const int n_now = n_refs - me_ref0;
     hipLaunchKernelGGL(me_plan_kernel<PICS>, dim3(n_b64 * b.n, n_now), dim3(ME_THREADS), 0, s, pics, n_b64, me_ref0);
     if (marks[0]) (void)hipEventRecord(marks[0], s);
-    hipLaunchKernelGGL(me_search_kernel<PICS>, dim3(n_b64 * b.n, p.me_max_items, n_refs), dim3(ME_THREADS), 0, s, pics, n_b64, me_ref0, 1 << 30);
+    hipLaunchKernelGGL(me_search_kernel<PICS>, dim3(n_b64, p.me_max_items, n_refs * b.n), dim3(ME_THREADS), 0, s, pics, n_refs, me_ref0, 1 << 30);
     if (marks[1]) (void)hipEventRecord(marks[1], s);
     hipLaunchKernelGGL(me_finish_kernel<PICS>, dim3((n_b64 * n_refs * SVTME_PU_COUNT + 255) / 256, b.n), dim3(256), 0, s, pics);
     if (marks[2]) (void)hipEventRecord(marks[2], s);
