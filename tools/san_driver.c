@@ -311,6 +311,41 @@ static uint64_t run_extras(uint32_t w, uint32_t h, uint32_t seed, uint64_t hsh) 
         CHECK(svtme_host_free(eng, block));
         hsh = fnv(hsh, &a, sizeof(a));
     }
+    /* global-motion calls on the stored pictures. The warp filter and the error table are the caller's to give: this walk
+       uses stand-ins of the right shape (an identity filter: tap 3 = 128, and |error| as the measure), with which the warp
+       error of the identity model is the frame error */
+    {
+        static int32_t pts[2 * SVTME_GM_MAX_CORNERS], corr[4 * SVTME_GM_MAX_CORNERS];
+        int32_t        n_pts = 0, n_corr = 0, n_few = 0;
+        int64_t        e_frame = 0, e_warp = 0, e_stop = 0;
+        EXPECT(svtme_gm_frame_error(eng, 102, 100, 0, &e_frame), SVTME_ERR_BAD_ARG); /* no tables yet */
+        int16_t filter[193 * 8];
+        int32_t lut[512];
+        for (int i = 0; i < 193; ++i)
+            for (int k = 0; k < 8; ++k) filter[i * 8 + k] = k == 3 ? 128 : 0;
+        for (int i = 0; i < 512; ++i) lut[i] = i < 255 ? 255 - i : i - 255;
+        EXPECT(svtme_gm_set_tables(eng, NULL, lut), SVTME_ERR_BAD_ARG);
+        CHECK(svtme_gm_set_tables(eng, filter, lut));
+        for (int level = 0; level < 3; ++level) {
+            CHECK(svtme_gm_corners(eng, 102, level, pts, SVTME_GM_MAX_CORNERS, &n_pts));
+            CHECK(svtme_gm_corners(eng, 102, level, pts, 5, &n_few));
+            if (n_few != (n_pts < 5 ? n_pts : 5)) EXPECT(-110, SVTME_OK);
+            CHECK(svtme_gm_correspondences(eng, 102, 100, level, corr, &n_corr));
+            if (n_corr > n_pts) EXPECT(-111, SVTME_OK);
+            hsh = fnv(hsh, &n_pts, sizeof(n_pts));
+            hsh = fnv(hsh, corr, sizeof(int32_t) * 4 * (size_t)n_corr);
+            svtme_gm_warp wm = {{0, 0, 1 << 16, 0, 0, 1 << 16}, 0, 0, 0, 0};
+            CHECK(svtme_gm_frame_error(eng, 102, 100, level, &e_frame));
+            CHECK(svtme_gm_warp_error(eng, 102, 100, level, &wm, INT64_MAX, &e_warp));
+            CHECK(svtme_gm_warp_error(eng, 102, 100, level, &wm, 0, &e_stop)); /* stops after the first 32x32 block */
+            if (e_warp != e_frame || e_stop > e_warp || e_frame <= 0) EXPECT(-112, SVTME_OK);
+            hsh = fnv(hsh, &e_frame, sizeof(e_frame));
+            hsh = fnv(hsh, &e_stop, sizeof(e_stop));
+        }
+        EXPECT(svtme_gm_corners(eng, 999, 0, pts, 8, &n_pts), SVTME_ERR_NOT_FOUND);
+        EXPECT(svtme_gm_corners(eng, 102, 3, pts, 8, &n_pts), SVTME_ERR_BAD_ARG);
+        EXPECT(svtme_gm_warp_error(eng, 102, 100, 0, NULL, 0, &e_warp), SVTME_ERR_BAD_ARG);
+    }
     svtme_destroy(eng);
     /* two engines on this device behind one handle: pictures round robin, sources where they are read */
     {
