@@ -7,8 +7,10 @@
 // another one's result, so that every search of a picture can run at the same time:
 //
 //  hme_l0_kernel   one wave per (b64, reference, search), search = one of the 2 pre-HME shapes or one of the 2x2
-//                  level-0 regions: ~15 000 items per 1080p picture. The 16x16 block of the sixteenth-resolution
-//                  picture (8 sampled rows x 4 dwords) sits in registers; the reference window is staged in LDS. A lane
+//                  level-0 regions: ~15 000 items per 1080p picture (for the small level-0 areas of the fast presets:
+//                  one item for the four regions of a reference, the two of a row searched as one window). The 16x16
+//                  block of the sixteenth-resolution picture (8 sampled rows x 4 dwords) sits in scalar registers
+//                  (scalar loads: it is the same for every lane); the reference window is staged in LDS. A lane
 //                  owns 4 horizontally adjacent positions x T same-parity search rows and walks them together, staggered
 //                  by one sampled source row, so each reference row is read from LDS once for 4 T positions: 32 T
 //                  v_qsad_pk_u16_u8 per unit into T packed accumulators.
@@ -33,11 +35,6 @@ constexpr int HI_XCHUNK    = 96; // search positions per staged column chunk (le
 constexpr int HI_WIN2_BYTES = 6144; // levels 1 and 2
 constexpr int HI_WIN2_BYTES_FS = 8192; // the same with FULL_SAD_SEARCH: 16 + 63 rows of the 64x64 block's 16x16 window
 constexpr int HI_THREADS_FS = 64; // threads of a level-1/2 work item with FULL_SAD_SEARCH
-
-// Per-wave LDS of a level-0 / pre-HME search: the sampled rows of the 16x16 sixteenth-resolution block.
-struct L0Shared {
-    uint32_t src[16 * 4];
-};
 
 // Level-0 vector of region (0,0) of list 0 / reference 0 (record `o`) as hme_level0_b64 leaves it (:1967-1999): the
 // region's own result unless it is the worst of the regions and a pre-HME result beats it; zero on the zero-MV early exit
@@ -233,7 +230,7 @@ __device__ __forceinline__ void strip_units(const uint32_t *win, int pd, int n_x
 // PAIR (bw == 16 only): the window is two regions of w_reg = sa_w / 2 columns side by side; returns the left region's
 // minimum and leaves the right one's in key1, both with positions counted inside the region (y * w_reg + x).
 template <bool FS, bool PAIR = false>
-__device__ __forceinline__ u64 l0_search(L0Shared &S, uint32_t *win, int zero, const DevPlane &cur, const DevPlane &ref, int ox, int oy, int bw,
+__device__ __forceinline__ u64 l0_search(uint32_t *win, int zero, const DevPlane &cur, const DevPlane &ref, int ox, int oy, int bw,
                                          int rows, int wx, int wy, int sa_w, int sa_h, bool skip_even, int w_reg, u64 &key1) {
     constexpr int NR = FS ? 16 : 8, STEP = FS ? 1 : 2;
     const int lane = threadIdx.x & 63;
@@ -328,7 +325,7 @@ __global__ void __launch_bounds__(HI_THREADS) hme_zz_kernel(PICS pp, int n_b64) 
 // the record of list 0 / reference r: both are only read when the picture's controls make references depend on each
 // other (p.dep_l0, p.dep_pre), and are complete by then. zz: the zero-MV SAD of the reference (~0 when not computed).
 template <bool FS, class P>
-__device__ __forceinline__ void l0_item(const P &p, L0Shared &S, uint32_t *win, int b64x, int b64y, int block_w, int block_h, int l, int r,
+__device__ __forceinline__ void l0_item(const P &p, uint32_t *win, int b64x, int b64y, int block_w, int block_h, int l, int r,
                                         int sub, uint32_t zz, HmeRefOut *rec, const HmeRefOut *first, const HmeRefOut *same0, bool all_regions) {
     const auto    &k    = p.ctrl;
     const int      lane = threadIdx.x & 63;
@@ -408,7 +405,7 @@ __device__ __forceinline__ void l0_item(const P &p, L0Shared &S, uint32_t *win, 
             if (tiled) {
                 for (int sh = 0; sh < 2; ++sh) {
                     u64       k1;
-                    const u64 k0 = l0_search<FS, true>(S, win, p.zero, cur, ref, ox, oy, bw, rows, ox + rx[0], oy + ry[2 * sh], 2 * rw[0], rh[0], false,
+                    const u64 k0 = l0_search<FS, true>(win, p.zero, cur, ref, ox, oy, bw, rows, ox + rx[0], oy + ry[2 * sh], 2 * rw[0], rh[0], false,
                                                        rw[0], k1);
                     if (lane == 0) {
                         decode_key(k0, rw[0], rx[0], ry[2 * sh], 4, rec->raw_x[sh], rec->raw_y[sh], rec->raw_sad[sh], !FS);
@@ -419,7 +416,7 @@ __device__ __forceinline__ void l0_item(const P &p, L0Shared &S, uint32_t *win, 
                 for (int q_ = 0; q_ < nw * nh; ++q_) {
                     u64       none;
                     const int i   = (q_ % nw) * 2 + q_ / nw;
-                    const u64 key = l0_search<FS>(S, win, p.zero, cur, ref, ox, oy, bw, rows, ox + rx[q_], oy + ry[q_], rw[q_], rh[q_], false, 0, none);
+                    const u64 key = l0_search<FS>(win, p.zero, cur, ref, ox, oy, bw, rows, ox + rx[q_], oy + ry[q_], rw[q_], rh[q_], false, 0, none);
                     if (lane == 0) decode_key(key, rw[q_], rx[q_], ry[q_], 4, rec->raw_x[i], rec->raw_y[i], rec->raw_sad[i], !FS);
                 }
             }
@@ -434,13 +431,12 @@ __device__ __forceinline__ void l0_item(const P &p, L0Shared &S, uint32_t *win, 
     }
     if (lane == 0) count_ops(p, ops_k, (unsigned long long)max(skip ? h >> 1 : (int)h, 0) * max((int)w, 0) * rows * bw);
     u64       none;
-    const u64 key = l0_search<FS>(S, win, p.zero, cur, ref, ox, oy, bw, rows, ox + org_x, oy + org_y, w, h, skip, 0, none);
+    const u64 key = l0_search<FS>(win, p.zero, cur, ref, ox, oy, bw, rows, ox + org_x, oy + org_y, w, h, skip, 0, none);
     if (lane == 0) decode_key(key, w, org_x, org_y, 4, *res_x, *res_y, *res_sad, !FS);
 }
 
 template <bool FS, class PICS>
 __global__ void __launch_bounds__(HI_THREADS, 3) hme_l0_kernel(PICS pp, int n_b64, int hme_phase, int all_regions) {
-    __shared__ L0Shared               S;
     __shared__ __align__(16) uint32_t win[HI_WIN_BYTES / 4 + 64];
     const auto &p   = pp[blockIdx.x / n_b64];
     const auto &k   = p.ctrl;
@@ -477,7 +473,7 @@ __global__ void __launch_bounds__(HI_THREADS, 3) hme_l0_kernel(PICS pp, int n_b6
         out->valid  = searched ? 1u : 0u;
     }
     if (!searched) return;
-    l0_item<FS>(p, S, win, b64x, b64y, block_w, block_h, l, r, sub, zz, out, b64_out, &b64_out[r], all_regions != 0);
+    l0_item<FS>(p, win, b64x, b64y, block_w, block_h, l, r, sub, zz, out, b64_out, &b64_out[r], all_regions != 0);
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
