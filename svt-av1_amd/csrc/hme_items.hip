@@ -700,21 +700,31 @@ template <int BWD, int MAXH>
 __device__ u64 quick_search(const uint32_t *src, uint32_t *win, const DevPlane &ref, int rows, int wx, int wy, int sa_h) {
     constexpr int PD  = BWD + 2; // dwords per staged row: 8 positions + the block width - 1 more pixels, rounded up
     constexpr int RPC = BWD / 4; // sampled block rows per lane (rows <= 8 RPC); RPC x 4 BWD x 255 fits the 16-bit sums
-    constexpr int NB  = ((MAXH + 2 * (8 * RPC - 1)) * PD + 63) / 64;
+    constexpr int PR  = (PD + 3) / 4; // 16-byte pieces per staged row; the last one carries PD - 4 (PR - 1) = 2 dwords
+    constexpr int NB  = ((MAXH + 2 * (8 * RPC - 1)) * PR + 63) / 64;
+    static_assert(PD - 4 * (PR - 1) == 2, "the last piece of a row is half a piece");
     const int     lane = threadIdx.x & 63;
-    const int     n = (sa_h + 2 * (rows - 1)) * PD;
+    const int     n = (sa_h + 2 * (rows - 1)) * PR;
     wave_sync();
     {
-        // element i = lane + 64 k of the window; indices past the end repeat the last element (same value, same slot)
+        // piece i = lane + 64 k of the window, 16 bytes in one load (a third of the load instructions of dword loads,
+        // which is what this kernel waits for); indices past the end repeat the last piece (same value, same slot). The
+        // LDS rows stay PD dwords apart (the walk's bank pattern), so a row's last piece stores its first 8 bytes only.
         const uint8_t *g = ref.pix + (ptrdiff_t)wy * ref.stride + wx;
-        uint32_t       v[NB];
+        uint4          v[NB];
+        int            at[NB];
 #pragma unroll
         for (int k = 0; k < NB; ++k) {
-            const int i = min(lane + 64 * k, n - 1), r = i / PD, d = i - r * PD;
-            __builtin_memcpy(&v[k], g + (ptrdiff_t)r * ref.stride + 4 * d, 4);
+            const int i = min(lane + 64 * k, n - 1), r = i / PR, c = i - r * PR;
+            __builtin_memcpy(&v[k], g + (ptrdiff_t)r * ref.stride + 16 * c, 16);
+            at[k] = (r * PD + 4 * c) | (c == PR - 1 ? (int)0x80000000 : 0);
         }
 #pragma unroll
-        for (int k = 0; k < NB; ++k) win[min(lane + 64 * k, n - 1)] = v[k];
+        for (int k = 0; k < NB; ++k) {
+            uint2 *dst = reinterpret_cast<uint2 *>(win + (at[k] & 0x7FFFFFFF)); // (PD is even: 8-byte aligned)
+            dst[0]     = make_uint2(v[k].x, v[k].y);
+            if (at[k] >= 0) dst[1] = make_uint2(v[k].z, v[k].w);
+        }
     }
     wave_sync();
     const int chunk = lane & 7, q = lane >> 3, xg = q & 1;
