@@ -484,8 +484,8 @@ template <bool FS>
 constexpr int kSrcPitch = FS ? 16 : 20;
 template <bool FS>
 struct L12Shared {
-    uint32_t src1[(FS ? 32 : 16) * kSrcPitch<FS>]; // sampled rows of the quarter-resolution 32x32 block
-    uint32_t src2[(FS ? 64 : 32) * kSrcPitch<FS>]; // sampled rows of the full-resolution 64x64 block
+    __align__(16) uint32_t src1[(FS ? 32 : 16) * kSrcPitch<FS>]; // sampled rows of the quarter-resolution 32x32 block
+    __align__(16) uint32_t src2[(FS ? 64 : 32) * kSrcPitch<FS>]; // sampled rows of the full-resolution 64x64 block
 };
 
 // Exhaustive search of a small window with a large block whose sampled rows are staged at `src` (16 dwords per row):
@@ -495,18 +495,23 @@ struct L12Shared {
 // row. Issues its loads and stores without waiting: the caller's next barrier orders them.
 template <int K = 8, int STEP = 2, int PITCH = 16>
 __device__ __forceinline__ void stage_block(uint32_t *dst, const DevPlane &cur, int ox, int oy, int bw, int rows) {
-    const int bwd = bw >> 2, lane = threadIdx.x & 63, d = lane & 15; // one wave fetches
-    if (d >= bwd) return;
-    uint32_t v[K];
+    // 16-byte pieces, a row's in neighbouring lanes: lane = (row of the trip: lane / 4, piece: lane % 4), 16 rows per trip
+    // (PITCH is a multiple of 4 dwords and dst 16-byte aligned; a piece may reach past a narrower block's right edge,
+    // into columns the searches do not read)
+    static_assert(PITCH % 4 == 0, "rows start on 16-byte boundaries");
+    const int lane = threadIdx.x & 63, c = lane & 3, pr = (bw + 15) >> 4; // one wave fetches
+    if (c >= pr) return;
+    constexpr int KT = (4 * K + 15) / 16; // trips: up to 4 K rows, 16 per trip
+    uint4         v[KT];
 #pragma unroll
-    for (int k = 0; k < K; ++k) {
-        const int r = (lane >> 4) + 4 * k;
-        if (r < rows) v[k] = *reinterpret_cast<const uint32_t *>(cur.pix + (ptrdiff_t)(oy + STEP * r) * cur.stride + ox + 4 * d);
+    for (int k = 0; k < KT; ++k) {
+        const int r = (lane >> 2) + 16 * k;
+        if (r < rows) __builtin_memcpy(&v[k], cur.pix + (ptrdiff_t)(oy + STEP * r) * cur.stride + ox + 16 * c, 16);
     }
 #pragma unroll
-    for (int k = 0; k < K; ++k) {
-        const int r = (lane >> 4) + 4 * k;
-        if (r < rows) dst[r * PITCH + d] = v[k];
+    for (int k = 0; k < KT; ++k) {
+        const int r = (lane >> 2) + 16 * k;
+        if (r < rows) *reinterpret_cast<uint4 *>(dst + r * PITCH + 4 * c) = v[k];
     }
 }
 
