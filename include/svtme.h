@@ -440,6 +440,61 @@ int svtme_gm_warp_error(svtme_engine *e, uint64_t cur_key, uint64_t ref_key, int
                         int64_t best_error, int64_t *error);
 int svtme_gm_frame_error(svtme_engine *e, uint64_t cur_key, uint64_t ref_key, int downsample_level, int64_t *error);
 
+/* ---- TPL dispenser: the source-based mode search of tpl_mc_flow_dispenser_sb_generic
+ * (Source/Lib/Encoder/Codec/EbSourceBasedOperationsProcess.c:632-933): for every block of the dispenser's grid the cost of
+ * the DC intra prediction from the source picture's own neighbours (:651-691) and the cost of every single-reference ME
+ * candidate at its full-pel vector, clamped to TPL_PADX / TPL_PADY around the reference (:836-930), on the full-resolution
+ * planes the store already holds (tpl_ref_ds_ptr_array[l][r].picture_ptr is the input_padded_picture_ptr of the same PA
+ * reference objects ME reads, EbPictureDecisionProcess.c:4985-4988). These searches read source pictures only, so all
+ * blocks of a picture are independent; what follows in the dispenser - transform, quantisation and reconstruction of the
+ * chosen mode, in raster order because intra prediction then reads reconstructed neighbours (:935-1197) - stays in the
+ * encoder, which runs it on the results exactly as it does when tpl_src_data_ready is set (:993-1002).
+ *
+ * The grid: dispenser_search_level 0 / 1 / 2 = 16x16 / 32x32 / 64x64 blocks (:540-542), 16x16 in every 64x64 block that
+ * is not complete (:2086-2088, :2113-2115), a block counts when at least half of it lies inside the picture (:604-607).
+ * Results are indexed [b64][i], i = 0 the 64x64 block, 1-4 the 32x32 blocks, 5-20 the 16x16 blocks in the order of
+ * tpl_blk_idx_tab (:514-516); blocks outside the grid have valid = 0.
+ *
+ * Costs: the sum of absolute differences where the encoder's controls say so (tpl_opt_flag && use_pred_sad_in_intra_search,
+ * tpl_opt_flag && use_pred_sad_in_inter_search: tpl levels 4-7, presets M7 and faster, EbResourceCoordinationProcess.c:
+ * 241-330; EbEncHandle.c:3098-3125). The transform-domain cost of the slower levels and the directional / smooth / Paeth
+ * intra modes of tpl_opt_flag == 0 are not on the device: SVTME_ERR_UNSUPPORTED. The ME results come in the layout of
+ * MeSbResults (EbMotionEstimationLcuResults.h:29-52), n_pu entries per 64x64 block (SQUARE_PU_COUNT or
+ * MAX_SB64_PU_COUNT_NO_8X8), one 64x64 block after the other. Synchronous; takes turns with the global-motion calls. */
+#define SVTME_TPL_BLOCKS 21
+typedef struct svtme_tpl_picture {
+    uint64_t cur_key; /* pcs->enhanced_picture_ptr: the picture's own store entry */
+    uint64_t ref_key[SVTME_MAX_LISTS][SVTME_MAX_REFS]; /* tpl_data.tpl_ref_ds_ptr_array[l][r].picture_ptr */
+    uint8_t  ref_skip[SVTME_MAX_LISTS][SVTME_MAX_REFS]; /* ref_tpl_group_idx > 0 && !base_pcs->tpl_valid_pic[..] (:846-849) */
+    uint32_t width, height; /* enhanced_picture_ptr->width / height */
+    uint8_t  i_slice; /* pcs->slice_type == I_SLICE: no ME candidates (:832-834) */
+    uint8_t  dispenser_search_level; /* tpl_ctrls.dispenser_search_level */
+    uint8_t  disable_intra_pred; /* tpl_ctrls.disable_intra_pred_nref && !tpl_data.is_used_as_reference_flag (:592-593) */
+    uint8_t  tpl_opt_flag; /* tpl_ctrls.* */
+    uint8_t  use_pred_sad_in_intra_search;
+    uint8_t  use_pred_sad_in_inter_search;
+    uint8_t  enable_me_16x16; /* pcs->enable_me_16x16 (:827-828) */
+    uint8_t  n_pu; /* entries per 64x64 block in the three arrays below */
+    uint8_t  max_cand, max_refs, max_l0; /* pa_me_data->max_cand / max_refs / max_l0 */
+    uint8_t  n_ref[SVTME_MAX_LISTS]; /* tpl_data.tpl_ref0_count / tpl_ref1_count: ref_key[l][r] is set for r < n_ref[l]; a
+                                        candidate that names another reference makes the call fail with SVTME_ERR_BAD_ARG */
+    uint8_t  reserved[3];
+    const uint8_t  *total_me_candidate_index; /* [n_b64][n_pu] */
+    const uint8_t  *me_candidate_array; /* [n_b64][n_pu * max_cand], MeCandidate bytes */
+    const uint32_t *me_mv_array; /* [n_b64][n_pu * max_refs], MvCandidate::as_int */
+} svtme_tpl_picture;
+
+typedef struct svtme_tpl_block {
+    int64_t best_intra_cost; /* INT64_MAX when intra prediction is disabled (:636) */
+    int64_t best_inter_cost; /* INT64_MAX when no candidate passed the gates (:635) */
+    int16_t mv_x, mv_y; /* final_best_mv.col / .row: 1/8 pel, clamped (:853-876); 0 without a candidate */
+    int8_t  best_rf_idx; /* svt_get_ref_frame_type(list, ref) - 1, -1 without a candidate (:619, :850) */
+    uint8_t best_is_inter; /* best_inter_cost < best_intra_cost: best_mode is NEWMV, else DC_PRED (:932-933) */
+    uint8_t best_intra_mode; /* DC_PRED (0) */
+    uint8_t valid; /* 1: the block belongs to the dispenser's grid */
+} svtme_tpl_block;
+int svtme_tpl_search(svtme_engine *e, const svtme_tpl_picture *pic, svtme_tpl_block *out /* [n_b64][SVTME_TPL_BLOCKS] */);
+
 const char *svtme_version(void);
 
 #ifdef __cplusplus

@@ -39,6 +39,9 @@
 #include "aom_dsp_rtcd.h"
 #include "common_dsp_rtcd.h"
 #include "EbMcp.h"
+#include "EbEncodeContext.h"
+#include "EbModeDecisionProcess.h" /* quantizer_to_qindex */
+#include "EbUtility.h" /* get_coded_blk_stats */
 
 #include "../include/svtme.h"
 #include "ref_dump.h"
@@ -63,6 +66,16 @@ void perform_gm_detection(PictureParentControlSet *pcs_ptr, uint32_t sb_index, M
 void compute_distortion(PictureParentControlSet *pcs_ptr, uint32_t sb_index, MeContext *context_ptr);
 void    get_max_allocated_me_refs(uint8_t ref_count_used_list0, uint8_t ref_count_used_list1,
                                   uint8_t *max_ref_to_alloc, uint8_t *max_cand_to_alloc);
+
+/* the TPL dispenser and what it needs set up (EbSourceBasedOperationsProcess.c:547, :375; EbResourceCoordinationProcess.c:161;
+ * EbIntraPrediction.c:1867, :1879, called by svt_av1_enc_init, EbEncHandle.c:1460-1464) */
+void tpl_mc_flow_dispenser_sb_generic(EncodeContext *encode_context_ptr, SequenceControlSet *scs_ptr, PictureParentControlSet *pcs_ptr,
+                                      int32_t frame_idx, uint32_t sb_index, int32_t qIndex, uint8_t dispenser_search_level);
+void set_tpl_extended_controls(PictureParentControlSet *pcs_ptr, uint8_t tpl_level);
+void svt_av1_build_quantizer(AomBitDepth bit_depth, int32_t y_dc_delta_q, int32_t u_dc_delta_q, int32_t u_ac_delta_q,
+                             int32_t v_dc_delta_q, int32_t v_ac_delta_q, Quants *const quants, Dequants *const deq);
+void init_intra_dc_predictors_c_internal(void);
+void init_intra_predictors_internal(void);
 
 /* AVX2 kernels of the reference, compiled stand-alone from
  * Source/Lib/Encoder/ASM_AVX2/EbComputeSAD_Intrinsic_AVX2.c (prototypes as in aom_dsp_rtcd.h). */
@@ -608,6 +621,206 @@ static void run_pic_shim(Shim *s, const Job *job, uint32_t pi, PicState *st) {
     free(m);
 }
 
+
+/* ---------------------------------------------------------------------------------------------------------------
+ * REF_MODE_TPL: the TPL dispenser of one picture (tpl_disp_kernel's loop over the 64x64 blocks,
+ * EbSourceBasedOperationsProcess.c:2105-2116) on the ME results run_pic just left in pcs->pa_me_data, every reference
+ * outside the sliding window (the source pictures are the references of the reconstruction path too), which makes a
+ * picture's run independent of the others. The cost functions are reached through the reference's own function
+ * pointers, which lets the driver keep every cost per block. */
+static const uint8_t k_tpl_blk_cu[21] = {0, 1, 22, 43, 64, 2, 7, 12, 17, 23, 28, 33, 38, 44, 49, 54, 59, 65, 70, 75, 80}; /* tpl_blk_idx_tab[0], :514-516 */
+
+typedef struct TplLog {
+    const uint8_t *plane0; /* pixel (0,0) of the current picture's full plane */
+    uint32_t       stride, w16;
+    int32_t        cur; /* 16x16 cell of the block at work */
+    uint8_t       *n;
+    int32_t       *costs; /* [cell][REF_TPL_MAX_COSTS] */
+    uint32_t (*sad)(const uint8_t *, uint32_t, const uint8_t *, uint32_t, uint32_t, uint32_t);
+    int (*satd)(const TranLow *, int);
+    void (*subtract)(int, int, int16_t *, ptrdiff_t, const uint8_t *, ptrdiff_t, const uint8_t *, ptrdiff_t);
+} TplLog;
+static TplLog g_tpl;
+
+static void tpl_log_block(const uint8_t *src_mb) {
+    const ptrdiff_t off = src_mb - g_tpl.plane0;
+    g_tpl.cur = (int32_t)((off / g_tpl.stride) >> 4) * (int32_t)g_tpl.w16 + (int32_t)((off % g_tpl.stride) >> 4);
+}
+static void tpl_log_cost(int32_t c) {
+    if (g_tpl.cur < 0) return;
+    if (g_tpl.n[g_tpl.cur] >= REF_TPL_MAX_COSTS) die("more costs per block than REF_TPL_MAX_COSTS");
+    g_tpl.costs[(size_t)g_tpl.cur * REF_TPL_MAX_COSTS + g_tpl.n[g_tpl.cur]++] = c;
+}
+static uint32_t tpl_rec_sad(const uint8_t *src, uint32_t src_stride, const uint8_t *ref, uint32_t ref_stride, uint32_t h, uint32_t w) {
+    tpl_log_block(src);
+    const uint32_t v = g_tpl.sad(src, src_stride, ref, ref_stride, h, w);
+    tpl_log_cost((int32_t)v);
+    return v;
+}
+static void tpl_rec_subtract(int rows, int cols, int16_t *diff, ptrdiff_t diff_stride, const uint8_t *src, ptrdiff_t src_stride,
+                             const uint8_t *pred, ptrdiff_t pred_stride) {
+    tpl_log_block(src);
+    g_tpl.subtract(rows, cols, diff, diff_stride, src, src_stride, pred, pred_stride);
+}
+static int tpl_rec_satd(const TranLow *coeff, int length) {
+    const int v = g_tpl.satd(coeff, length);
+    tpl_log_cost(v);
+    return v;
+}
+
+typedef struct TplState {
+    EncodeContext      *enc;
+    EbPictureBufferDesc recon;
+    EbObjectWrapper     scs_wrapper;
+    uint32_t            w16, h16, n_stats;
+    int32_t             qindex;
+} TplState;
+
+static void tpl_setup(const Job *job, uint32_t pi, PicState *st, TplState *t) {
+    const ref_job_pic       *jp  = &job->pics[pi];
+    PictureParentControlSet *pcs = st->pcs;
+    SequenceControlSet      *scs = st->scs;
+    const uint32_t           w = job->hdr.width, h = job->hdr.height;
+    memset(t, 0, sizeof(*t));
+    t->w16 = (w + 15) >> 4;
+    t->h16 = (h + 15) >> 4;
+    t->scs_wrapper.object_ptr = scs;
+    pcs->scs_wrapper_ptr      = &t->scs_wrapper;
+    pcs->enhanced_picture_ptr = &job->planes[jp->cur_frame].full;
+    pcs->hierarchical_levels  = 4;
+    scs->static_config.hierarchical_levels = 4;
+    scs->static_config.qp     = jp->tpl_qp;
+    scs->lad_mg     = 1;
+    scs->tpl_lad_mg = 1; /* keeps the source-based results in tpl_src_stats_buffer (:983-992) */
+    scs->in_loop_ois = 1; /* EbEncHandle.c:3495 */
+    scs->seq_header.max_frame_width  = (uint16_t)w;
+    scs->seq_header.max_frame_height = (uint16_t)h;
+    scs->seq_header.enable_intra_edge_filter = 1;
+    scs->enable_paeth = scs->enable_smooth = DEFAULT;
+    set_tpl_extended_controls(pcs, jp->tpl_level);
+    svt_av1_build_quantizer(AOM_BITS_8, 0, 0, 0, 0, 0, &scs->quants_8bit, &scs->deq_8bit);
+    t->qindex = quantizer_to_qindex[jp->tpl_qp]; /* tpl_mc_flow_dispenser :1355, enable_tpl_qps is 0 at every level */
+
+    TPLData *td = &pcs->tpl_data;
+    td->tpl_slice_type            = pcs->slice_type;
+    td->tpl_temporal_layer_index  = jp->temporal_layer;
+    td->is_used_as_reference_flag = jp->is_ref;
+    td->base_pcs                  = pcs;
+    td->tpl_ref0_count            = jp->n_ref[0]; /* tpl_regular_setup_me_refs, EbPictureDecisionProcess.c:4955-4996 */
+    td->tpl_ref1_count            = jp->n_list == 2 ? jp->n_ref[1] : 0;
+    for (int l = 0; l < jp->n_list; ++l)
+        for (int r = 0; r < jp->n_ref[l]; ++r) {
+            td->ref_in_slide_window[l][r] = EB_FALSE;
+            td->ref_tpl_group_idx[l][r]   = -1;
+            td->tpl_ref_ds_ptr_array[l][r].picture_ptr    = &job->planes[jp->ref_frame[l][r]].full;
+            td->tpl_ref_ds_ptr_array[l][r].picture_number = jp->ref_poc[l][r];
+        }
+    pcs->tpl_src_data_ready = 0;
+
+    MotionEstimationData *md = pcs->pa_me_data;
+    md->tpl_src_stats_buffer = (TplSrcStats *)calloc((size_t)t->w16 * t->h16, sizeof(TplSrcStats));
+    for (uint32_t i = 0; i < t->w16 * t->h16; ++i) md->tpl_src_stats_buffer[i].best_rf_idx = -99; /* "not written" */
+    t->n_stats    = (t->w16 * 2) * (t->h16 * 2); /* the finest grid result_model_store writes (8x8, :253-287) */
+    md->tpl_stats = (TplStats **)calloc(t->n_stats, sizeof(TplStats *)); /* pointers into one array: a block's entry is */
+    TplStats *all = (TplStats *)calloc(t->n_stats + 4 * t->w16 * 2 + 4, sizeof(TplStats)); /* followed in memory by its */
+    for (uint32_t i = 0; i < t->n_stats; ++i) md->tpl_stats[i] = all + i; /* neighbours' (result_model_store) */
+
+    desc_init(&t->recon, w, h, TPL_PADX); /* :1730-1745 */
+    t->enc = (EncodeContext *)calloc(1, sizeof(EncodeContext));
+    if (!t->enc || !md->tpl_src_stats_buffer) die("out of memory");
+    t->enc->mc_flow_rec_picture_buffer[0] = &t->recon;
+
+    g_tpl.plane0 = pcs->enhanced_picture_ptr->buffer_y + pcs->enhanced_picture_ptr->origin_x +
+        (size_t)pcs->enhanced_picture_ptr->origin_y * pcs->enhanced_picture_ptr->stride_y;
+    g_tpl.stride = pcs->enhanced_picture_ptr->stride_y;
+    g_tpl.w16    = t->w16;
+    g_tpl.cur    = -1;
+    g_tpl.n      = (uint8_t *)calloc((size_t)t->w16 * t->h16, 1);
+    g_tpl.costs  = (int32_t *)calloc((size_t)t->w16 * t->h16 * REF_TPL_MAX_COSTS, sizeof(int32_t));
+}
+
+static void tpl_dump(const Job *job, uint32_t pi, PicState *st, TplState *t, FILE *o) {
+    PictureParentControlSet *pcs = st->pcs;
+    const TplControls       *tc  = &pcs->tpl_ctrls;
+    const uint32_t           w = job->hdr.width, h = job->hdr.height;
+    ref_tpl_pic_dump pd;
+    memset(&pd, 0, sizeof(pd));
+    pd.tpl_opt_flag = tc->tpl_opt_flag;
+    pd.use_pred_sad_in_intra_search = tc->use_pred_sad_in_intra_search;
+    pd.use_pred_sad_in_inter_search = tc->use_pred_sad_in_inter_search;
+    pd.dispenser_search_level = tc->dispenser_search_level;
+    pd.subsample_tx = tc->subsample_tx;
+    pd.pf_shape     = (uint8_t)tc->pf_shape;
+    pd.disable_intra_pred = tc->disable_intra_pred_nref && pcs->tpl_data.is_used_as_reference_flag == 0;
+    pd.synth_blk_size = tc->synth_blk_size;
+    pd.qindex = (uint32_t)t->qindex;
+    uint64_t hash = 0xcbf29ce484222325ull;
+    for (uint32_t y = 0; y < h; ++y) {
+        const uint8_t *row = t->recon.buffer_y + (size_t)(y + t->recon.origin_y) * t->recon.stride_y + t->recon.origin_x;
+        for (uint32_t x = 0; x < w; ++x) hash = (hash ^ row[x]) * 0x100000001b3ull;
+    }
+    pd.recon_hash = hash;
+    fwrite(&pd, sizeof(pd), 1, o);
+    for (uint32_t b64 = 0; b64 < st->n_b64; ++b64) {
+        const SbParams *sp = &pcs->sb_params_array[b64];
+        for (int bi = 0; bi < 21; ++bi) {
+            const CodedBlockStats *bs = get_coded_blk_stats(k_tpl_blk_cu[bi]);
+            const uint32_t x = sp->origin_x + bs->origin_x, y = sp->origin_y + bs->origin_y, cell = (y >> 4) * t->w16 + (x >> 4);
+            ref_tpl_blk_dump d;
+            memset(&d, 0, sizeof(d));
+            const uint8_t level = (sp->width == 64 && sp->height == 64) ? tc->dispenser_search_level : 0;
+            const int in_level  = level == 0 ? bi >= 5 : (level == 1 ? (bi >= 1 && bi <= 4) : bi == 0);
+            const TplSrcStats *ss = &pcs->pa_me_data->tpl_src_stats_buffer[cell];
+            if (in_level && x < w && y < h && ss->best_rf_idx != -99) {
+                d.valid           = 1;
+                d.best_mode       = ss->best_mode;
+                d.best_intra_mode = (uint8_t)ss->best_intra_mode;
+                d.best_rf_idx     = ss->best_rf_idx;
+                d.mv_row          = ss->mv.row;
+                d.mv_col          = ss->mv.col;
+                d.ref_frame_poc   = ss->ref_frame_poc;
+                d.src_srcrf_dist  = ss->srcrf_dist;
+                d.src_srcrf_rate  = ss->srcrf_rate;
+                d.n_costs         = g_tpl.n[cell];
+                memcpy(d.costs, &g_tpl.costs[(size_t)cell * REF_TPL_MAX_COSTS], sizeof(d.costs));
+                const TplStats *ts; /* result_model_store's grids, :223-287 */
+                if (tc->synth_blk_size == 32) ts = pcs->pa_me_data->tpl_stats[(y >> 5) * ((pcs->aligned_width + 31) / 32) + (x >> 5)];
+                else if (tc->synth_blk_size == 16) ts = pcs->pa_me_data->tpl_stats[(y >> 4) * ((pcs->aligned_width + 15) / 16) + (x >> 4)];
+                else ts = pcs->pa_me_data->tpl_stats[(y >> 3) * (((pcs->aligned_width + 15) / 16) << 1) + (x >> 3)];
+                d.srcrf_dist = ts->srcrf_dist; d.recrf_dist = ts->recrf_dist;
+                d.srcrf_rate = ts->srcrf_rate; d.recrf_rate = ts->recrf_rate;
+                d.stats_mv_row = ts->mv.row;   d.stats_mv_col = ts->mv.col;
+                d.stats_ref_frame_poc = ts->ref_frame_poc;
+            }
+            fwrite(&d, sizeof(d), 1, o);
+        }
+    }
+}
+
+static void tpl_free(PicState *st, TplState *t) {
+    MotionEstimationData *md = st->pcs->pa_me_data;
+    free(md->tpl_stats[0]);
+    free(md->tpl_stats);
+    free(md->tpl_src_stats_buffer);
+    free(t->recon.buffer_y);
+    free(t->enc);
+    free(g_tpl.n);
+    free(g_tpl.costs);
+    g_tpl.n = NULL; g_tpl.costs = NULL;
+}
+
+static void run_pic_tpl(const Job *job, uint32_t pi, PicState *st, FILE *o) {
+    TplState t;
+    tpl_setup(job, pi, st, &t);
+    for (uint32_t sb = 0; sb < st->n_b64; ++sb) {
+        const SbParams *sp = &st->scs->sb_params_array[sb];
+        tpl_mc_flow_dispenser_sb_generic(t.enc, st->scs, st->pcs, 0, sb, t.qindex,
+                                         (sp->width == 64 && sp->height == 64) ? st->pcs->tpl_ctrls.dispenser_search_level : 0);
+    }
+    tpl_dump(job, pi, st, &t, o);
+    tpl_free(st, &t);
+}
+
 static double now_s(void) {
     struct timespec ts;
     clock_gettime(CLOCK_MONOTONIC, &ts);
@@ -703,6 +916,28 @@ int main(int argc, char **argv) {
             free_pic(&st);
         }
         shim.destroy(shim.engine);
+    } else if (job.hdr.mode == REF_MODE_TPL) {
+        init_intra_dc_predictors_c_internal();
+        init_intra_predictors_internal();
+        g_tpl.sad      = svt_nxm_sad_kernel_sub_sampled;
+        g_tpl.satd     = svt_aom_satd;
+        g_tpl.subtract = svt_aom_subtract_block;
+        fwrite(&oh, sizeof(oh), 1, o);
+        for (uint32_t pi = 0; pi < job.hdr.n_pics; ++pi) {
+            PicState st;
+            memset(&st, 0, sizeof(st));
+            setup_pic(&job, pi, &st);
+            run_pic(&job, pi, &st, job.hdr.threads, 1);
+            fwrite(st.out, 1, sizeof(ref_pic_dump) + (size_t)st.n_b64 * sizeof(ref_b64_dump), o);
+            svt_nxm_sad_kernel_sub_sampled = tpl_rec_sad;
+            svt_aom_satd                   = tpl_rec_satd;
+            svt_aom_subtract_block         = tpl_rec_subtract;
+            run_pic_tpl(&job, pi, &st, o);
+            svt_nxm_sad_kernel_sub_sampled = g_tpl.sad;
+            svt_aom_satd                   = g_tpl.satd;
+            svt_aom_subtract_block         = g_tpl.subtract;
+            free_pic(&st);
+        }
     } else if (job.hdr.mode == REF_MODE_DUMP) {
         fwrite(&oh, sizeof(oh), 1, o);
         for (uint32_t pi = 0; pi < job.hdr.n_pics; ++pi) {

@@ -19,6 +19,13 @@
 #define REF_MODE_SHIM 5 /* ref_me only: the reference-side binding end to end. The searches run on the GPU engine through
                            its C ABI (a third argument names libsvtme.so), every block's results are unpacked into a real
                            MeContext, and the reference's own me_prune_ref .. perform_gm_detection run on it */
+#define REF_MODE_TPL 6 /* ref_me only: after each picture's ME, the TPL dispenser (tpl_mc_flow_dispenser_sb_generic,
+                          EbSourceBasedOperationsProcess.c:547-1199) over all its 64x64 blocks with the controls of
+                          ref_job_pic::tpl_level and the quantiser of ::tpl_qp; every picture's ME dump is followed by a
+                          ref_tpl_pic_dump and n_b64 * 21 ref_tpl_blk_dump records. With a third argument (libsvtme.so) the
+                          source-based search of every block comes from the GPU engine (svtme_tpl_search) and the dispenser
+                          runs with tpl_src_data_ready = 1, i.e. only its reconstruction path */
+#define REF_TPL_MAX_COSTS 24
 #define REF_DUMP_MAX_REFS 7 /* MAX_PA_ME_MV, EbMotionEstimationLcuResults.h:23 */
 #define REF_DUMP_MAX_CAND 23 /* MAX_PA_ME_CAND, :24 */
 
@@ -58,7 +65,9 @@ typedef struct ref_job_pic {
     uint8_t  tf_hme_me_level;
     uint16_t tf_me_exit_th;
     uint8_t  restricted_motion_vector; /* scs->static_config.restricted_motion_vector (single tile) */
-    uint8_t  pad[3];
+    uint8_t  tpl_level; /* REF_MODE_TPL: set_tpl_extended_controls' level (EbResourceCoordinationProcess.c:161-341) */
+    uint8_t  tpl_qp; /* REF_MODE_TPL: scs->static_config.qp */
+    uint8_t  pad[1];
 } ref_job_pic;
 
 typedef struct ref_out_header {
@@ -110,5 +119,32 @@ typedef struct ref_b64_dump {
      * whatever the previous block wrote). */
     uint8_t tf_me_exit;
 } ref_b64_dump;
+
+/* REF_MODE_TPL */
+typedef struct ref_tpl_pic_dump {
+    uint8_t  tpl_opt_flag, use_pred_sad_in_intra_search, use_pred_sad_in_inter_search, dispenser_search_level;
+    uint8_t  subsample_tx, pf_shape, disable_intra_pred, synth_blk_size;
+    uint32_t qindex;
+    uint64_t recon_hash; /* FNV-1a over the reconstructed luma, row by row, after the last block */
+} ref_tpl_pic_dump;
+
+/* One of the 21 blocks (tpl_blk_idx_tab order: 64x64, 4 x 32x32, 16 x 16x16) of a 64x64 block. */
+typedef struct ref_tpl_blk_dump {
+    uint8_t  valid; /* the dispenser processed this block */
+    uint8_t  best_mode; /* TplSrcStats (:985-991) */
+    uint8_t  best_intra_mode;
+    uint8_t  n_costs;
+    int32_t  best_rf_idx;
+    int16_t  mv_row, mv_col;
+    uint64_t ref_frame_poc;
+    int64_t  src_srcrf_dist, src_srcrf_rate;
+    /* every svt_nxm_sad_kernel_sub_sampled / svt_aom_satd result of the block in call order: the intra modes, then the
+     * ME candidates that passed the gates (:636-930) */
+    int32_t  costs[REF_TPL_MAX_COSTS];
+    /* TplStats as result_model_store left them (:211-288) */
+    int64_t  srcrf_dist, recrf_dist, srcrf_rate, recrf_rate;
+    int16_t  stats_mv_row, stats_mv_col;
+    uint64_t stats_ref_frame_poc;
+} ref_tpl_blk_dump;
 #pragma pack(pop)
 #endif

@@ -12,7 +12,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 REF_BIN = os.path.join(HERE, "_ref", "ref_me")
 ORACLE_BIN = os.path.join(HERE, "build", "oracle_me")
 
-MODE_DUMP, MODE_BENCH, MODE_PLANES, MODE_DUMP_NOTAIL, MODE_TAIL, MODE_SHIM = 0, 1, 2, 3, 4, 5
+MODE_DUMP, MODE_BENCH, MODE_PLANES, MODE_DUMP_NOTAIL, MODE_TAIL, MODE_SHIM, MODE_TPL = 0, 1, 2, 3, 4, 5, 6
 
 SA = np.dtype([("width", "<u2"), ("height", "<u2")])
 SAMM = np.dtype([("sa_min", SA), ("sa_max", SA)])
@@ -54,20 +54,35 @@ B64_DUMP = np.dtype([
     ("stationary_block_present_sb", "u1"), ("rc_me_allow_gm", "u1"), ("tf_me_exit", "u1"),
 ])
 
+TPL_MAX_COSTS = 24
+TPL_PIC_DUMP = np.dtype([
+    ("tpl_opt_flag", "u1"), ("use_pred_sad_in_intra_search", "u1"), ("use_pred_sad_in_inter_search", "u1"),
+    ("dispenser_search_level", "u1"), ("subsample_tx", "u1"), ("pf_shape", "u1"), ("disable_intra_pred", "u1"),
+    ("synth_blk_size", "u1"), ("qindex", "<u4"), ("recon_hash", "<u8"),
+])
+TPL_BLK_DUMP = np.dtype([
+    ("valid", "u1"), ("best_mode", "u1"), ("best_intra_mode", "u1"), ("n_costs", "u1"), ("best_rf_idx", "<i4"),
+    ("mv_row", "<i2"), ("mv_col", "<i2"), ("ref_frame_poc", "<u8"), ("src_srcrf_dist", "<i8"), ("src_srcrf_rate", "<i8"),
+    ("costs", "<i4", (TPL_MAX_COSTS,)),
+    ("srcrf_dist", "<i8"), ("recrf_dist", "<i8"), ("srcrf_rate", "<i8"), ("recrf_rate", "<i8"),
+    ("stats_mv_row", "<i2"), ("stats_mv_col", "<i2"), ("stats_ref_frame_poc", "<u8"),
+])
+
 _HDR = "<8sIIIIIIIIII"
-_PIC = "<IIQiBBBBBBBB8I8QBBHB3x"
+_PIC = "<IIQiBBBBBBBB8I8QBBHBBBx"
 _OUT = "<8sIIIIIIdQ"
 
 
 def write_job(path, frames, pics, enc_mode, *, mode=MODE_DUMP, threads=1, use_avx2=0, reps=1,
               frame_rate=30 << 16, sc_class1=0, gm_enabled=0, gm_dist_th=0, ref_counts=(4, 3), tf=None, first_pass=None,
-              restricted_motion_vector=0, number_scale=1):
+              restricted_motion_vector=0, number_scale=1, tpl=(0, 0)):
     """frames: uint8 [n, h, w]; pics: list of svtme.gop.Picture (refs are POCs = frame indices).
     tf = (hme_me_level, me_exit_th) runs every picture as a temporal-filter search (ME_MCTF) of its first list-0
     reference: the controls then come from tf_signal_derivation_me_kernel_oq and enc_mode is not used.
     first_pass = (bypass_zz_check, reduce_me_search) runs every picture as first-pass ME (ME_FIRST_PASS): controls from
     first_pass_signal_derivation_me_kernel; enc_mode only selects the HME level flags.
-    number_scale: picture numbers are poc * number_scale (frames stay indexed by poc): stretches the picture distances."""
+    number_scale: picture numbers are poc * number_scale (frames stay indexed by poc): stretches the picture distances.
+    tpl = (tpl_level, qp): MODE_TPL runs the TPL dispenser with these after every picture's ME."""
     variant = (1, tf[0], tf[1]) if tf else ((4, (first_pass[0] & 1) | ((first_pass[1] & 1) << 1), 0) if first_pass else (0, 0, 0))
     n, h, w = frames.shape
     with open(path, "wb") as f:
@@ -82,11 +97,13 @@ def write_job(path, frames, pics, enc_mode, *, mode=MODE_DUMP, threads=1, use_av
             n_list = 2 if p.refs[1] else 1
             f.write(struct.pack(_PIC, p.poc, frame_rate, p.poc * number_scale, enc_mode, p.temporal_layer, p.is_ref, n_list,
                                 len(p.refs[0]), len(p.refs[1]), sc_class1, gm_enabled, gm_dist_th,
-                                *rf[0], *rf[1], *[r * number_scale for r in rf[0] + rf[1]], *variant, restricted_motion_vector))
+                                *rf[0], *rf[1], *[r * number_scale for r in rf[0] + rf[1]], *variant, restricted_motion_vector,
+                                tpl[0], tpl[1]))
 
 
 def read_dump(path):
-    """Returns (header dict, list of (pic_dump record, b64 record array))."""
+    """Returns (header dict, list of (pic_dump record, b64 record array)); MODE_TPL: list of (pic_dump, b64 records,
+    tpl pic record, tpl block records [n_b64, 21])."""
     with open(path, "rb") as f:
         data = f.read()
     hs = struct.calcsize(_OUT)
@@ -94,7 +111,7 @@ def read_dump(path):
     assert magic == b"SVTMEO01", magic
     hdr = dict(n_pics=n_pics, n_b64=n_b64, used_avx2=avx2, mode=mode, bench_seconds=secs, bench_pictures=npic)
     out = []
-    if mode in (MODE_DUMP, MODE_DUMP_NOTAIL, MODE_TAIL, MODE_SHIM):
+    if mode in (MODE_DUMP, MODE_DUMP_NOTAIL, MODE_TAIL, MODE_SHIM, MODE_TPL):
         assert pds == PIC_DUMP.itemsize and bds == B64_DUMP.itemsize, (pds, PIC_DUMP.itemsize, bds, B64_DUMP.itemsize)
         off = hs
         for _ in range(n_pics):
@@ -102,6 +119,13 @@ def read_dump(path):
             off += pds
             bd = np.frombuffer(data, B64_DUMP, n_b64, off)
             off += bds * n_b64
+            if mode == MODE_TPL:
+                tp = np.frombuffer(data, TPL_PIC_DUMP, 1, off)[0]
+                off += TPL_PIC_DUMP.itemsize
+                tb = np.frombuffer(data, TPL_BLK_DUMP, n_b64 * 21, off).reshape(n_b64, 21)
+                off += TPL_BLK_DUMP.itemsize * n_b64 * 21
+                out.append((pd, bd, tp, tb))
+                continue
             out.append((pd, bd))
     elif mode == MODE_PLANES:
         off = hs
@@ -156,6 +180,13 @@ def run_reference_shim(frames, pics, enc_mode, library, **kw):
     (libsvtme.so) through its C ABI, each block's results are unpacked into a real MeContext and the reference's own
     me_prune_ref .. perform_gm_detection finish the block. Returns what run_reference returns."""
     return run_binary(REF_BIN, frames, pics, enc_mode, extra_args=(library,), mode=MODE_SHIM, **kw)
+
+
+def run_reference_tpl(frames, pics, enc_mode, tpl_level, qp, library=None, **kw):
+    """ref_me's MODE_TPL: every picture's ME, then the TPL dispenser on its results. With `library` (libsvtme.so) the
+    dispenser's source-based search comes from the GPU engine and only its reconstruction path runs on the host."""
+    return run_binary(REF_BIN, frames, pics, enc_mode, extra_args=(library,) if library else (), mode=MODE_TPL,
+                      tpl=(tpl_level, qp), **kw)
 
 
 def run_oracle(frames, pics, enc_mode, **kw):

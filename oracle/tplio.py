@@ -1,0 +1,121 @@
+"""TEST INFRASTRUCTURE: ctypes access to the CPU restatement of the TPL dispenser's source-based mode search
+(oracle/tpl_oracle.c) and the structures it shares with the engine's C ABI (include/svtme.h). Not part of the product."""
+import ctypes
+import os
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ORACLE_LIB = os.path.join(HERE, "build", "libme_oracle.so")
+TPL_BLOCKS = 21
+INT64_MAX = (1 << 63) - 1
+
+# tpl_blk_idx_tab (EbSourceBasedOperationsProcess.c:514-516): position and size of block i inside its 64x64 block
+BLOCK_GEOMETRY = [(0, 0, 64)] + [((i & 1) * 32, (i >> 1) * 32, 32) for i in range(4)] + \
+    [((q & 1) * 32 + (s & 1) * 16, (q >> 1) * 32 + (s >> 1) * 16, 16) for q in range(4) for s in range(4)]
+
+TPL_BLOCK = np.dtype([("best_intra_cost", "<i8"), ("best_inter_cost", "<i8"), ("mv_x", "<i2"), ("mv_y", "<i2"),
+                      ("best_rf_idx", "i1"), ("best_is_inter", "u1"), ("best_intra_mode", "u1"), ("valid", "u1")])
+assert TPL_BLOCK.itemsize == 24
+
+
+class TplPicture(ctypes.Structure):
+    _fields_ = [("cur_key", ctypes.c_uint64), ("ref_key", (ctypes.c_uint64 * 4) * 2), ("ref_skip", (ctypes.c_uint8 * 4) * 2),
+                ("width", ctypes.c_uint32), ("height", ctypes.c_uint32),
+                ("i_slice", ctypes.c_uint8), ("dispenser_search_level", ctypes.c_uint8), ("disable_intra_pred", ctypes.c_uint8),
+                ("tpl_opt_flag", ctypes.c_uint8), ("use_pred_sad_in_intra_search", ctypes.c_uint8),
+                ("use_pred_sad_in_inter_search", ctypes.c_uint8), ("enable_me_16x16", ctypes.c_uint8), ("n_pu", ctypes.c_uint8),
+                ("max_cand", ctypes.c_uint8), ("max_refs", ctypes.c_uint8), ("max_l0", ctypes.c_uint8),
+                ("n_ref", ctypes.c_uint8 * 2), ("reserved", ctypes.c_uint8 * 3),
+                ("total_me_candidate_index", ctypes.POINTER(ctypes.c_uint8)),
+                ("me_candidate_array", ctypes.POINTER(ctypes.c_uint8)),
+                ("me_mv_array", ctypes.POINTER(ctypes.c_uint32))]
+
+
+def make_picture(width, height, ctrl, me, cur_key=0, ref_keys=((), ()), ref_skip=None, i_slice=0, n_ref=None):
+    """ctrl: dict with dispenser_search_level, disable_intra_pred, tpl_opt_flag, use_pred_sad_in_intra_search,
+    use_pred_sad_in_inter_search; me: dict with total_me_candidate_index [n_b64, n_pu] u8, me_candidate_array
+    [n_b64, n_pu * max_cand] u8, me_mv_array [n_b64, n_pu * max_refs] u32, enable_me_16x16, max_cand, max_refs, max_l0.
+    Returns (TplPicture, keep-alive tuple)."""
+    cnt = np.ascontiguousarray(me["total_me_candidate_index"], np.uint8)
+    cand = np.ascontiguousarray(me["me_candidate_array"], np.uint8)
+    mv = np.ascontiguousarray(me["me_mv_array"], np.uint32)
+    n_pu = cnt.shape[1]
+    assert cand.shape[1] == n_pu * me["max_cand"] and mv.shape[1] == n_pu * me["max_refs"]
+    p = TplPicture()
+    p.cur_key = cur_key
+    for l in range(2):
+        for r in range(4):
+            p.ref_key[l][r] = ref_keys[l][r] if r < len(ref_keys[l]) else 0
+            p.ref_skip[l][r] = int(ref_skip[l][r]) if ref_skip is not None else 0
+    p.width, p.height, p.i_slice = width, height, i_slice
+    p.n_ref[0], p.n_ref[1] = n_ref if n_ref is not None else (len(ref_keys[0]), len(ref_keys[1]))
+    for k in ("dispenser_search_level", "disable_intra_pred", "tpl_opt_flag", "use_pred_sad_in_intra_search",
+              "use_pred_sad_in_inter_search"):
+        setattr(p, k, int(ctrl[k]))
+    p.enable_me_16x16, p.n_pu = int(me["enable_me_16x16"]), n_pu
+    p.max_cand, p.max_refs, p.max_l0 = int(me["max_cand"]), int(me["max_refs"]), int(me["max_l0"])
+    p.total_me_candidate_index = cnt.ctypes.data_as(ctypes.POINTER(ctypes.c_uint8))
+    p.me_candidate_array = cand.ctypes.data_as(ctypes.POINTER(ctypes.c_uint8))
+    p.me_mv_array = mv.ctypes.data_as(ctypes.POINTER(ctypes.c_uint32))
+    return p, (cnt, cand, mv)
+
+
+_lib = None
+
+
+def oracle_search(cur, refs, pic):
+    """cur: uint8 [h, w]; refs: {(list, ref): uint8 [h, w]}; pic: TplPicture. Returns TPL_BLOCK records [n_b64, 21]."""
+    global _lib
+    if _lib is None:
+        _lib = ctypes.CDLL(ORACLE_LIB)
+    h, w = cur.shape
+    cur = np.ascontiguousarray(cur, np.uint8)
+    keep = {k: np.ascontiguousarray(v, np.uint8) for k, v in refs.items()}
+    ptrs = (ctypes.POINTER(ctypes.c_uint8) * 8)()
+    for (l, r), a in keep.items():
+        assert a.shape == cur.shape
+        ptrs[l * 4 + r] = a.ctypes.data_as(ctypes.POINTER(ctypes.c_uint8))
+    n_b64 = ((w + 63) // 64) * ((h + 63) // 64)
+    out = np.zeros((n_b64, TPL_BLOCKS), TPL_BLOCK)
+    rc = _lib.orc_tpl_search(cur.ctypes.data_as(ctypes.POINTER(ctypes.c_uint8)), w, ptrs, ctypes.byref(pic),
+                             out.ctypes.data_as(ctypes.c_void_p))
+    if rc != 0:
+        raise RuntimeError("orc_tpl_search: %d" % rc)
+    return out
+
+
+def me_inputs_of(pd, bd):
+    """The ME results a reference dump holds (refio.PIC_DUMP record, refio.B64_DUMP records) in the shape make_picture takes."""
+    return dict(total_me_candidate_index=bd["total_me_candidate_index"].copy(),
+                me_candidate_array=bd["me_candidate_array"][:, :85 * int(pd["max_cand"])].copy(),
+                me_mv_array=bd["me_mv_array"][:, :85 * int(pd["max_refs"])].copy(),
+                enable_me_16x16=int(pd["enable_me_16x16"]), max_cand=int(pd["max_cand"]), max_refs=int(pd["max_refs"]),
+                max_l0=int(pd["max_l0"]))
+
+
+def controls_of(tp):
+    """refio.TPL_PIC_DUMP record -> the control dict make_picture takes."""
+    return {k: int(tp[k]) for k in ("dispenser_search_level", "disable_intra_pred", "tpl_opt_flag",
+                                    "use_pred_sad_in_intra_search", "use_pred_sad_in_inter_search")}
+
+
+def expected_from_reference(tb, ctrl):
+    """What the reference's dump (refio.TPL_BLK_DUMP records [n_b64, 21]) says the search found, as TPL_BLOCK records: the
+    costs come from the recorded cost calls (the intra cost first when intra prediction is on, then one per candidate)."""
+    out = np.zeros(tb.shape, TPL_BLOCK)
+    out["valid"] = tb["valid"]
+    v = tb["valid"] == 1
+    n_intra = 0 if ctrl["disable_intra_pred"] else 1
+    costs = tb["costs"].astype(np.int64)
+    k = np.arange(costs.shape[-1])
+    inter_mask = (k >= n_intra) & (k < tb["n_costs"][..., None])
+    inter = np.where(inter_mask, costs, INT64_MAX).min(axis=-1)
+    out["best_inter_cost"] = np.where(v, inter, 0)
+    out["best_intra_cost"] = np.where(v, costs[..., 0] if n_intra else INT64_MAX, 0)
+    out["best_rf_idx"] = np.where(v, tb["best_rf_idx"], 0)
+    out["mv_x"] = np.where(v, tb["mv_col"], 0)
+    out["mv_y"] = np.where(v, tb["mv_row"], 0)
+    out["best_is_inter"] = np.where(v, tb["best_mode"] != 0, 0)
+    out["best_intra_mode"] = np.where(v, tb["best_intra_mode"], 0)
+    return out

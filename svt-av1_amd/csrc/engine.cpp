@@ -130,6 +130,9 @@ struct GmState {
         int      level = 0;
     } cached[2]; // whose corners d_corners[i] holds
     int last_used = 1;
+    // svtme_tpl_search: the caller's ME results and the block records, device and pinned host copies (first call allocates)
+    uint8_t *d_tpl = nullptr, *h_tpl = nullptr;
+    size_t   tpl_bytes = 0;
 };
 constexpr size_t kGmCornerInts = 2 + 2 * (size_t)SVTME_GM_MAX_CORNERS, kGmMatchInts = 5 * (size_t)SVTME_GM_MAX_CORNERS;
 
@@ -350,10 +353,11 @@ extern "C" void svtme_destroy(svtme_engine *e) {
     if (e->h_params) (void)hipHostFree(e->h_params);
     {
         GmState &g = e->gm;
-        void    *dev[] = {g.d_score, g.d_keep, g.d_rows, g.d_corners[0], g.d_corners[1], g.d_match, g.d_block_err, g.d_result, g.d_filter, g.d_lut};
+        void    *dev[] = {g.d_score, g.d_keep, g.d_rows, g.d_corners[0], g.d_corners[1], g.d_match, g.d_block_err, g.d_result, g.d_filter, g.d_lut, g.d_tpl};
         for (void *d : dev)
             if (d) (void)hipFree(d);
         if (g.h_buf) (void)hipHostFree(g.h_buf);
+        if (g.h_tpl) (void)hipHostFree(g.h_tpl);
     }
     for (auto sm : e->s_me)
         if (sm) (void)hipStreamDestroy(sm);
@@ -1034,10 +1038,11 @@ int gm_init(svtme_engine *e) { // e->gm.mu held, device current
 // The planes of `n` keys at a downsample level, held against release for the duration of a call.
 struct GmPlanes {
     svtme_engine *e;
-    int           n = 0, slot[2] = {-1, -1};
-    DevPlane      plane[2];
-    hipEvent_t    ready[2];
-    uint64_t      gen[2];
+    static constexpr int kMax = 1 + SVTME_MAX_LISTS * SVTME_MAX_REFS;
+    int           n = 0, slot[kMax];
+    DevPlane      plane[kMax];
+    hipEvent_t    ready[kMax];
+    uint64_t      gen[kMax];
     explicit GmPlanes(svtme_engine *e_) : e(e_) {}
     int take(const uint64_t *keys, int count, int level) {
         std::lock_guard<std::mutex> lock(e->mu);
@@ -1201,6 +1206,88 @@ extern "C" int svtme_gm_warp_error(svtme_engine *e, uint64_t cur_key, uint64_t r
 
 extern "C" int svtme_gm_frame_error(svtme_engine *e, uint64_t cur_key, uint64_t ref_key, int downsample_level, int64_t *error) {
     return gm_error(e, cur_key, ref_key, downsample_level, nullptr, INT64_MAX, error);
+}
+
+// ---- TPL dispenser: source-based mode search
+extern "C" int svtme_tpl_search(svtme_engine *e, const svtme_tpl_picture *pic, svtme_tpl_block *out) {
+    if (!e || !pic || !out || !pic->total_me_candidate_index || !pic->me_candidate_array || !pic->me_mv_array) return SVTME_ERR_BAD_ARG;
+    if (pic->width < 64 || pic->height < 64 || pic->width > e->cfg.max_width || pic->height > e->cfg.max_height || pic->width % 8 ||
+        pic->height % 8 || pic->dispenser_search_level > 2 || pic->n_ref[0] > SVTME_MAX_REFS || pic->n_ref[1] > SVTME_MAX_REFS ||
+        (pic->n_pu != SVTME_PU_COUNT && pic->n_pu != 21) || pic->max_cand == 0 || pic->max_refs == 0 ||
+        pic->max_l0 + (pic->n_ref[1] ? pic->n_ref[1] : 0) > pic->max_refs || pic->n_ref[0] > pic->max_l0)
+        return SVTME_ERR_BAD_ARG;
+    // transform-domain costs and the intra modes beyond DC are not on the device
+    if (!pic->tpl_opt_flag || !pic->use_pred_sad_in_intra_search || !pic->use_pred_sad_in_inter_search) return SVTME_ERR_UNSUPPORTED;
+    DEVICE_OR_FAIL(e->cfg.device);
+    std::lock_guard<std::mutex> gm_lock(e->gm.mu);
+    GmState  &g = e->gm;
+    const int b64_w = (int)(pic->width + 63) / 64, n_b64 = b64_w * ((int)(pic->height + 63) / 64);
+    const size_t cnt_bytes = (size_t)n_b64 * pic->n_pu, cand_bytes = cnt_bytes * pic->max_cand, mv_bytes = cnt_bytes * pic->max_refs * 4;
+    const size_t mv_off = (cnt_bytes + cand_bytes + 63) / 64 * 64, out_off = (mv_off + mv_bytes + 63) / 64 * 64;
+    const size_t out_bytes = (size_t)n_b64 * SVTME_TPL_BLOCKS * sizeof(svtme_tpl_block), err_off = out_off + out_bytes, total = err_off + 64;
+    if (g.tpl_bytes < total) {
+        if (g.d_tpl) (void)hipFree(g.d_tpl);
+        if (g.h_tpl) (void)hipHostFree(g.h_tpl);
+        g.d_tpl = g.h_tpl = nullptr;
+        g.tpl_bytes = 0;
+        if (hipMalloc((void **)&g.d_tpl, total) != hipSuccess || hipHostMalloc((void **)&g.h_tpl, total, hipHostMallocDefault) != hipSuccess) {
+            (void)hipGetLastError();
+            return SVTME_ERR_NO_RESOURCES;
+        }
+        g.tpl_bytes = total;
+    }
+    GmPlanes pl(e);
+    uint64_t keys[GmPlanes::kMax];
+    int      n_keys = 0;
+    keys[n_keys++]  = pic->cur_key;
+    for (int l = 0; l < SVTME_MAX_LISTS; ++l)
+        for (int r = 0; r < pic->n_ref[l]; ++r) keys[n_keys++] = pic->ref_key[l][r];
+    if (const int rc = pl.take(keys, n_keys, 0)) return rc;
+    TplParams p;
+    memset(&p, 0, sizeof(p));
+    p.cur = pl.plane[0];
+    if (p.cur.width != (int)pic->width || p.cur.height != (int)pic->height) return SVTME_ERR_BAD_ARG;
+    for (int l = 0, k = 1; l < SVTME_MAX_LISTS; ++l)
+        for (int r = 0; r < pic->n_ref[l]; ++r, ++k) {
+            if (pl.plane[k].width != p.cur.width || pl.plane[k].height != p.cur.height) return SVTME_ERR_BAD_ARG;
+            p.ref[l][r]      = pl.plane[k];
+            p.ref_skip[l][r] = pic->ref_skip[l][r];
+        }
+    p.n_ref[0] = pic->n_ref[0];
+    p.n_ref[1] = pic->n_ref[1];
+    p.width = (int)pic->width;
+    p.height = (int)pic->height;
+    p.b64_w = b64_w;
+    p.n_b64 = n_b64;
+    p.level = pic->dispenser_search_level;
+    p.disable_intra_pred = pic->disable_intra_pred;
+    p.i_slice = pic->i_slice;
+    p.enable_me_16x16 = pic->enable_me_16x16;
+    p.n_pu = pic->n_pu;
+    p.max_cand = pic->max_cand;
+    p.max_refs = pic->max_refs;
+    p.max_l0 = pic->max_l0;
+    p.cnt   = g.d_tpl;
+    p.cand  = g.d_tpl + cnt_bytes;
+    p.mv    = reinterpret_cast<const uint32_t *>(g.d_tpl + mv_off);
+    p.out   = reinterpret_cast<svtme_tpl_block *>(g.d_tpl + out_off);
+    p.error = reinterpret_cast<int *>(g.d_tpl + err_off);
+    memcpy(g.h_tpl, pic->total_me_candidate_index, cnt_bytes);
+    memcpy(g.h_tpl + cnt_bytes, pic->me_candidate_array, cand_bytes);
+    memcpy(g.h_tpl + mv_off, pic->me_mv_array, mv_bytes);
+    const hipStream_t st = e->s_me[3];
+    for (int k = 0; k < n_keys; ++k) GM_TRY(hipStreamWaitEvent(st, pl.ready[k], 0));
+    GM_TRY(hipMemcpyAsync(g.d_tpl, g.h_tpl, mv_off + mv_bytes, hipMemcpyHostToDevice, st));
+    GM_TRY(hipMemsetAsync(g.d_tpl + out_off, 0, out_bytes + 64, st));
+    launch_tpl_search(p, st);
+    GM_TRY(hipGetLastError());
+    GM_TRY(hipMemcpyAsync(g.h_tpl + out_off, g.d_tpl + out_off, out_bytes + 64, hipMemcpyDeviceToHost, st));
+    GM_TRY(hipStreamSynchronize(st));
+    int err;
+    memcpy(&err, g.h_tpl + err_off, sizeof(err));
+    if (err) return SVTME_ERR_BAD_ARG;
+    memcpy(out, g.h_tpl + out_off, out_bytes);
+    return SVTME_OK;
 }
 
 // Diagnostic, not part of the public header: resident workgroups per CU of {hme_l0, hme_l12, me_search}.

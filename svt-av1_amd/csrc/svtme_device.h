@@ -162,6 +162,23 @@ void launch_gm_match(const DevPlane &frm, const DevPlane &ref, const int *frm_co
 void launch_gm_error(const DevPlane &frm, const DevPlane &ref, const svtme_gm_warp *wm, const int16_t *filter, const int32_t *lut,
                      uint32_t *block_err, long long best_error, long long *result, hipStream_t s);
 
+// TPL dispenser, source-based mode search (tpl_kernels.hip): the planes and the ME results of one picture
+struct TplParams {
+    DevPlane cur; // full-resolution planes
+    DevPlane ref[SVTME_MAX_LISTS][SVTME_MAX_REFS];
+    uint8_t  ref_skip[SVTME_MAX_LISTS][SVTME_MAX_REFS];
+    int32_t  n_ref[SVTME_MAX_LISTS];
+    int32_t  width, height, b64_w, n_b64;
+    int32_t  level, disable_intra_pred, i_slice, enable_me_16x16; // svtme_tpl_picture's fields
+    int32_t  n_pu, max_cand, max_refs, max_l0;
+    const uint8_t  *cnt; // [n_b64][n_pu]
+    const uint8_t  *cand; // [n_b64][n_pu * max_cand]
+    const uint32_t *mv; // [n_b64][n_pu * max_refs]
+    svtme_tpl_block *out; // [n_b64][SVTME_TPL_BLOCKS], zeroed
+    int             *error; // bit 0: a candidate named a reference beyond n_ref
+};
+void launch_tpl_search(const TplParams &p, hipStream_t s);
+
 int  occupancy_me_search();
 void occupancy_hme_items(int out[2]);
 

@@ -119,9 +119,28 @@ EXPORTS = ("svtme_version", "svtme_derive_controls", "svtme_derive_tf_controls",
            "svtme_host_unregister", "svtme_host_alloc", "svtme_host_free", "svtme_pictures_submit",
            "svtme_group_create", "svtme_group_destroy", "svtme_group_size", "svtme_group_store_put", "svtme_group_store_release",
            "svtme_group_picture_submit", "svtme_group_picture_wait", "svtme_group_picture_done", "svtme_group_stats",
-           "svtme_gm_set_tables", "svtme_gm_corners", "svtme_gm_correspondences", "svtme_gm_warp_error", "svtme_gm_frame_error")
+           "svtme_gm_set_tables", "svtme_gm_corners", "svtme_gm_correspondences", "svtme_gm_warp_error", "svtme_gm_frame_error",
+           "svtme_tpl_search")
 MAX_BATCH = 32
 GM_MAX_CORNERS = 4096
+
+
+TPL_BLOCKS = 21
+TPL_BLOCK = np.dtype([("best_intra_cost", "<i8"), ("best_inter_cost", "<i8"), ("mv_x", "<i2"), ("mv_y", "<i2"),
+                      ("best_rf_idx", "i1"), ("best_is_inter", "u1"), ("best_intra_mode", "u1"), ("valid", "u1")])
+
+
+class TplPicture(C.Structure):
+    """svtme_tpl_picture"""
+    _fields_ = [("cur_key", C.c_uint64), ("ref_key", (C.c_uint64 * MAX_REFS) * MAX_LISTS), ("ref_skip", (C.c_uint8 * MAX_REFS) * MAX_LISTS),
+                ("width", C.c_uint32), ("height", C.c_uint32),
+                ("i_slice", C.c_uint8), ("dispenser_search_level", C.c_uint8), ("disable_intra_pred", C.c_uint8),
+                ("tpl_opt_flag", C.c_uint8), ("use_pred_sad_in_intra_search", C.c_uint8),
+                ("use_pred_sad_in_inter_search", C.c_uint8), ("enable_me_16x16", C.c_uint8), ("n_pu", C.c_uint8),
+                ("max_cand", C.c_uint8), ("max_refs", C.c_uint8), ("max_l0", C.c_uint8),
+                ("n_ref", C.c_uint8 * MAX_LISTS), ("reserved", C.c_uint8 * 3),
+                ("total_me_candidate_index", C.POINTER(C.c_uint8)), ("me_candidate_array", C.POINTER(C.c_uint8)),
+                ("me_mv_array", C.POINTER(C.c_uint32))]
 
 
 class GmWarp(C.Structure):
@@ -187,6 +206,7 @@ def load_library():
     lib.svtme_gm_correspondences.argtypes = [C.c_void_p, C.c_uint64, C.c_uint64, C.c_int, C.c_void_p, C.POINTER(C.c_int32)]
     lib.svtme_gm_warp_error.argtypes = [C.c_void_p, C.c_uint64, C.c_uint64, C.c_int, C.POINTER(GmWarp), C.c_int64, C.POINTER(C.c_int64)]
     lib.svtme_gm_frame_error.argtypes = [C.c_void_p, C.c_uint64, C.c_uint64, C.c_int, C.POINTER(C.c_int64)]
+    lib.svtme_tpl_search.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
     _lib = lib
     return lib
 
@@ -518,6 +538,15 @@ class Engine:
         if rc:
             raise SvtmeError(rc, "svtme_gm_frame_error")
         return err.value
+
+    def tpl_search(self, pic):
+        """pic: a TplPicture (or any ctypes structure of that layout). Returns TPL_BLOCK records [n_b64, 21]."""
+        n_b64 = ((pic.width + 63) // 64) * ((pic.height + 63) // 64)
+        out = np.zeros((n_b64, TPL_BLOCKS), TPL_BLOCK)
+        rc = self.lib.svtme_tpl_search(self.h, C.addressof(pic), out.ctypes.data)
+        if rc:
+            raise SvtmeError(rc, "svtme_tpl_search")
+        return out
 
     def timing(self, ticket):
         ms = (C.c_float * 8)()

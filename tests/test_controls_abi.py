@@ -47,6 +47,7 @@ def test_bad_arguments_are_rejected_without_touching_a_device():
     assert lib.svtme_derive_controls(C.byref(key), C.byref(c)) == svtme.ERR_BAD_ARG
     assert lib.svtme_store_release(None, 1) == svtme.ERR_BAD_ARG
     assert lib.svtme_unpack_b64(None, 0, None, None, None, None, None) == svtme.ERR_BAD_ARG
+    assert lib.svtme_tpl_search(None, None, None) == svtme.ERR_BAD_ARG
 
 
 def test_engine_creation_fails_loudly_without_a_gpu():
@@ -166,6 +167,8 @@ int main(void) {
     printf("%zu %zu %zu %zu %zu %zu\\n", offsetof(svtme_picture, ref_key), offsetof(svtme_picture, ctrl),
            offsetof(svtme_picture, tail), offsetof(svtme_picture, tf_me_exit_th), offsetof(svtme_results, n_ref),
            offsetof(svtme_search_result, hme_sad));
+    printf("%zu %zu %zu %zu %zu %zu\\n", sizeof(svtme_tpl_picture), sizeof(svtme_tpl_block), offsetof(svtme_tpl_picture, width),
+           offsetof(svtme_tpl_picture, n_ref), offsetof(svtme_tpl_picture, me_mv_array), offsetof(svtme_tpl_block, best_rf_idx));
     return 0;
 }
 ''')
@@ -177,5 +180,7 @@ int main(void) {
     want = [C.sizeof(svtme.Controls), C.sizeof(svtme.Picture), C.sizeof(svtme.Tail), C.sizeof(svtme.SearchResult),
             C.sizeof(svtme.Results), C.sizeof(svtme.Config), C.sizeof(svtme.PresetKey), C.sizeof(svtme.SaMinMax),
             svtme.Picture.ref_key.offset, svtme.Picture.ctrl.offset, svtme.Picture.tail.offset,
-            svtme.Picture.tf_me_exit_th.offset, svtme.Results.n_ref.offset, svtme.SearchResult.hme_sad.offset]
+            svtme.Picture.tf_me_exit_th.offset, svtme.Results.n_ref.offset, svtme.SearchResult.hme_sad.offset,
+            C.sizeof(svtme.TplPicture), svtme.TPL_BLOCK.itemsize, svtme.TplPicture.width.offset, svtme.TplPicture.n_ref.offset,
+            svtme.TplPicture.me_mv_array.offset, svtme.TPL_BLOCK.fields["best_rf_idx"][1]]
     assert got == want, (got, want)

@@ -1,0 +1,156 @@
+"""The TPL dispenser's source-based mode search on the GPU engine (svtme_tpl_search, through the C ABI) against what the
+real reference computed (tests/golden/tpl_*.npz, tpl_digests.json) and against the CPU restatement on random ME results."""
+import hashlib
+import json
+import os
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+for _p in ("svt-av1_amd", "oracle", "tests"):
+    sys.path.insert(0, os.path.join(ROOT, _p))
+import refio  # noqa: E402
+import support  # noqa: E402
+import tpl_cases  # noqa: E402
+import tplio  # noqa: E402
+from test_tpl_oracle import assert_blocks_equal, load_case, picture_of  # noqa: E402
+
+pytestmark = pytest.mark.gpu
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+
+
+def _engine(frames):
+    import svtme
+    n, h, w = frames.shape
+    eng = svtme.Engine(w, h, store_slots=n + 1, max_in_flight=2)
+    for i in range(n):
+        eng.store_put(i + 1, i, frames[i])  # key = poc + 1, as picture_of numbers them
+    return eng
+
+
+@pytest.mark.parametrize("name", sorted(tpl_cases.CASES))
+def test_engine_reproduces_reference_tpl_search(name):
+    frames, pics, per = load_case(name, tpl_cases.CASES[name])
+    eng = _engine(frames)
+    try:
+        for pic, (ctrl, me, tb) in zip(pics, per):
+            p, keep, refs = picture_of(frames, pic, ctrl, me)
+            assert_blocks_equal(eng.tpl_search(p), tplio.expected_from_reference(tb, ctrl), "%s poc %d" % (name, pic.poc))
+    finally:
+        eng.close()
+
+
+def _random_me(rng, n_b64, n_pu, n_ref, max_mv):
+    """ME results no encoder would produce but the interface allows: any count, any mix of directions and references,
+    vectors far outside the picture."""
+    max_l0 = max(n_ref[0], 1)
+    max_refs = max_l0 + n_ref[1]
+    max_cand = int(rng.integers(1, 24))
+    cnt = rng.integers(0, max_cand + 1, (n_b64, n_pu)).astype(np.uint8)
+    direction = rng.integers(0, 3 if n_ref[1] else 1, (n_b64, n_pu * max_cand))
+    if n_ref[1] == 0:
+        direction[:] = 0
+    r0 = rng.integers(0, n_ref[0], direction.shape)
+    r1 = rng.integers(0, max(n_ref[1], 1), direction.shape)
+    cand = (direction | (r0 << 2) | (r1 << 4) | (1 << 7)).astype(np.uint8)
+    mv = rng.integers(-max_mv, max_mv + 1, (n_b64, n_pu * max_refs, 2)).astype(np.int16)
+    mv_u32 = (mv[..., 0].astype(np.uint16).astype(np.uint32)) | (mv[..., 1].astype(np.uint16).astype(np.uint32) << 16)
+    return dict(total_me_candidate_index=cnt, me_candidate_array=cand, me_mv_array=mv_u32,
+                enable_me_16x16=int(rng.integers(0, 2)), max_cand=max_cand, max_refs=max_refs, max_l0=max_l0)
+
+
+@pytest.mark.parametrize("seed", range(int(os.environ.get("SVTME_FUZZ_N", "12"))))
+def test_random_me_results_match_the_restatement(seed):
+    rng = np.random.default_rng(1000 + seed)
+    w, h = int(rng.integers(8, 50)) * 8, int(rng.integers(8, 36)) * 8
+    n_ref = (int(rng.integers(1, 5)), int(rng.integers(0, 4)))
+    n_frames = 1 + n_ref[0] + n_ref[1]
+    kind = ["synth", "noise", "flat"][int(rng.integers(0, 3))]
+    frames = support.make_job(w, h, n_frames, 8, seed=seed + 7, kind=kind)[0]
+    n_b64 = ((w + 63) // 64) * ((h + 63) // 64)
+    me = _random_me(rng, n_b64, [85, 21][int(rng.integers(0, 2))], n_ref, int(rng.choice([8, 64, 400, 2000])))
+    ctrl = dict(dispenser_search_level=int(rng.integers(0, 3)), disable_intra_pred=int(rng.integers(0, 2)), tpl_opt_flag=1,
+                use_pred_sad_in_intra_search=1, use_pred_sad_in_inter_search=1)
+    from svtme import gop
+    pic = gop.Picture(poc=0, temporal_layer=0, is_ref=1, refs=[list(range(1, 1 + n_ref[0])), list(range(1 + n_ref[0], n_frames))])
+    skip = rng.integers(0, 4, (2, 4)) == 0
+    p, keep, refs = picture_of(frames, pic, ctrl, me, ref_skip=skip, i_slice=int(rng.integers(0, 8) == 0))
+    eng = _engine(frames)
+    try:
+        got = eng.tpl_search(p)
+    finally:
+        eng.close()
+    exp = tplio.oracle_search(frames[0], refs, p)
+    assert_blocks_equal(got, exp, "seed %d %dx%d level %d" % (seed, w, h, ctrl["dispenser_search_level"]))
+    assert exp["valid"].sum() > 0
+
+
+def test_unsupported_controls_and_bad_arguments():
+    import svtme
+    frames, pics, per = load_case("tpl4_m8_200x136", tpl_cases.CASES["tpl4_m8_200x136"])
+    pic = next(p for p in pics if len(p.refs[1]) >= 1)
+    ctrl, me, tb = per[pics.index(pic)]
+    eng = _engine(frames)
+    try:
+        for off in ("tpl_opt_flag", "use_pred_sad_in_intra_search", "use_pred_sad_in_inter_search"):
+            p, keep, refs = picture_of(frames, pic, dict(ctrl, **{off: 0}), me)
+            with pytest.raises(svtme.SvtmeError) as ei:
+                eng.tpl_search(p)
+            assert ei.value.code == svtme.ERR_UNSUPPORTED
+        # a candidate of a reference that was not handed over
+        p, keep, refs = picture_of(frames, pic, ctrl, me, n_ref=(len(pic.refs[0]), 0))
+        with pytest.raises(svtme.SvtmeError) as ei:
+            eng.tpl_search(p)
+        assert ei.value.code == svtme.ERR_BAD_ARG
+        # a key the store does not hold; a picture size the store's planes do not have
+        p, keep, refs = picture_of(frames, pic, ctrl, me)
+        p.ref_key[0][0] = 9999
+        with pytest.raises(svtme.SvtmeError) as ei:
+            eng.tpl_search(p)
+        assert ei.value.code == svtme.ERR_NOT_FOUND
+        p, keep, refs = picture_of(frames, pic, ctrl, me)
+        p.height = 128
+        with pytest.raises(svtme.SvtmeError) as ei:
+            eng.tpl_search(p)
+        assert ei.value.code == svtme.ERR_BAD_ARG
+        # and the engine still works afterwards
+        p, keep, refs = picture_of(frames, pic, ctrl, me)
+        assert_blocks_equal(eng.tpl_search(p), tplio.expected_from_reference(tb, ctrl), "after the errors")
+    finally:
+        eng.close()
+
+
+def test_1080p_search_on_the_engines_own_me_results_equals_the_reference_digest():
+    """The whole chain on the device at the benchmark's size: open-loop ME with the device tail, whose candidate and vector
+    arrays (bit-exact with the reference's, test_gpu_parity) feed the TPL search; the digest is the real reference's."""
+    import svtme
+    name, c = next(iter(tpl_cases.DIGEST_CASES.items()))
+    want = json.load(open(os.path.join(GOLDEN, "tpl_digests.json")))[name]
+    frames, pics, rc = support.make_job(**tpl_cases.job_args(c))
+    shape = want["me_shape"]
+    tail = svtme.Tail(enable=1, enable_me_8x8=shape["enable_me_8x8"], enable_me_16x16=shape["enable_me_16x16"],
+                      max_refs=shape["max_refs"], max_cand=shape["max_cand"], max_l0=shape["max_l0"],
+                      input_resolution=shape["input_resolution"], gm_enabled=1, gm_use_distance_based_active_th=1)
+    n, h, w = frames.shape
+    eng = svtme.Engine(w, h, store_slots=n + 2, max_in_flight=2)
+    try:
+        for i in range(n):
+            eng.store_put(i + 1, i, frames[i])
+        ctrl_me = svtme.derive_controls(c["enc_mode"], w, h, 0, 30 << 16)
+        hsh = hashlib.sha256()
+        for pic, ctrl in zip(pics, want["controls"]):
+            desc = eng.make_picture(w, h, pic.poc, pic.temporal_layer, pic.is_ref, pic.refs, ctrl_me, tail=tail, key_of=lambda poc: poc + 1)
+            out = eng.run_picture(desc)
+            me = dict(total_me_candidate_index=out["total_me_candidate_index"],
+                      me_candidate_array=out["me_candidate_array"][:, :85 * shape["max_cand"]],
+                      me_mv_array=out["me_mv_array"][:, :85 * shape["max_refs"]], enable_me_16x16=shape["enable_me_16x16"],
+                      max_cand=shape["max_cand"], max_refs=shape["max_refs"], max_l0=shape["max_l0"])
+            p, keep, refs = picture_of(frames, pic, ctrl, me)
+            got = eng.tpl_search(p)
+            for f in tpl_cases.SEARCH_FIELDS:
+                hsh.update(np.ascontiguousarray(got[f]).tobytes())
+        assert hsh.hexdigest() == want["sha256"]
+    finally:
+        eng.close()
