@@ -42,6 +42,9 @@
 #include "EbEncodeContext.h"
 #include "EbModeDecisionProcess.h" /* quantizer_to_qindex */
 #include "EbUtility.h" /* get_coded_blk_stats */
+#include "EbCoefficients.h" /* av1_scan_orders */
+#include "EbInvTransforms.h" /* txsize_to_bsize */
+#include "EbTransforms.h" /* svt_av1_wht_fwd_txfm */
 
 #include "../include/svtme.h"
 #include "ref_dump.h"
@@ -473,6 +476,7 @@ typedef struct Shim {
     int (*wait)(svtme_engine *, svtme_ticket, svtme_results *);
     int (*done)(svtme_engine *, svtme_ticket);
     int (*unpack)(const svtme_results *, uint32_t, uint32_t *, uint32_t *, svtme_search_result *, uint32_t *, uint32_t *);
+    int (*tpl_search)(svtme_engine *, const svtme_tpl_picture *, svtme_tpl_block *);
 } Shim;
 
 static void *shim_sym(Shim *s, const char *name) {
@@ -498,6 +502,7 @@ static void shim_open(Shim *s, const char *lib, const Job *job) {
     *(void **)&s->wait      = shim_sym(s, "svtme_picture_wait");
     *(void **)&s->done      = shim_sym(s, "svtme_picture_done");
     *(void **)&s->unpack    = shim_sym(s, "svtme_unpack_b64");
+    *(void **)&s->tpl_search = shim_sym(s, "svtme_tpl_search");
     svtme_config cfg;
     memset(&cfg, 0, sizeof(cfg));
     cfg.max_width     = job->hdr.width;
@@ -809,9 +814,122 @@ static void tpl_free(PicState *st, TplState *t) {
     g_tpl.n = NULL; g_tpl.costs = NULL;
 }
 
-static void run_pic_tpl(const Job *job, uint32_t pi, PicState *st, FILE *o) {
+
+/* REF_MODE_TPL with the engine: what a patched dispenser does with svtme_tpl_search's answers. The search of :634-933 is
+ * the engine's; the encoder keeps :935-992 (transform and quantisation of the best inter candidate for srcrf_dist) and
+ * leaves the block's source-based results where the reference itself keeps them between TPL groups
+ * (tpl_src_stats_buffer, :983-992), so that the unmodified dispenser, run with tpl_src_data_ready = 1, takes them from
+ * there (:993-1002) and does its reconstruction path. */
+static const uint8_t k_tpl_me_idx[21] = {0, 1, 2, 3, 4, 5, 6, 9, 10, 7, 8, 11, 12, 13, 14, 17, 18, 15, 16, 19, 20};
+static const TxSize  k_tpl_tx[3][3]   = {{TX_16X16, TX_32X32, TX_64X64}, {TX_16X8, TX_32X16, TX_64X32}, {TX_16X4, TX_32X8, TX_64X16}}; /* :543-545 */
+
+static void tpl_fill_from_engine(Shim *s, const Job *job, uint32_t pi, PicState *st, TplState *t) {
+    const ref_job_pic       *jp  = &job->pics[pi];
+    PictureParentControlSet *pcs = st->pcs;
+    SequenceControlSet      *scs = st->scs;
+    const TplControls       *tc  = &pcs->tpl_ctrls;
+    MotionEstimationData    *md  = pcs->pa_me_data;
+    const uint32_t           n_pu = SQUARE_PU_COUNT;
+
+    /* the picture's ME results, one 64x64 block after the other, as svtme_tpl_search reads them */
+    uint8_t  *cnt  = (uint8_t *)calloc((size_t)st->n_b64 * n_pu, 1);
+    uint8_t  *cand = (uint8_t *)calloc((size_t)st->n_b64 * n_pu * md->max_cand, 1);
+    uint32_t *mv   = (uint32_t *)calloc((size_t)st->n_b64 * n_pu * md->max_refs, 4);
+    for (uint32_t b = 0; b < st->n_b64; ++b) {
+        const MeSbResults *r = md->me_results[b];
+        memcpy(cnt + (size_t)b * n_pu, r->total_me_candidate_index, n_pu);
+        memcpy(cand + (size_t)b * n_pu * md->max_cand, r->me_candidate_array, (size_t)n_pu * md->max_cand);
+        memcpy(mv + (size_t)b * n_pu * md->max_refs, r->me_mv_array, (size_t)n_pu * md->max_refs * 4);
+    }
+    svtme_tpl_picture d;
+    memset(&d, 0, sizeof(d));
+    d.cur_key = (uint64_t)(uintptr_t)&job->planes[jp->cur_frame];
+    d.width   = pcs->enhanced_picture_ptr->width;
+    d.height  = pcs->enhanced_picture_ptr->height;
+    d.n_ref[0] = pcs->tpl_data.tpl_ref0_count;
+    d.n_ref[1] = pcs->tpl_data.tpl_ref1_count;
+    for (int l = 0; l < 2; ++l)
+        for (int r = 0; r < d.n_ref[l]; ++r) {
+            d.ref_key[l][r] = (uint64_t)(uintptr_t)&job->planes[jp->ref_frame[l][r]];
+            const int32_t g = pcs->tpl_data.ref_tpl_group_idx[l][r];
+            d.ref_skip[l][r] = g > 0 && pcs->tpl_data.base_pcs->tpl_valid_pic[g] == 0; /* :846-849 */
+        }
+    d.i_slice                      = pcs->slice_type == I_SLICE;
+    d.dispenser_search_level       = tc->dispenser_search_level;
+    d.disable_intra_pred           = tc->disable_intra_pred_nref && pcs->tpl_data.is_used_as_reference_flag == 0;
+    d.tpl_opt_flag                 = tc->tpl_opt_flag;
+    d.use_pred_sad_in_intra_search = tc->use_pred_sad_in_intra_search;
+    d.use_pred_sad_in_inter_search = tc->use_pred_sad_in_inter_search;
+    d.enable_me_16x16              = pcs->enable_me_16x16;
+    d.n_pu     = (uint8_t)n_pu;
+    d.max_cand = md->max_cand;
+    d.max_refs = md->max_refs;
+    d.max_l0   = md->max_l0;
+    d.total_me_candidate_index = cnt;
+    d.me_candidate_array       = cand;
+    d.me_mv_array              = mv;
+    svtme_tpl_block *blk = (svtme_tpl_block *)calloc((size_t)st->n_b64 * SVTME_TPL_BLOCKS, sizeof(*blk));
+    if (s->tpl_search(s->engine, &d, blk) != SVTME_OK) die("svtme_tpl_search failed");
+
+    MacroblockPlane mbp; /* :579-586 */
+    mbp.quant_qtx = scs->quants_8bit.y_quant[t->qindex];       mbp.quant_fp_qtx = scs->quants_8bit.y_quant_fp[t->qindex];
+    mbp.round_fp_qtx = scs->quants_8bit.y_round_fp[t->qindex]; mbp.quant_shift_qtx = scs->quants_8bit.y_quant_shift[t->qindex];
+    mbp.zbin_qtx = scs->quants_8bit.y_zbin[t->qindex];         mbp.round_qtx = scs->quants_8bit.y_round[t->qindex];
+    mbp.dequant_qtx = scs->deq_8bit.y_dequant_qtx[t->qindex];
+    const EbPictureBufferDesc *in = pcs->enhanced_picture_ptr;
+    static int16_t src_diff[64 * 64];
+    static TranLow coeff[64 * 64], qcoeff[64 * 64], dqcoeff[64 * 64];
+    for (uint32_t b = 0; b < st->n_b64; ++b) {
+        const SbParams *sp    = &pcs->sb_params_array[b];
+        const int       level = (sp->width == 64 && sp->height == 64) ? tc->dispenser_search_level : 0;
+        const uint32_t  size  = 16u << level;
+        const TxSize    tx    = k_tpl_tx[tc->subsample_tx][level];
+        for (int bi = 0; bi < SVTME_TPL_BLOCKS; ++bi) {
+            const svtme_tpl_block *e = &blk[(size_t)b * SVTME_TPL_BLOCKS + bi];
+            if (!e->valid) continue;
+            const CodedBlockStats *bs = get_coded_blk_stats(k_tpl_blk_cu[bi]);
+            const uint32_t x = sp->origin_x + bs->origin_x, y = sp->origin_y + bs->origin_y;
+            TplSrcStats   *ss = &md->tpl_src_stats_buffer[(y >> 4) * t->w16 + (x >> 4)];
+            memset(ss, 0, sizeof(*ss));
+            ss->best_rf_idx     = e->best_rf_idx;
+            ss->mv.row          = e->mv_y;
+            ss->mv.col          = e->mv_x;
+            ss->best_mode       = e->best_is_inter ? NEWMV : DC_PRED;
+            ss->best_intra_mode = (PredictionMode)e->best_intra_mode;
+            if (e->best_rf_idx >= 0) {
+                const int l = e->best_rf_idx < 4 ? 0 : 1, r = e->best_rf_idx >= 4 ? e->best_rf_idx - 4 : e->best_rf_idx;
+                ss->ref_frame_poc = pcs->tpl_data.tpl_ref_ds_ptr_array[l][r].picture_number;
+                if (e->best_is_inter) { /* :935-982 with use_pred_sad_in_inter_search */
+                    const EbPictureBufferDesc *rp = pcs->tpl_data.tpl_ref_ds_ptr_array[l][r].picture_ptr;
+                    const uint8_t *src_mb = in->buffer_y + in->origin_x + x + (size_t)(in->origin_y + y) * in->stride_y;
+                    const int32_t  ro = (int32_t)rp->origin_x + ((int32_t)x + (e->mv_x >> 3)) +
+                        ((int32_t)y + (e->mv_y >> 3) + (int32_t)rp->origin_y) * (int32_t)rp->stride_y;
+                    svt_aom_subtract_block(size >> tc->subsample_tx, size, src_diff, size << tc->subsample_tx, src_mb,
+                                           in->stride_y << tc->subsample_tx, rp->buffer_y + ro, rp->stride_y << tc->subsample_tx);
+                    svt_av1_wht_fwd_txfm(src_diff, size << tc->subsample_tx, coeff, tx, tc->tpl_opt_flag ? tc->pf_shape : DEFAULT_SHAPE, 8, 0);
+                    /* get_quantize_error, :167-193 */
+                    const ScanOrder *so = &av1_scan_orders[tx][DCT_DCT];
+                    const int pix_num = 1 << num_pels_log2_lookup[txsize_to_bsize[tx]], shift = tx == TX_32X32 ? 0 : 2;
+                    uint16_t  eob = 0;
+                    int64_t   sse;
+                    svt_av1_quantize_fp(coeff, pix_num, mbp.zbin_qtx, mbp.round_fp_qtx, mbp.quant_fp_qtx, mbp.quant_shift_qtx, qcoeff, dqcoeff,
+                                        mbp.dequant_qtx, &eob, so->scan, so->iscan);
+                    int64_t recon_error = svt_av1_block_error(coeff, dqcoeff, pix_num, &sse) >> shift;
+                    if (recon_error < 1) recon_error = 1;
+                    ss->srcrf_rate = 0; /* tpl_opt_flag: no rate (:975-979) */
+                    ss->srcrf_dist = (recon_error << TPL_DEP_COST_SCALE_LOG2) << tc->subsample_tx;
+                }
+            }
+        }
+    }
+    pcs->tpl_src_data_ready = 1;
+    free(blk); free(cnt); free(cand); free(mv);
+}
+
+static void run_pic_tpl(const Job *job, uint32_t pi, PicState *st, FILE *o, Shim *shim) {
     TplState t;
     tpl_setup(job, pi, st, &t);
+    if (shim) tpl_fill_from_engine(shim, job, pi, st, &t);
     for (uint32_t sb = 0; sb < st->n_b64; ++sb) {
         const SbParams *sp = &st->scs->sb_params_array[sb];
         tpl_mc_flow_dispenser_sb_generic(t.enc, st->scs, st->pcs, 0, sb, t.qindex,
@@ -922,6 +1040,11 @@ int main(int argc, char **argv) {
         g_tpl.sad      = svt_nxm_sad_kernel_sub_sampled;
         g_tpl.satd     = svt_aom_satd;
         g_tpl.subtract = svt_aom_subtract_block;
+        Shim shim, *use_shim = NULL;
+        if (argc >= 4) { /* the source-based search from the GPU engine */
+            shim_open(&shim, argv[3], &job);
+            use_shim = &shim;
+        }
         fwrite(&oh, sizeof(oh), 1, o);
         for (uint32_t pi = 0; pi < job.hdr.n_pics; ++pi) {
             PicState st;
@@ -932,12 +1055,13 @@ int main(int argc, char **argv) {
             svt_nxm_sad_kernel_sub_sampled = tpl_rec_sad;
             svt_aom_satd                   = tpl_rec_satd;
             svt_aom_subtract_block         = tpl_rec_subtract;
-            run_pic_tpl(&job, pi, &st, o);
+            run_pic_tpl(&job, pi, &st, o, use_shim);
             svt_nxm_sad_kernel_sub_sampled = g_tpl.sad;
             svt_aom_satd                   = g_tpl.satd;
             svt_aom_subtract_block         = g_tpl.subtract;
             free_pic(&st);
         }
+        if (use_shim) shim.destroy(shim.engine);
     } else if (job.hdr.mode == REF_MODE_DUMP) {
         fwrite(&oh, sizeof(oh), 1, o);
         for (uint32_t pi = 0; pi < job.hdr.n_pics; ++pi) {

@@ -154,3 +154,30 @@ def test_1080p_search_on_the_engines_own_me_results_equals_the_reference_digest(
         assert hsh.hexdigest() == want["sha256"]
     finally:
         eng.close()
+
+
+DISPENSER_FIELDS = ("valid", "best_mode", "best_intra_mode", "best_rf_idx", "mv_row", "mv_col", "ref_frame_poc", "src_srcrf_dist",
+                    "src_srcrf_rate", "srcrf_dist", "recrf_dist", "srcrf_rate", "recrf_rate", "stats_mv_row", "stats_mv_col",
+                    "stats_ref_frame_poc")
+
+
+@pytest.mark.skipif(not refio.have_reference(), reason="oracle/_ref/ref_me (built where the reference sources are) is not here")
+@pytest.mark.parametrize("name", sorted(tpl_cases.CASES))
+def test_reference_dispenser_runs_unchanged_on_the_engines_search(name):
+    """The drop-in evidence: ref_me with the engine behind the seam. The reference's ME runs, svtme_tpl_search replaces the
+    dispenser's source-based search, the binding fills tpl_src_stats_buffer (transform and quantisation of the chosen
+    candidate with the reference's own functions), and the unmodified tpl_mc_flow_dispenser_sb_generic does its
+    reconstruction path on that. Every block's source-based record, its final TplStats and the reconstructed picture are
+    the unmodified reference's."""
+    import svtme
+    c = tpl_cases.CASES[name]
+    g = np.load(os.path.join(GOLDEN, name + ".npz"))
+    frames, pics, rc = support.make_job(**tpl_cases.job_args(c))
+    hdr, recs = refio.run_reference_tpl(frames, pics, c["enc_mode"], c["level"], c["qp"], library=svtme.LIB_PATH, ref_counts=rc)
+    assert len(recs) == int(g["n_pics"])
+    for i, (pd, bd, tp, tb) in enumerate(recs):
+        want_tp, want = g["pic%d_tpl" % i], g["pic%d_blocks" % i]
+        assert int(tp["recon_hash"]) == int(want_tp["recon_hash"]), (name, i)
+        for f in DISPENSER_FIELDS:
+            assert np.array_equal(tb[f], want[f]), (name, i, f)
+        assert int(tb["n_costs"].sum()) == 0  # the host evaluated no cost: the search was the engine's

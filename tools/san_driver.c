@@ -346,6 +346,57 @@ static uint64_t run_extras(uint32_t w, uint32_t h, uint32_t seed, uint64_t hsh) 
         EXPECT(svtme_gm_corners(eng, 102, 3, pts, 8, &n_pts), SVTME_ERR_BAD_ARG);
         EXPECT(svtme_gm_warp_error(eng, 102, 100, 0, NULL, 0, &e_warp), SVTME_ERR_BAD_ARG);
     }
+    /* the TPL dispenser's source-based search on made-up ME results: one single-reference candidate per list and block
+       with vectors that reach the clamp, every level, with and without intra prediction; its refusals */
+    {
+        const uint32_t n_b64 = ((w + 63) / 64) * ((h + 63) / 64), n_pu = SVTME_PU_COUNT, max_cand = 3, max_refs = 2;
+        uint8_t  *cnt  = (uint8_t *)calloc((size_t)n_b64 * n_pu, 1);
+        uint8_t  *cand = (uint8_t *)calloc((size_t)n_b64 * n_pu * max_cand, 1);
+        uint32_t *mv   = (uint32_t *)calloc((size_t)n_b64 * n_pu * max_refs, 4);
+        svtme_tpl_block *blk = (svtme_tpl_block *)calloc((size_t)n_b64 * SVTME_TPL_BLOCKS, sizeof(*blk));
+        for (uint32_t i = 0; i < n_b64 * n_pu; ++i) {
+            cnt[i] = 3;
+            cand[i * max_cand + 0] = 0; /* list 0, reference 0 */
+            cand[i * max_cand + 1] = 1 | (1 << 7); /* list 1, reference 0 */
+            cand[i * max_cand + 2] = 2 | (1 << 7); /* bi-directional: not looked at */
+            mv[i * max_refs + 0] = (uint32_t)(uint16_t)(int16_t)(((int)(i * 37 % 801)) - 400) | ((uint32_t)(uint16_t)(int16_t)(((int)(i * 53 % 601)) - 300) << 16);
+            mv[i * max_refs + 1] = (uint32_t)(uint16_t)(int16_t)(-(int)(i % 23)) | ((uint32_t)(uint16_t)(int16_t)(i % 17) << 16);
+        }
+        svtme_tpl_picture tp;
+        memset(&tp, 0, sizeof(tp));
+        tp.cur_key = 102; tp.ref_key[0][0] = 100; tp.ref_key[1][0] = 101;
+        tp.n_ref[0] = tp.n_ref[1] = 1;
+        tp.width = w; tp.height = h;
+        tp.tpl_opt_flag = tp.use_pred_sad_in_intra_search = tp.use_pred_sad_in_inter_search = 1;
+        tp.enable_me_16x16 = 1;
+        tp.n_pu = (uint8_t)n_pu; tp.max_cand = (uint8_t)max_cand; tp.max_refs = (uint8_t)max_refs; tp.max_l0 = 1;
+        tp.total_me_candidate_index = cnt; tp.me_candidate_array = cand; tp.me_mv_array = mv;
+        for (int level = 0; level < 3; ++level)
+            for (int no_intra = 0; no_intra < 2; ++no_intra) {
+                tp.dispenser_search_level = (uint8_t)level;
+                tp.disable_intra_pred     = (uint8_t)no_intra;
+                CHECK(svtme_tpl_search(eng, &tp, blk));
+                uint32_t n_valid = 0;
+                for (uint32_t i = 0; i < n_b64 * SVTME_TPL_BLOCKS; ++i) {
+                    if (!blk[i].valid) continue;
+                    ++n_valid;
+                    if (blk[i].best_rf_idx != 0 && blk[i].best_rf_idx != 4) EXPECT(-120, SVTME_OK);
+                    if (no_intra && !blk[i].best_is_inter) EXPECT(-121, SVTME_OK);
+                }
+                if (!n_valid) EXPECT(-122, SVTME_OK);
+                hsh = fnv(hsh, blk, sizeof(*blk) * (size_t)n_b64 * SVTME_TPL_BLOCKS);
+            }
+        tp.use_pred_sad_in_inter_search = 0;
+        EXPECT(svtme_tpl_search(eng, &tp, blk), SVTME_ERR_UNSUPPORTED);
+        tp.use_pred_sad_in_inter_search = 1;
+        tp.n_ref[1] = 0; /* the list-1 candidates now name a reference that was not handed over */
+        EXPECT(svtme_tpl_search(eng, &tp, blk), SVTME_ERR_BAD_ARG);
+        tp.n_ref[1] = 1;
+        tp.ref_key[1][0] = 999;
+        EXPECT(svtme_tpl_search(eng, &tp, blk), SVTME_ERR_NOT_FOUND);
+        EXPECT(svtme_tpl_search(eng, &tp, NULL), SVTME_ERR_BAD_ARG);
+        free(cnt); free(cand); free(mv); free(blk);
+    }
     svtme_destroy(eng);
     /* two engines on this device behind one handle: pictures round robin, sources where they are read */
     {
