@@ -926,15 +926,22 @@ static void tpl_fill_from_engine(Shim *s, const Job *job, uint32_t pi, PicState 
     free(blk); free(cnt); free(cand); free(mv);
 }
 
+static double now_s(void);
+static double g_tpl_seconds[2]; /* the binding's part (engine call, transform and quantisation of the choices), the dispenser */
+
 static void run_pic_tpl(const Job *job, uint32_t pi, PicState *st, FILE *o, Shim *shim) {
     TplState t;
     tpl_setup(job, pi, st, &t);
+    const double t0 = now_s();
     if (shim) tpl_fill_from_engine(shim, job, pi, st, &t);
+    const double t1 = now_s();
+    g_tpl_seconds[0] += t1 - t0;
     for (uint32_t sb = 0; sb < st->n_b64; ++sb) {
         const SbParams *sp = &st->scs->sb_params_array[sb];
         tpl_mc_flow_dispenser_sb_generic(t.enc, st->scs, st->pcs, 0, sb, t.qindex,
                                          (sp->width == 64 && sp->height == 64) ? st->pcs->tpl_ctrls.dispenser_search_level : 0);
     }
+    g_tpl_seconds[1] += now_s() - t1;
     tpl_dump(job, pi, st, &t, o);
     tpl_free(st, &t);
 }
@@ -1062,6 +1069,8 @@ int main(int argc, char **argv) {
             free_pic(&st);
         }
         if (use_shim) shim.destroy(shim.engine);
+        printf("{\"pictures\": %u, \"binding_seconds\": %.6f, \"dispenser_seconds\": %.6f, \"engine\": %d}\n", job.hdr.n_pics,
+               g_tpl_seconds[0], g_tpl_seconds[1], use_shim != NULL);
     } else if (job.hdr.mode == REF_MODE_DUMP) {
         fwrite(&oh, sizeof(oh), 1, o);
         for (uint32_t pi = 0; pi < job.hdr.n_pics; ++pi) {

@@ -1,0 +1,67 @@
+"""Timing of the TPL dispenser's source-based search at 1080p preset 8 (tpl level 4): the reference's dispenser alone (one
+host core) against the same dispenser with the search on the engine, and the engine call by itself.
+    python tools/tpl_probe.py [--calls-only]   (--calls-only: no child processes, for use under a profiler)"""
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+for p in ("svt-av1_amd", "oracle", "tests"):
+    sys.path.insert(0, os.path.join(ROOT, p))
+import numpy as np  # noqa: E402
+import refio  # noqa: E402
+import support  # noqa: E402
+import svtme  # noqa: E402
+import tpl_cases  # noqa: E402
+import tplio  # noqa: E402
+from test_tpl_oracle import picture_of  # noqa: E402
+
+
+def main():
+    calls_only = "--calls-only" in sys.argv
+    name, c = next(iter(tpl_cases.DIGEST_CASES.items()))
+    frames, pics, rc = support.make_job(**tpl_cases.job_args(c))
+    want = json.load(open(os.path.join(ROOT, "tests", "golden", "tpl_digests.json")))[name]
+    shape = want["me_shape"]
+    if not calls_only:
+        for lib in (None, svtme.LIB_PATH):
+            hdr, recs = refio.run_reference_tpl(frames, pics, c["enc_mode"], c["level"], c["qp"], library=lib, ref_counts=rc)
+            t = json.loads(hdr["stdout"].strip().splitlines()[-1])
+            print("reference dispenser, search %s: %.2f ms per picture (+ %.2f ms binding: engine call, transform and quantisation of the choices)"
+                  % ("on the engine" if lib else "on the host  ", 1e3 * t["dispenser_seconds"] / t["pictures"],
+                     1e3 * t["binding_seconds"] / t["pictures"]))
+    n, h, w = frames.shape
+    eng = svtme.Engine(w, h, store_slots=n + 2, max_in_flight=2)
+    try:
+        for i in range(n):
+            eng.store_put(i + 1, i, frames[i])
+        tail = svtme.Tail(enable=1, enable_me_8x8=shape["enable_me_8x8"], enable_me_16x16=shape["enable_me_16x16"],
+                          max_refs=shape["max_refs"], max_cand=shape["max_cand"], max_l0=shape["max_l0"],
+                          input_resolution=shape["input_resolution"], gm_enabled=1, gm_use_distance_based_active_th=1)
+        ctrl_me = svtme.derive_controls(c["enc_mode"], w, h, 0, 30 << 16)
+        jobs = []
+        for pic, ctrl in zip(pics, want["controls"]):
+            out = eng.run_picture(eng.make_picture(w, h, pic.poc, pic.temporal_layer, pic.is_ref, pic.refs, ctrl_me, tail=tail,
+                                                   key_of=lambda poc: poc + 1))
+            me = dict(total_me_candidate_index=out["total_me_candidate_index"],
+                      me_candidate_array=out["me_candidate_array"][:, :85 * shape["max_cand"]],
+                      me_mv_array=out["me_mv_array"][:, :85 * shape["max_refs"]], enable_me_16x16=shape["enable_me_16x16"],
+                      max_cand=shape["max_cand"], max_refs=shape["max_refs"], max_l0=shape["max_l0"])
+            jobs.append(picture_of(frames, pic, ctrl, me))
+        for p, keep, refs in jobs:
+            eng.tpl_search(p)
+        reps = 50
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            for p, keep, refs in jobs:
+                eng.tpl_search(p)
+        dt = (time.perf_counter() - t0) / (reps * len(jobs))
+        print("svtme_tpl_search, 1080p, %d blocks: %.3f ms per call (ME results in: %.2f MB, block records out: %.2f MB)"
+              % (8160, 1e3 * dt, 510 * 85 * (1 + shape["max_cand"] + 4 * shape["max_refs"]) / 1e6, 510 * 21 * 24 / 1e6))
+    finally:
+        eng.close()
+
+
+if __name__ == "__main__":
+    main()
