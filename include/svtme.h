@@ -455,12 +455,23 @@ int svtme_gm_frame_error(svtme_engine *e, uint64_t cur_key, uint64_t ref_key, in
  * Results are indexed [b64][i], i = 0 the 64x64 block, 1-4 the 32x32 blocks, 5-20 the 16x16 blocks in the order of
  * tpl_blk_idx_tab (:514-516); blocks outside the grid have valid = 0.
  *
- * Costs: the sum of absolute differences where the encoder's controls say so (tpl_opt_flag && use_pred_sad_in_intra_search,
- * tpl_opt_flag && use_pred_sad_in_inter_search: tpl levels 4-7, presets M7 and faster, EbResourceCoordinationProcess.c:
- * 241-330; EbEncHandle.c:3098-3125). The transform-domain cost of the slower levels and the directional / smooth / Paeth
- * intra modes of tpl_opt_flag == 0 are not on the device: SVTME_ERR_UNSUPPORTED. The ME results come in the layout of
- * MeSbResults (EbMotionEstimationLcuResults.h:29-52), n_pu entries per 64x64 block (SQUARE_PU_COUNT or
- * MAX_SB64_PU_COUNT_NO_8X8), one 64x64 block after the other. Synchronous; takes turns with the global-motion calls. */
+ * Costs, for tpl_opt_flag = 1 (tpl levels 2-7, presets M6 and faster; EbResourceCoordinationProcess.c:203-330,
+ * EbEncHandle.c:3098-3125; only DC intra prediction is tried then): the sum of absolute differences where
+ * use_pred_sad_in_intra_search / use_pred_sad_in_inter_search say so (:690, :886), else the sum of the absolute
+ * coefficients of the residual's forward 16x16 DCT (svt_av1_wht_fwd_txfm with pf_shape + svt_aom_satd, :790-813, :900-916):
+ * on the device for dispenser_search_level 0 and subsample_tx 0, which is what the levels that use it have.
+ * tpl_opt_flag = 0 (level 1: twelve more intra modes with edge filters, a rate estimate) is not on the device:
+ * SVTME_ERR_UNSUPPORTED, as is every combination not named here.
+ *
+ * src_dist = 1 adds what :935-982 derive from the chosen inter candidate: its residual's forward transform, quantised with
+ * the picture's quantiser (svt_av1_quantize_fp, no quantisation matrices) and compared with the coefficients
+ * (get_quantize_error, :167-193); src_recon_error is that function's recon_error, from which the encoder forms
+ * srcrf_dist = (recon_error << TPL_DEP_COST_SCALE_LOG2) << subsample_tx. Available for 16x16 blocks with subsample_tx 0
+ * (tpl levels 2-4); SVTME_ERR_UNSUPPORTED otherwise - the encoder then transforms the chosen candidate itself.
+ *
+ * The ME results come in the layout of MeSbResults (EbMotionEstimationLcuResults.h:29-52), n_pu entries per 64x64 block
+ * (SQUARE_PU_COUNT or MAX_SB64_PU_COUNT_NO_8X8), one 64x64 block after the other. Synchronous; takes turns with the
+ * global-motion calls. */
 #define SVTME_TPL_BLOCKS 21
 typedef struct svtme_tpl_picture {
     uint64_t cur_key; /* pcs->enhanced_picture_ptr: the picture's own store entry */
@@ -478,7 +489,13 @@ typedef struct svtme_tpl_picture {
     uint8_t  max_cand, max_refs, max_l0; /* pa_me_data->max_cand / max_refs / max_l0 */
     uint8_t  n_ref[SVTME_MAX_LISTS]; /* tpl_data.tpl_ref0_count / tpl_ref1_count: ref_key[l][r] is set for r < n_ref[l]; a
                                         candidate that names another reference makes the call fail with SVTME_ERR_BAD_ARG */
-    uint8_t  reserved[3];
+    uint8_t  subsample_tx; /* tpl_ctrls.subsample_tx */
+    uint8_t  pf_shape; /* tpl_ctrls.pf_shape: DEFAULT_SHAPE 0, N2_SHAPE 1, N4_SHAPE 2 (EbDefinitions.h) */
+    uint8_t  src_dist; /* 1: fill svtme_tpl_block::src_recon_error */
+    /* [0] dc, [1] ac of the luma quantiser at the dispenser's qindex: scs->quants_8bit.y_round_fp[q], .y_quant_fp[q],
+     * scs->deq_8bit.y_dequant_qtx[q] (:579-586); read when src_dist is set */
+    int16_t  y_round_fp[2], y_quant_fp[2], y_dequant[2];
+    uint8_t  reserved[4];
     const uint8_t  *total_me_candidate_index; /* [n_b64][n_pu] */
     const uint8_t  *me_candidate_array; /* [n_b64][n_pu * max_cand], MeCandidate bytes */
     const uint32_t *me_mv_array; /* [n_b64][n_pu * max_refs], MvCandidate::as_int */
@@ -492,6 +509,7 @@ typedef struct svtme_tpl_block {
     uint8_t best_is_inter; /* best_inter_cost < best_intra_cost: best_mode is NEWMV, else DC_PRED (:932-933) */
     uint8_t best_intra_mode; /* DC_PRED (0) */
     uint8_t valid; /* 1: the block belongs to the dispenser's grid */
+    int64_t src_recon_error; /* src_dist and best_is_inter: get_quantize_error's recon_error of the chosen candidate; else 0 */
 } svtme_tpl_block;
 int svtme_tpl_search(svtme_engine *e, const svtme_tpl_picture *pic, svtme_tpl_block *out /* [n_b64][SVTME_TPL_BLOCKS] */);
 

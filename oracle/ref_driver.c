@@ -765,6 +765,11 @@ static void tpl_dump(const Job *job, uint32_t pi, PicState *st, TplState *t, FIL
         for (uint32_t x = 0; x < w; ++x) hash = (hash ^ row[x]) * 0x100000001b3ull;
     }
     pd.recon_hash = hash;
+    for (int k = 0; k < 2; ++k) {
+        pd.y_round_fp[k] = st->scs->quants_8bit.y_round_fp[t->qindex][k];
+        pd.y_quant_fp[k] = st->scs->quants_8bit.y_quant_fp[t->qindex][k];
+        pd.y_dequant[k]  = st->scs->deq_8bit.y_dequant_qtx[t->qindex][k];
+    }
     fwrite(&pd, sizeof(pd), 1, o);
     for (uint32_t b64 = 0; b64 < st->n_b64; ++b64) {
         const SbParams *sp = &pcs->sb_params_array[b64];
@@ -861,6 +866,15 @@ static void tpl_fill_from_engine(Shim *s, const Job *job, uint32_t pi, PicState 
     d.use_pred_sad_in_intra_search = tc->use_pred_sad_in_intra_search;
     d.use_pred_sad_in_inter_search = tc->use_pred_sad_in_inter_search;
     d.enable_me_16x16              = pcs->enable_me_16x16;
+    d.subsample_tx                 = tc->subsample_tx;
+    d.pf_shape                     = (uint8_t)tc->pf_shape;
+    /* whole 16x16 transforms: the engine also transforms and quantises the candidate it chose */
+    d.src_dist = tc->dispenser_search_level == 0 && tc->subsample_tx == 0;
+    for (int k = 0; k < 2; ++k) {
+        d.y_round_fp[k] = scs->quants_8bit.y_round_fp[t->qindex][k];
+        d.y_quant_fp[k] = scs->quants_8bit.y_quant_fp[t->qindex][k];
+        d.y_dequant[k]  = scs->deq_8bit.y_dequant_qtx[t->qindex][k];
+    }
     d.n_pu     = (uint8_t)n_pu;
     d.max_cand = md->max_cand;
     d.max_refs = md->max_refs;
@@ -899,7 +913,10 @@ static void tpl_fill_from_engine(Shim *s, const Job *job, uint32_t pi, PicState 
             if (e->best_rf_idx >= 0) {
                 const int l = e->best_rf_idx < 4 ? 0 : 1, r = e->best_rf_idx >= 4 ? e->best_rf_idx - 4 : e->best_rf_idx;
                 ss->ref_frame_poc = pcs->tpl_data.tpl_ref_ds_ptr_array[l][r].picture_number;
-                if (e->best_is_inter) { /* :935-982 with use_pred_sad_in_inter_search */
+                if (e->best_is_inter && d.src_dist) {
+                    ss->srcrf_rate = 0; /* tpl_opt_flag: no rate (:975-979) */
+                    ss->srcrf_dist = (e->src_recon_error << TPL_DEP_COST_SCALE_LOG2) << tc->subsample_tx; /* :980-981 */
+                } else if (e->best_is_inter) { /* :935-982 on the host */
                     const EbPictureBufferDesc *rp = pcs->tpl_data.tpl_ref_ds_ptr_array[l][r].picture_ptr;
                     const uint8_t *src_mb = in->buffer_y + in->origin_x + x + (size_t)(in->origin_y + y) * in->stride_y;
                     const int32_t  ro = (int32_t)rp->origin_x + ((int32_t)x + (e->mv_x >> 3)) +
@@ -969,7 +986,36 @@ static void run_pic(const Job *job, uint32_t pi, PicState *st, uint32_t threads,
     free(tid); free(wk);
 }
 
+/* ref_me dct16 <in> <out>: the reference's forward transform as the TPL dispenser calls it (svt_av1_wht_fwd_txfm, TX_16X16,
+ * 8 bit) on every 16x16 residual block of <in> (int16 [n][256]), for DEFAULT_SHAPE, N2_SHAPE and N4_SHAPE: int32 [3][n][256]. */
+static int dct16_main(const char *in_path, const char *out_path) {
+    FILE *f = fopen(in_path, "rb");
+    if (!f) die("cannot open the block file");
+    fseek(f, 0, SEEK_END);
+    const long n = ftell(f) / (256 * 2);
+    fseek(f, 0, SEEK_SET);
+    int16_t *blocks = (int16_t *)malloc((size_t)n * 512);
+    if (fread(blocks, 512, (size_t)n, f) != (size_t)n) die("short block file");
+    fclose(f);
+    setup_common_rtcd_internal(0);
+    setup_rtcd_internal(0);
+    FILE *o = fopen(out_path, "wb");
+    if (!o) die("cannot open output file");
+    const EB_TRANS_COEFF_SHAPE shapes[3] = {DEFAULT_SHAPE, N2_SHAPE, N4_SHAPE};
+    for (int s = 0; s < 3; ++s)
+        for (long i = 0; i < n; ++i) {
+            int32_t coeff[256];
+            memset(coeff, 0, sizeof(coeff));
+            svt_av1_wht_fwd_txfm(blocks + i * 256, 16, coeff, TX_16X16, shapes[s], 8, 0);
+            fwrite(coeff, sizeof(coeff), 1, o);
+        }
+    fclose(o);
+    free(blocks);
+    return 0;
+}
+
 int main(int argc, char **argv) {
+    if (argc == 4 && !strcmp(argv[1], "dct16")) return dct16_main(argv[2], argv[3]);
     if (argc < 3) die("usage: ref_me <job> <out>");
     FILE *f = fopen(argv[1], "rb");
     if (!f) die("cannot open job file");

@@ -126,6 +126,8 @@ typedef struct ref_tpl_pic_dump {
     uint8_t  subsample_tx, pf_shape, disable_intra_pred, synth_blk_size;
     uint32_t qindex;
     uint64_t recon_hash; /* FNV-1a over the reconstructed luma, row by row, after the last block */
+    int16_t  y_round_fp[2], y_quant_fp[2], y_dequant[2]; /* [dc, ac] of scs->quants_8bit / deq_8bit at qindex (:579-586) */
+    uint8_t  pad[4];
 } ref_tpl_pic_dump;
 
 /* One of the 21 blocks (tpl_blk_idx_tab order: 64x64, 4 x 32x32, 16 x 16x16) of a 64x64 block. */

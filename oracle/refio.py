@@ -59,6 +59,7 @@ TPL_PIC_DUMP = np.dtype([
     ("tpl_opt_flag", "u1"), ("use_pred_sad_in_intra_search", "u1"), ("use_pred_sad_in_inter_search", "u1"),
     ("dispenser_search_level", "u1"), ("subsample_tx", "u1"), ("pf_shape", "u1"), ("disable_intra_pred", "u1"),
     ("synth_blk_size", "u1"), ("qindex", "<u4"), ("recon_hash", "<u8"),
+    ("y_round_fp", "<i2", (2,)), ("y_quant_fp", "<i2", (2,)), ("y_dequant", "<i2", (2,)), ("pad", "u1", (4,)),
 ])
 TPL_BLK_DUMP = np.dtype([
     ("valid", "u1"), ("best_mode", "u1"), ("best_intra_mode", "u1"), ("n_costs", "u1"), ("best_rf_idx", "<i4"),
@@ -187,6 +188,17 @@ def run_reference_tpl(frames, pics, enc_mode, tpl_level, qp, library=None, **kw)
     dispenser's source-based search comes from the GPU engine and only its reconstruction path runs on the host."""
     return run_binary(REF_BIN, frames, pics, enc_mode, extra_args=(library,) if library else (), mode=MODE_TPL,
                       tpl=(tpl_level, qp), **kw)
+
+
+def reference_dct16(blocks):
+    """The reference's forward transform of the TPL dispenser (svt_av1_wht_fwd_txfm, TX_16X16) on int16 residual blocks
+    [n, 16, 16]: int32 [3, n, 16, 16] for DEFAULT_SHAPE, N2_SHAPE, N4_SHAPE."""
+    blocks = np.ascontiguousarray(blocks, np.int16)
+    with tempfile.TemporaryDirectory(prefix="svtme_") as td:
+        a, b = os.path.join(td, "in.bin"), os.path.join(td, "out.bin")
+        blocks.tofile(a)
+        subprocess.run([REF_BIN, "dct16", a, b], check=True, timeout=120)
+        return np.fromfile(b, np.int32).reshape(3, len(blocks), 16, 16)
 
 
 def run_oracle(frames, pics, enc_mode, **kw):

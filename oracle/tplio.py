@@ -15,8 +15,13 @@ BLOCK_GEOMETRY = [(0, 0, 64)] + [((i & 1) * 32, (i >> 1) * 32, 32) for i in rang
     [((q & 1) * 32 + (s & 1) * 16, (q >> 1) * 32 + (s >> 1) * 16, 16) for q in range(4) for s in range(4)]
 
 TPL_BLOCK = np.dtype([("best_intra_cost", "<i8"), ("best_inter_cost", "<i8"), ("mv_x", "<i2"), ("mv_y", "<i2"),
-                      ("best_rf_idx", "i1"), ("best_is_inter", "u1"), ("best_intra_mode", "u1"), ("valid", "u1")])
-assert TPL_BLOCK.itemsize == 24
+                      ("best_rf_idx", "i1"), ("best_is_inter", "u1"), ("best_intra_mode", "u1"), ("valid", "u1"),
+                      ("src_recon_error", "<i8")])
+assert TPL_BLOCK.itemsize == 32
+
+
+CONTROL_FIELDS = ("dispenser_search_level", "disable_intra_pred", "tpl_opt_flag", "use_pred_sad_in_intra_search",
+                  "use_pred_sad_in_inter_search", "subsample_tx", "pf_shape")
 
 
 class TplPicture(ctypes.Structure):
@@ -26,15 +31,18 @@ class TplPicture(ctypes.Structure):
                 ("tpl_opt_flag", ctypes.c_uint8), ("use_pred_sad_in_intra_search", ctypes.c_uint8),
                 ("use_pred_sad_in_inter_search", ctypes.c_uint8), ("enable_me_16x16", ctypes.c_uint8), ("n_pu", ctypes.c_uint8),
                 ("max_cand", ctypes.c_uint8), ("max_refs", ctypes.c_uint8), ("max_l0", ctypes.c_uint8),
-                ("n_ref", ctypes.c_uint8 * 2), ("reserved", ctypes.c_uint8 * 3),
+                ("n_ref", ctypes.c_uint8 * 2), ("subsample_tx", ctypes.c_uint8), ("pf_shape", ctypes.c_uint8),
+                ("src_dist", ctypes.c_uint8), ("y_round_fp", ctypes.c_int16 * 2), ("y_quant_fp", ctypes.c_int16 * 2),
+                ("y_dequant", ctypes.c_int16 * 2), ("reserved", ctypes.c_uint8 * 4),
                 ("total_me_candidate_index", ctypes.POINTER(ctypes.c_uint8)),
                 ("me_candidate_array", ctypes.POINTER(ctypes.c_uint8)),
                 ("me_mv_array", ctypes.POINTER(ctypes.c_uint32))]
 
 
-def make_picture(width, height, ctrl, me, cur_key=0, ref_keys=((), ()), ref_skip=None, i_slice=0, n_ref=None):
+def make_picture(width, height, ctrl, me, cur_key=0, ref_keys=((), ()), ref_skip=None, i_slice=0, n_ref=None, quant=None):
     """ctrl: dict with dispenser_search_level, disable_intra_pred, tpl_opt_flag, use_pred_sad_in_intra_search,
-    use_pred_sad_in_inter_search; me: dict with total_me_candidate_index [n_b64, n_pu] u8, me_candidate_array
+    use_pred_sad_in_inter_search, subsample_tx, pf_shape; quant: None, or (y_round_fp, y_quant_fp, y_dequant) pairs [dc, ac],
+    which also asks for the source distortion (src_dist); me: dict with total_me_candidate_index [n_b64, n_pu] u8, me_candidate_array
     [n_b64, n_pu * max_cand] u8, me_mv_array [n_b64, n_pu * max_refs] u32, enable_me_16x16, max_cand, max_refs, max_l0.
     Returns (TplPicture, keep-alive tuple)."""
     cnt = np.ascontiguousarray(me["total_me_candidate_index"], np.uint8)
@@ -50,9 +58,12 @@ def make_picture(width, height, ctrl, me, cur_key=0, ref_keys=((), ()), ref_skip
             p.ref_skip[l][r] = int(ref_skip[l][r]) if ref_skip is not None else 0
     p.width, p.height, p.i_slice = width, height, i_slice
     p.n_ref[0], p.n_ref[1] = n_ref if n_ref is not None else (len(ref_keys[0]), len(ref_keys[1]))
-    for k in ("dispenser_search_level", "disable_intra_pred", "tpl_opt_flag", "use_pred_sad_in_intra_search",
-              "use_pred_sad_in_inter_search"):
+    for k in CONTROL_FIELDS:
         setattr(p, k, int(ctrl[k]))
+    if quant is not None:
+        p.src_dist = 1
+        for k in range(2):
+            p.y_round_fp[k], p.y_quant_fp[k], p.y_dequant[k] = int(quant[0][k]), int(quant[1][k]), int(quant[2][k])
     p.enable_me_16x16, p.n_pu = int(me["enable_me_16x16"]), n_pu
     p.max_cand, p.max_refs, p.max_l0 = int(me["max_cand"]), int(me["max_refs"]), int(me["max_l0"])
     p.total_me_candidate_index = cnt.ctypes.data_as(ctypes.POINTER(ctypes.c_uint8))
@@ -78,6 +89,7 @@ def oracle_search(cur, refs, pic):
         ptrs[l * 4 + r] = a.ctypes.data_as(ctypes.POINTER(ctypes.c_uint8))
     n_b64 = ((w + 63) // 64) * ((h + 63) // 64)
     out = np.zeros((n_b64, TPL_BLOCKS), TPL_BLOCK)
+    _lib.orc_tpl_search.restype = ctypes.c_int
     rc = _lib.orc_tpl_search(cur.ctypes.data_as(ctypes.POINTER(ctypes.c_uint8)), w, ptrs, ctypes.byref(pic),
                              out.ctypes.data_as(ctypes.c_void_p))
     if rc != 0:
@@ -96,13 +108,24 @@ def me_inputs_of(pd, bd):
 
 def controls_of(tp):
     """refio.TPL_PIC_DUMP record -> the control dict make_picture takes."""
-    return {k: int(tp[k]) for k in ("dispenser_search_level", "disable_intra_pred", "tpl_opt_flag",
-                                    "use_pred_sad_in_intra_search", "use_pred_sad_in_inter_search")}
+    return {k: int(tp[k]) for k in CONTROL_FIELDS}
 
 
-def expected_from_reference(tb, ctrl):
+def src_dist_available(ctrl):
+    """The source distortion (and transform-domain costs) exist for whole 16x16 transforms only."""
+    return ctrl["dispenser_search_level"] == 0 and ctrl["subsample_tx"] == 0
+
+
+def quant_of(tp):
+    """refio.TPL_PIC_DUMP record -> the quantiser triple make_picture takes."""
+    return (tp["y_round_fp"].tolist(), tp["y_quant_fp"].tolist(), tp["y_dequant"].tolist())
+
+
+def expected_from_reference(tb, ctrl, src_dist=False):
     """What the reference's dump (refio.TPL_BLK_DUMP records [n_b64, 21]) says the search found, as TPL_BLOCK records: the
-    costs come from the recorded cost calls (the intra cost first when intra prediction is on, then one per candidate)."""
+    costs come from the recorded cost calls (the intra cost first when intra prediction is on, then one per candidate);
+    src_dist: src_recon_error from the recorded srcrf_dist = (recon_error << TPL_DEP_COST_SCALE_LOG2) << subsample_tx of the
+    blocks an inter candidate won."""
     out = np.zeros(tb.shape, TPL_BLOCK)
     out["valid"] = tb["valid"]
     v = tb["valid"] == 1
@@ -118,4 +141,17 @@ def expected_from_reference(tb, ctrl):
     out["mv_y"] = np.where(v, tb["mv_row"], 0)
     out["best_is_inter"] = np.where(v, tb["best_mode"] != 0, 0)
     out["best_intra_mode"] = np.where(v, tb["best_intra_mode"], 0)
+    if src_dist:
+        out["src_recon_error"] = np.where(v & (tb["best_mode"] != 0), tb["src_srcrf_dist"] >> (4 + ctrl["subsample_tx"]), 0)
+    return out
+
+
+def oracle_fwd_dct16x16(residual, shape=0):
+    """residual: int16 [16, 16] -> int32 [16, 16] coefficients of the restatement's forward DCT."""
+    global _lib
+    if _lib is None:
+        _lib = ctypes.CDLL(ORACLE_LIB)
+    r = np.ascontiguousarray(residual, np.int16)
+    out = np.zeros((16, 16), np.int32)
+    _lib.orc_tpl_fwd_dct16x16(r.ctypes.data_as(ctypes.c_void_p), out.ctypes.data_as(ctypes.c_void_p), int(shape))
     return out

@@ -11,6 +11,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <math.h>
 
 #include <mutex>
 #include <new>
@@ -1216,8 +1217,12 @@ extern "C" int svtme_tpl_search(svtme_engine *e, const svtme_tpl_picture *pic, s
         (pic->n_pu != SVTME_PU_COUNT && pic->n_pu != 21) || pic->max_cand == 0 || pic->max_refs == 0 ||
         pic->max_l0 + (pic->n_ref[1] ? pic->n_ref[1] : 0) > pic->max_refs || pic->n_ref[0] > pic->max_l0)
         return SVTME_ERR_BAD_ARG;
-    // transform-domain costs and the intra modes beyond DC are not on the device
-    if (!pic->tpl_opt_flag || !pic->use_pred_sad_in_intra_search || !pic->use_pred_sad_in_inter_search) return SVTME_ERR_UNSUPPORTED;
+    // the intra modes beyond DC are not on the device; transform-domain costs and the source distortion are there for whole
+    // 16x16 transforms
+    if (!pic->tpl_opt_flag || pic->pf_shape > 2) return SVTME_ERR_UNSUPPORTED;
+    if ((!pic->use_pred_sad_in_intra_search || !pic->use_pred_sad_in_inter_search || pic->src_dist) &&
+        (pic->dispenser_search_level != 0 || pic->subsample_tx != 0))
+        return SVTME_ERR_UNSUPPORTED;
     DEVICE_OR_FAIL(e->cfg.device);
     std::lock_guard<std::mutex> gm_lock(e->gm.mu);
     GmState  &g = e->gm;
@@ -1267,6 +1272,19 @@ extern "C" int svtme_tpl_search(svtme_engine *e, const svtme_tpl_picture *pic, s
     p.max_cand = pic->max_cand;
     p.max_refs = pic->max_refs;
     p.max_l0 = pic->max_l0;
+    p.sad_intra = pic->use_pred_sad_in_intra_search != 0;
+    p.sad_inter = pic->use_pred_sad_in_inter_search != 0;
+    p.pf_shape  = pic->pf_shape;
+    p.src_dist  = pic->src_dist != 0;
+    for (int k = 0; k < 2; ++k) {
+        p.round_fp[k] = pic->y_round_fp[k];
+        p.quant_fp[k] = pic->y_quant_fp[k];
+        p.dequant[k]  = pic->y_dequant[k];
+    }
+    for (int k = 0; k < 16; ++k) { // cospi_arr(13) / (12) at every fourth angle (EbInvTransforms.h)
+        p.cos13[k] = (int32_t)lround(cos(4 * k * 3.14159265358979323846 / 128.0) * 8192.0);
+        p.cos12[k] = (int32_t)lround(cos(4 * k * 3.14159265358979323846 / 128.0) * 4096.0);
+    }
     p.cnt   = g.d_tpl;
     p.cand  = g.d_tpl + cnt_bytes;
     p.mv    = reinterpret_cast<const uint32_t *>(g.d_tpl + mv_off);

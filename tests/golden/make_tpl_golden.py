@@ -32,7 +32,8 @@ def digest(recs):
     """sha256 over the search results (tplio.expected_from_reference) of every picture, field by field."""
     h = hashlib.sha256()
     for pd, bd, tp, tb in recs:
-        exp = tplio.expected_from_reference(tb, tplio.controls_of(tp))
+        ctrl = tplio.controls_of(tp)
+        exp = tplio.expected_from_reference(tb, ctrl, src_dist=tplio.src_dist_available(ctrl))
         for f in tpl_cases.SEARCH_FIELDS:
             h.update(np.ascontiguousarray(exp[f]).tobytes())
     return h.hexdigest()
@@ -60,6 +61,7 @@ def main():
         frames, pics, recs = run(c)
         pd0 = recs[0][0]
         dig[name] = dict(sha256=digest(recs), controls=[tplio.controls_of(r[2]) for r in recs],
+                         quant=[list(q) for q in tplio.quant_of(recs[0][2])],
                          me_shape={k: int(pd0[k]) for k in ("enable_me_8x8", "enable_me_16x16", "max_cand", "max_refs", "max_l0",
                                                             "input_resolution")})
         print(name, dig[name]["sha256"])

@@ -35,9 +35,13 @@ def test_engine_reproduces_reference_tpl_search(name):
     frames, pics, per = load_case(name, tpl_cases.CASES[name])
     eng = _engine(frames)
     try:
-        for pic, (ctrl, me, tb) in zip(pics, per):
-            p, keep, refs = picture_of(frames, pic, ctrl, me)
-            assert_blocks_equal(eng.tpl_search(p), tplio.expected_from_reference(tb, ctrl), "%s poc %d" % (name, pic.poc))
+        for pic, (ctrl, me, tb, quant) in zip(pics, per):
+            src = tplio.src_dist_available(ctrl)
+            p, keep, refs = picture_of(frames, pic, ctrl, me, quant=quant if src else None)
+            assert_blocks_equal(eng.tpl_search(p), tplio.expected_from_reference(tb, ctrl, src_dist=src), "%s poc %d" % (name, pic.poc))
+            if src:  # without the source distortion the search is the same
+                p, keep, refs = picture_of(frames, pic, ctrl, me)
+                assert_blocks_equal(eng.tpl_search(p), tplio.expected_from_reference(tb, ctrl), "%s poc %d, search only" % (name, pic.poc))
     finally:
         eng.close()
 
@@ -71,12 +75,20 @@ def test_random_me_results_match_the_restatement(seed):
     frames = support.make_job(w, h, n_frames, 8, seed=seed + 7, kind=kind)[0]
     n_b64 = ((w + 63) // 64) * ((h + 63) // 64)
     me = _random_me(rng, n_b64, [85, 21][int(rng.integers(0, 2))], n_ref, int(rng.choice([8, 64, 400, 2000])))
-    ctrl = dict(dispenser_search_level=int(rng.integers(0, 3)), disable_intra_pred=int(rng.integers(0, 2)), tpl_opt_flag=1,
-                use_pred_sad_in_intra_search=1, use_pred_sad_in_inter_search=1)
+    level = int(rng.integers(0, 3))
+    ctrl = dict(dispenser_search_level=level, disable_intra_pred=int(rng.integers(0, 2)), tpl_opt_flag=1,
+                use_pred_sad_in_intra_search=1, use_pred_sad_in_inter_search=1, subsample_tx=int(rng.integers(0, 3)),
+                pf_shape=int(rng.integers(0, 3)))
+    quant = None
+    if level == 0 and seed % 3:  # whole 16x16 transforms: transform-domain costs and / or the source distortion
+        ctrl.update(subsample_tx=0, use_pred_sad_in_intra_search=int(rng.integers(0, 2)), use_pred_sad_in_inter_search=int(rng.integers(0, 2)))
+        if rng.integers(0, 3):
+            dq = [int(rng.integers(4, 1400)), int(rng.integers(4, 1900))]
+            quant = ([int(rng.integers(0, 1 + d)) for d in dq], [min(32767, int(rng.integers(1, 3)) * 32768 // d) for d in dq], dq)
     from svtme import gop
     pic = gop.Picture(poc=0, temporal_layer=0, is_ref=1, refs=[list(range(1, 1 + n_ref[0])), list(range(1 + n_ref[0], n_frames))])
     skip = rng.integers(0, 4, (2, 4)) == 0
-    p, keep, refs = picture_of(frames, pic, ctrl, me, ref_skip=skip, i_slice=int(rng.integers(0, 8) == 0))
+    p, keep, refs = picture_of(frames, pic, ctrl, me, ref_skip=skip, i_slice=int(rng.integers(0, 8) == 0), quant=quant)
     eng = _engine(frames)
     try:
         got = eng.tpl_search(p)
@@ -91,14 +103,17 @@ def test_unsupported_controls_and_bad_arguments():
     import svtme
     frames, pics, per = load_case("tpl4_m8_200x136", tpl_cases.CASES["tpl4_m8_200x136"])
     pic = next(p for p in pics if len(p.refs[1]) >= 1)
-    ctrl, me, tb = per[pics.index(pic)]
+    ctrl, me, tb, quant = per[pics.index(pic)]
     eng = _engine(frames)
     try:
-        for off in ("tpl_opt_flag", "use_pred_sad_in_intra_search", "use_pred_sad_in_inter_search"):
-            p, keep, refs = picture_of(frames, pic, dict(ctrl, **{off: 0}), me)
+        # every intra mode (tpl_opt_flag 0); transform-domain costs or the source distortion on anything but whole 16x16 transforms
+        for change, q in ((dict(tpl_opt_flag=0), None), (dict(use_pred_sad_in_inter_search=0, dispenser_search_level=1), None),
+                          (dict(use_pred_sad_in_intra_search=0, subsample_tx=1), None), (dict(subsample_tx=2), quant),
+                          (dict(dispenser_search_level=2), quant), (dict(pf_shape=3), None)):
+            p, keep, refs = picture_of(frames, pic, dict(ctrl, **change), me, quant=q)
             with pytest.raises(svtme.SvtmeError) as ei:
                 eng.tpl_search(p)
-            assert ei.value.code == svtme.ERR_UNSUPPORTED
+            assert ei.value.code == svtme.ERR_UNSUPPORTED, change
         # a candidate of a reference that was not handed over
         p, keep, refs = picture_of(frames, pic, ctrl, me, n_ref=(len(pic.refs[0]), 0))
         with pytest.raises(svtme.SvtmeError) as ei:
@@ -147,7 +162,7 @@ def test_1080p_search_on_the_engines_own_me_results_equals_the_reference_digest(
                       me_candidate_array=out["me_candidate_array"][:, :85 * shape["max_cand"]],
                       me_mv_array=out["me_mv_array"][:, :85 * shape["max_refs"]], enable_me_16x16=shape["enable_me_16x16"],
                       max_cand=shape["max_cand"], max_refs=shape["max_refs"], max_l0=shape["max_l0"])
-            p, keep, refs = picture_of(frames, pic, ctrl, me)
+            p, keep, refs = picture_of(frames, pic, ctrl, me, quant=want["quant"])
             got = eng.tpl_search(p)
             for f in tpl_cases.SEARCH_FIELDS:
                 hsh.update(np.ascontiguousarray(got[f]).tobytes())

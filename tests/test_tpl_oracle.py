@@ -18,7 +18,7 @@ GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 
 
 def load_case(name, c):
-    """-> frames, pics, per picture (controls, me inputs, reference block records)"""
+    """-> frames, pics, per picture (controls, me inputs, reference block records, quantiser)"""
     g = np.load(os.path.join(GOLDEN, name + ".npz"))
     frames, pics, rc = support.make_job(**tpl_cases.job_args(c))
     assert int(g["n_pics"]) == len(pics)
@@ -28,8 +28,18 @@ def load_case(name, c):
         me = dict(total_me_candidate_index=g["pic%d_me_cnt" % i], me_candidate_array=g["pic%d_me_cand" % i],
                   me_mv_array=g["pic%d_me_mv" % i], enable_me_16x16=int(shape[0]), max_cand=int(shape[1]),
                   max_refs=int(shape[2]), max_l0=int(shape[3]))
-        per.append((tplio.controls_of(g["pic%d_tpl" % i]), me, g["pic%d_blocks" % i]))
+        per.append((tplio.controls_of(g["pic%d_tpl" % i]), me, g["pic%d_blocks" % i], tplio.quant_of(g["pic%d_tpl" % i])))
     return frames, pics, per
+
+
+def test_oracle_refuses_what_it_does_not_restate():
+    frames, pics, per = load_case("tpl4_m8_200x136", CASES["tpl4_m8_200x136"])
+    ctrl, me, tb, quant = per[0]
+    for change, q in ((dict(tpl_opt_flag=0), None), (dict(use_pred_sad_in_inter_search=0, dispenser_search_level=1), None),
+                      (dict(use_pred_sad_in_intra_search=0, subsample_tx=1), None), (dict(subsample_tx=2), quant), (dict(pf_shape=3), None)):
+        p, keep, refs = picture_of(frames, pics[0], dict(ctrl, **change), me, quant=q)
+        with pytest.raises(RuntimeError, match="-5"):
+            tplio.oracle_search(frames[pics[0].poc], refs, p)
 
 
 def picture_of(frames, pic, ctrl, me, **kw):
@@ -50,22 +60,25 @@ def assert_blocks_equal(got, exp, what):
 @pytest.mark.parametrize("name", sorted(CASES))
 def test_oracle_reproduces_reference_tpl_search(name):
     frames, pics, per = load_case(name, CASES[name])
-    n_blocks = n_intra = 0
-    for pic, (ctrl, me, tb) in zip(pics, per):
-        p, keep, refs = picture_of(frames, pic, ctrl, me)
+    n_blocks = n_intra = n_src = 0
+    for pic, (ctrl, me, tb, quant) in zip(pics, per):
+        src = tplio.src_dist_available(ctrl)
+        p, keep, refs = picture_of(frames, pic, ctrl, me, quant=quant if src else None)
         got = tplio.oracle_search(frames[pic.poc], refs, p)
-        exp = tplio.expected_from_reference(tb, ctrl)
+        exp = tplio.expected_from_reference(tb, ctrl, src_dist=src)
         assert_blocks_equal(got, exp, "%s poc %d" % (name, pic.poc))
+        n_src += int((exp["src_recon_error"] > 0).sum())
         n_blocks += int(exp["valid"].sum())
         n_intra += int((exp["valid"] & (exp["best_is_inter"] == 0)).sum())
     assert n_blocks > 0 and 0 < n_intra < n_blocks  # both outcomes occur in every case
+    assert (n_src > 0) == tplio.src_dist_available(per[0][0])
 
 
 @pytest.mark.parametrize("name", sorted(UNSUPPORTED_CASES))
 def test_oracle_refuses_the_levels_it_does_not_restate(name):
     frames, pics, per = load_case(name, UNSUPPORTED_CASES[name])
-    ctrl, me, tb = per[0]
-    assert not (ctrl["tpl_opt_flag"] and ctrl["use_pred_sad_in_intra_search"] and ctrl["use_pred_sad_in_inter_search"])
+    ctrl, me, tb, quant = per[0]
+    assert not ctrl["tpl_opt_flag"]
     p, keep, refs = picture_of(frames, pics[0], ctrl, me)
     with pytest.raises(RuntimeError, match="-5"):
         tplio.oracle_search(frames[pics[0].poc], refs, p)
@@ -78,7 +91,7 @@ def test_block_geometry_follows_the_dispensers_tables():
     assert tplio.BLOCK_GEOMETRY[5:9] == [(0, 0, 16), (16, 0, 16), (0, 16, 16), (16, 16, 16)]
     assert tplio.BLOCK_GEOMETRY[9] == (32, 0, 16) and tplio.BLOCK_GEOMETRY[20] == (48, 48, 16)
     frames, pics, per = load_case("tpl7_m11_328x200", CASES["tpl7_m11_328x200"])
-    ctrl, me, tb = per[0]
+    ctrl, me, tb, quant = per[0]
     w, h = 328, 200
     for b64 in range(tb.shape[0]):
         sx, sy = (b64 % 6) * 64, (b64 // 6) * 64
@@ -92,7 +105,7 @@ def test_i_slice_and_skipped_references():
     """No candidates on an I slice (best_rf_idx -1, DC wins); a skipped reference's candidates do not count."""
     frames, pics, per = load_case("tpl4_m8_200x136", CASES["tpl4_m8_200x136"])
     pic = next(p for p in pics if p.is_ref and len(p.refs[0]) + len(p.refs[1]) >= 2)
-    ctrl, me, tb = per[pics.index(pic)]
+    ctrl, me, tb, quant = per[pics.index(pic)]
     ctrl = dict(ctrl, disable_intra_pred=0)
     p, keep, refs = picture_of(frames, pic, ctrl, me, i_slice=1)
     got = tplio.oracle_search(frames[pic.poc], refs, p)
@@ -111,20 +124,20 @@ def test_i_slice_and_skipped_references():
 def test_candidate_of_a_missing_reference_is_an_error():
     frames, pics, per = load_case("tpl4_m8_200x136", CASES["tpl4_m8_200x136"])
     pic = next(p for p in pics if len(p.refs[1]) >= 1)
-    ctrl, me, tb = per[pics.index(pic)]
+    ctrl, me, tb, quant = per[pics.index(pic)]
     p, keep, refs = picture_of(frames, pic, ctrl, me, n_ref=(len(pic.refs[0]), 0))
     with pytest.raises(RuntimeError, match="-1"):
         tplio.oracle_search(frames[pic.poc], refs, p)
 
 
 @pytest.mark.skipif(not refio.have_reference(), reason="needs the reference build (oracle/_ref)")
-@pytest.mark.parametrize("name", ["tpl7_m11_328x200", "tpl4_m8_noise_192x128"])
+@pytest.mark.parametrize("name", ["tpl7_m11_328x200", "tpl4_m8_noise_192x128", "tpl3_m6_192x128"])
 def test_fixture_equals_a_fresh_reference_run(name):
     c = CASES[name]
     frames, pics, per = load_case(name, c)
     frames2, pics2, rc = support.make_job(**tpl_cases.job_args(c))
     hdr, recs = refio.run_reference_tpl(frames2, pics2, c["enc_mode"], c["level"], c["qp"], ref_counts=rc)
-    for (ctrl, me, tb), (pd, bd, tp, tb2) in zip(per, recs):
+    for (ctrl, me, tb, quant), (pd, bd, tp, tb2) in zip(per, recs):
         assert tb.tobytes() == tb2.tobytes() and ctrl == tplio.controls_of(tp)
 
 
@@ -137,12 +150,41 @@ def test_reference_digest_of_the_1080p_case():
     h = hashlib.sha256()
     for pic, (pd, bd, tp, tb) in zip(pics, recs):
         ctrl = tplio.controls_of(tp)
-        exp = tplio.expected_from_reference(tb, ctrl)
+        exp = tplio.expected_from_reference(tb, ctrl, src_dist=True)
         for f in SEARCH_FIELDS:
             h.update(np.ascontiguousarray(exp[f]).tobytes())
     want = json.load(open(os.path.join(GOLDEN, "tpl_digests.json")))[name]
     assert h.hexdigest() == want["sha256"]
     assert want["controls"] == [tplio.controls_of(r[2]) for r in recs]
     # the restatement on the last picture of the same run
-    p, keep, refs = picture_of(frames, pic, ctrl, tplio.me_inputs_of(pd, bd))
+    assert ctrl["pf_shape"] == 2 and want["quant"] == [list(q) for q in tplio.quant_of(tp)]
+    p, keep, refs = picture_of(frames, pic, ctrl, tplio.me_inputs_of(pd, bd), quant=tplio.quant_of(tp))
     assert_blocks_equal(tplio.oracle_search(frames[pic.poc], refs, p), exp, name)
+
+
+@pytest.mark.skipif(not refio.have_reference(), reason="needs the reference build (oracle/_ref)")
+def test_forward_dct_equals_the_references_on_random_and_extreme_residuals():
+    """The restatement's 16x16 forward DCT, shape by shape, against svt_av1_wht_fwd_txfm of the reference build: random
+    residuals of every magnitude, the extremes of 8-bit residuals (+-255 everywhere, checkerboards, single rows / columns)."""
+    rng = np.random.default_rng(7)
+    blocks = [rng.integers(-m, m + 1, (40, 16, 16)) for m in (1, 7, 60, 255)]
+    ext = np.zeros((8, 16, 16), np.int64)
+    ext[0] = 255
+    ext[1] = -255
+    ext[2] = 255 * (1 - 2 * ((np.arange(16)[:, None] + np.arange(16)[None, :]) & 1))
+    ext[3, 0, :] = 255
+    ext[4, :, 0] = -255
+    ext[5] = 255 * (1 - 2 * (np.arange(16)[None, :] & 1))
+    ext[6] = -255 * (1 - 2 * (np.arange(16)[:, None] & 1))
+    ext[7, 15, 15] = 255
+    blocks = np.concatenate(blocks + [ext]).astype(np.int16)
+    want = refio.reference_dct16(blocks)
+    for shape in range(3):
+        for i, b in enumerate(blocks):
+            got = tplio.oracle_fwd_dct16x16(b, shape)
+            assert np.array_equal(got, want[shape, i]), (shape, i)
+    keep = {1: 8, 2: 4}
+    for shape, k in keep.items():  # the reduced shapes are the whole transform with everything outside the corner zeroed
+        m = np.zeros((16, 16), bool)
+        m[:k, :k] = True
+        assert np.array_equal(want[shape], np.where(m, want[0], 0))

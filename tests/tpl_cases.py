@@ -14,18 +14,22 @@ CASES = {
     "tpl4_m9_flat_128x128": dict(width=128, height=128, n_frames=5, enc_mode=9, seed=86, structure="ra", level=4, qp=32, kind="flat"),
     # low delay, one list; large motion so that vectors reach the clamp at the picture border
     "tpl4_m7_ldp_256x192": dict(width=256, height=192, n_frames=6, enc_mode=7, seed=87, structure="ldp", level=4, qp=28, motion=(14, -11)),
+    # transform-domain costs (level 3: M6; level 2 is level 3 with intra prediction in every picture), whole 16x16 DCT
+    "tpl3_m6_192x128": dict(width=192, height=128, n_frames=5, enc_mode=6, seed=88, structure="ra", level=3, qp=32),
+    "tpl2_m6_200x136": dict(width=200, height=136, n_frames=9, enc_mode=6, seed=91, structure="ra", level=2, qp=20),
+    "tpl3_m6_noise_128x128": dict(width=128, height=128, n_frames=5, enc_mode=6, seed=92, structure="ra", level=3, qp=55, kind="noise"),
 }
-# levels whose costs are transform-domain or that try every intra mode: the reference's records are kept so that the
+# level 1 (M5 and slower) tries twelve more intra modes and estimates a rate: the reference's record is kept so that the
 # restatement's and the engine's refusal is a statement about known behaviour, not about missing data
 UNSUPPORTED_CASES = {
-    "tpl3_m6_192x128": dict(width=192, height=128, n_frames=5, enc_mode=6, seed=88, structure="ra", level=3, qp=32),
     "tpl1_m3_128x128": dict(width=128, height=128, n_frames=5, enc_mode=3, seed=89, structure="ra", level=1, qp=32),
 }
 # the benchmark's 1080p preset-8 shape: a digest of the reference's results only
 DIGEST_CASES = {
     "tpl4_m8_1920x1080": dict(width=1920, height=1080, n_frames=5, enc_mode=8, seed=90, structure="ra", level=4, qp=32, motion=(5, -3)),
 }
-SEARCH_FIELDS = ("valid", "best_intra_cost", "best_inter_cost", "mv_x", "mv_y", "best_rf_idx", "best_is_inter", "best_intra_mode")
+SEARCH_FIELDS = ("valid", "best_intra_cost", "best_inter_cost", "mv_x", "mv_y", "best_rf_idx", "best_is_inter", "best_intra_mode",
+                 "src_recon_error")
 
 
 def job_args(c):

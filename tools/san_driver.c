@@ -386,9 +386,26 @@ static uint64_t run_extras(uint32_t w, uint32_t h, uint32_t seed, uint64_t hsh) 
                 if (!n_valid) EXPECT(-122, SVTME_OK);
                 hsh = fnv(hsh, blk, sizeof(*blk) * (size_t)n_b64 * SVTME_TPL_BLOCKS);
             }
-        tp.use_pred_sad_in_inter_search = 0;
+        /* transform-domain costs and the quantisation error of the chosen candidate: whole 16x16 transforms only */
+        tp.dispenser_search_level = 0;
+        tp.disable_intra_pred     = 0;
+        tp.src_dist               = 1;
+        tp.y_round_fp[0] = 20; tp.y_round_fp[1] = 24; tp.y_quant_fp[0] = 1638; tp.y_quant_fp[1] = 1365; tp.y_dequant[0] = 40; tp.y_dequant[1] = 48;
+        for (int shape = 0; shape < 3; ++shape)
+            for (int sad = 0; sad < 2; ++sad) {
+                tp.pf_shape = (uint8_t)shape;
+                tp.use_pred_sad_in_intra_search = tp.use_pred_sad_in_inter_search = (uint8_t)sad;
+                CHECK(svtme_tpl_search(eng, &tp, blk));
+                for (uint32_t i = 0; i < n_b64 * SVTME_TPL_BLOCKS; ++i)
+                    if (blk[i].valid && (blk[i].src_recon_error > 0) != (blk[i].best_is_inter != 0)) EXPECT(-123, SVTME_OK);
+                hsh = fnv(hsh, blk, sizeof(*blk) * (size_t)n_b64 * SVTME_TPL_BLOCKS);
+            }
+        tp.dispenser_search_level = 1; /* 32x32 blocks have no 16x16 transform */
         EXPECT(svtme_tpl_search(eng, &tp, blk), SVTME_ERR_UNSUPPORTED);
-        tp.use_pred_sad_in_inter_search = 1;
+        tp.dispenser_search_level = 0;
+        tp.tpl_opt_flag = 0; /* every intra mode */
+        EXPECT(svtme_tpl_search(eng, &tp, blk), SVTME_ERR_UNSUPPORTED);
+        tp.tpl_opt_flag = 1;
         tp.n_ref[1] = 0; /* the list-1 candidates now name a reference that was not handed over */
         EXPECT(svtme_tpl_search(eng, &tp, blk), SVTME_ERR_BAD_ARG);
         tp.n_ref[1] = 1;
