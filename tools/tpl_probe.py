@@ -40,7 +40,7 @@ def main():
                           max_refs=shape["max_refs"], max_cand=shape["max_cand"], max_l0=shape["max_l0"],
                           input_resolution=shape["input_resolution"], gm_enabled=1, gm_use_distance_based_active_th=1)
         ctrl_me = svtme.derive_controls(c["enc_mode"], w, h, 0, 30 << 16)
-        jobs = []
+        jobs, jobs_satd = [], []
         for pic, ctrl in zip(pics, want["controls"]):
             out = eng.run_picture(eng.make_picture(w, h, pic.poc, pic.temporal_layer, pic.is_ref, pic.refs, ctrl_me, tail=tail,
                                                    key_of=lambda poc: poc + 1))
@@ -48,17 +48,21 @@ def main():
                       me_candidate_array=out["me_candidate_array"][:, :85 * shape["max_cand"]],
                       me_mv_array=out["me_mv_array"][:, :85 * shape["max_refs"]], enable_me_16x16=shape["enable_me_16x16"],
                       max_cand=shape["max_cand"], max_refs=shape["max_refs"], max_l0=shape["max_l0"])
-            jobs.append(picture_of(frames, pic, ctrl, me))
-        for p, keep, refs in jobs:
-            eng.tpl_search(p)
-        reps = 50
-        t0 = time.perf_counter()
-        for _ in range(reps):
-            for p, keep, refs in jobs:
+            jobs.append(picture_of(frames, pic, ctrl, me, quant=want["quant"]))  # with the chosen candidate's quantisation error
+            satd = dict(ctrl, use_pred_sad_in_intra_search=0, use_pred_sad_in_inter_search=0, pf_shape=0)
+            jobs_satd.append(picture_of(frames, pic, satd, me, quant=want["quant"]))  # tpl level 3's costs on the same pictures
+        for what, js in (("SAD costs (tpl level 4) + quantisation error of the choice", jobs),
+                         ("transform-domain costs (tpl level 3) + quantisation error", jobs_satd)):
+            for p, keep, refs in js:
                 eng.tpl_search(p)
-        dt = (time.perf_counter() - t0) / (reps * len(jobs))
-        print("svtme_tpl_search, 1080p, %d blocks: %.3f ms per call (ME results in: %.2f MB, block records out: %.2f MB)"
-              % (8160, 1e3 * dt, 510 * 85 * (1 + shape["max_cand"] + 4 * shape["max_refs"]) / 1e6, 510 * 21 * 24 / 1e6))
+            reps = 50
+            t0 = time.perf_counter()
+            for _ in range(reps):
+                for p, keep, refs in js:
+                    eng.tpl_search(p)
+            dt = (time.perf_counter() - t0) / (reps * len(js))
+            print("svtme_tpl_search, 1080p, %d blocks, %s: %.3f ms per call (ME results in: %.2f MB, block records out: %.2f MB)"
+                  % (8160, what, 1e3 * dt, 510 * 85 * (1 + shape["max_cand"] + 4 * shape["max_refs"]) / 1e6, 510 * 21 * 32 / 1e6))
     finally:
         eng.close()
 
