@@ -466,8 +466,11 @@ int svtme_gm_frame_error(svtme_engine *e, uint64_t cur_key, uint64_t ref_key, in
  * src_dist = 1 adds what :935-982 derive from the chosen inter candidate: its residual's forward transform, quantised with
  * the picture's quantiser (svt_av1_quantize_fp, no quantisation matrices) and compared with the coefficients
  * (get_quantize_error, :167-193); src_recon_error is that function's recon_error, from which the encoder forms
- * srcrf_dist = (recon_error << TPL_DEP_COST_SCALE_LOG2) << subsample_tx. Available for 16x16 blocks with subsample_tx 0
- * (tpl levels 2-4); SVTME_ERR_UNSUPPORTED otherwise - the encoder then transforms the chosen candidate itself.
+ * srcrf_dist = (recon_error << TPL_DEP_COST_SCALE_LOG2) << subsample_tx. Available for the transforms the tpl levels use
+ * (tx_size_array / sub2_tx_size_array / sub4_tx_size_array, :543-545): 16x16, 16x8 and 16x4 on 16x16 blocks
+ * (dispenser_search_level 0, subsample_tx 0 / 1 / 2) and 32x8 on 32x32 blocks (level 1 with subsample_tx 2, whose
+ * incomplete 64x64 blocks take 16x4); SVTME_ERR_UNSUPPORTED otherwise - the encoder then transforms the chosen candidate
+ * itself.
  *
  * The ME results come in the layout of MeSbResults (EbMotionEstimationLcuResults.h:29-52), n_pu entries per 64x64 block
  * (SQUARE_PU_COUNT or MAX_SB64_PU_COUNT_NO_8X8), one 64x64 block after the other. Synchronous; takes turns with the

@@ -868,8 +868,9 @@ static void tpl_fill_from_engine(Shim *s, const Job *job, uint32_t pi, PicState 
     d.enable_me_16x16              = pcs->enable_me_16x16;
     d.subsample_tx                 = tc->subsample_tx;
     d.pf_shape                     = (uint8_t)tc->pf_shape;
-    /* whole 16x16 transforms: the engine also transforms and quantises the candidate it chose */
-    d.src_dist = tc->dispenser_search_level == 0 && tc->subsample_tx == 0;
+    /* the engine also transforms and quantises the candidate it chose, for the transforms the tpl levels use (16x16, 16x8,
+     * 16x4 on 16x16 blocks, 32x8 on 32x32 blocks); for another combination the lines below do it with the reference's own */
+    d.src_dist = tc->dispenser_search_level == 0 || (tc->dispenser_search_level == 1 && tc->subsample_tx == 2);
     for (int k = 0; k < 2; ++k) {
         d.y_round_fp[k] = scs->quants_8bit.y_round_fp[t->qindex][k];
         d.y_quant_fp[k] = scs->quants_8bit.y_quant_fp[t->qindex][k];
@@ -986,16 +987,24 @@ static void run_pic(const Job *job, uint32_t pi, PicState *st, uint32_t threads,
     free(tid); free(wk);
 }
 
-/* ref_me dct16 <in> <out>: the reference's forward transform as the TPL dispenser calls it (svt_av1_wht_fwd_txfm, TX_16X16,
- * 8 bit) on every 16x16 residual block of <in> (int16 [n][256]), for DEFAULT_SHAPE, N2_SHAPE and N4_SHAPE: int32 [3][n][256]. */
-static int dct16_main(const char *in_path, const char *out_path) {
+/* ref_me dct <w> <h> <in> <out>: the reference's forward transform as the TPL dispenser calls it (svt_av1_wht_fwd_txfm, 8 bit)
+ * on every w x h residual block of <in> (int16 [n][h][w]), for DEFAULT_SHAPE, N2_SHAPE and N4_SHAPE: int32 [3][n][h][w].
+ * Sizes: the dispenser's own (tx_size_array / sub2_tx_size_array / sub4_tx_size_array, :543-545) up to 32 wide. */
+static int dct_main(int w, int h, const char *in_path, const char *out_path) {
+    TxSize tx;
+    if (w == 16 && h == 16) tx = TX_16X16;
+    else if (w == 16 && h == 8) tx = TX_16X8;
+    else if (w == 16 && h == 4) tx = TX_16X4;
+    else if (w == 32 && h == 8) tx = TX_32X8;
+    else die("dct: size not among the dispenser's");
+    const size_t px = (size_t)w * h;
     FILE *f = fopen(in_path, "rb");
     if (!f) die("cannot open the block file");
     fseek(f, 0, SEEK_END);
-    const long n = ftell(f) / (256 * 2);
+    const long n = ftell(f) / (long)(px * 2);
     fseek(f, 0, SEEK_SET);
-    int16_t *blocks = (int16_t *)malloc((size_t)n * 512);
-    if (fread(blocks, 512, (size_t)n, f) != (size_t)n) die("short block file");
+    int16_t *blocks = (int16_t *)malloc((size_t)n * px * 2);
+    if (fread(blocks, px * 2, (size_t)n, f) != (size_t)n) die("short block file");
     fclose(f);
     setup_common_rtcd_internal(0);
     setup_rtcd_internal(0);
@@ -1004,10 +1013,10 @@ static int dct16_main(const char *in_path, const char *out_path) {
     const EB_TRANS_COEFF_SHAPE shapes[3] = {DEFAULT_SHAPE, N2_SHAPE, N4_SHAPE};
     for (int s = 0; s < 3; ++s)
         for (long i = 0; i < n; ++i) {
-            int32_t coeff[256];
+            int32_t coeff[32 * 32];
             memset(coeff, 0, sizeof(coeff));
-            svt_av1_wht_fwd_txfm(blocks + i * 256, 16, coeff, TX_16X16, shapes[s], 8, 0);
-            fwrite(coeff, sizeof(coeff), 1, o);
+            svt_av1_wht_fwd_txfm(blocks + i * px, w, coeff, tx, shapes[s], 8, 0);
+            fwrite(coeff, sizeof(int32_t), px, o);
         }
     fclose(o);
     free(blocks);
@@ -1015,7 +1024,7 @@ static int dct16_main(const char *in_path, const char *out_path) {
 }
 
 int main(int argc, char **argv) {
-    if (argc == 4 && !strcmp(argv[1], "dct16")) return dct16_main(argv[2], argv[3]);
+    if (argc == 6 && !strcmp(argv[1], "dct")) return dct_main(atoi(argv[2]), atoi(argv[3]), argv[4], argv[5]);
     if (argc < 3) die("usage: ref_me <job> <out>");
     FILE *f = fopen(argv[1], "rb");
     if (!f) die("cannot open job file");

@@ -190,15 +190,16 @@ def run_reference_tpl(frames, pics, enc_mode, tpl_level, qp, library=None, **kw)
                       tpl=(tpl_level, qp), **kw)
 
 
-def reference_dct16(blocks):
-    """The reference's forward transform of the TPL dispenser (svt_av1_wht_fwd_txfm, TX_16X16) on int16 residual blocks
-    [n, 16, 16]: int32 [3, n, 16, 16] for DEFAULT_SHAPE, N2_SHAPE, N4_SHAPE."""
+def reference_dct(blocks):
+    """The reference's forward transform of the TPL dispenser (svt_av1_wht_fwd_txfm) on int16 residual blocks [n, h, w] with
+    (w, h) one of (16, 16), (16, 8), (16, 4), (32, 8): int32 [3, n, h, w] for DEFAULT_SHAPE, N2_SHAPE, N4_SHAPE."""
     blocks = np.ascontiguousarray(blocks, np.int16)
+    n, h, w = blocks.shape
     with tempfile.TemporaryDirectory(prefix="svtme_") as td:
         a, b = os.path.join(td, "in.bin"), os.path.join(td, "out.bin")
         blocks.tofile(a)
-        subprocess.run([REF_BIN, "dct16", a, b], check=True, timeout=120)
-        return np.fromfile(b, np.int32).reshape(3, len(blocks), 16, 16)
+        subprocess.run([REF_BIN, "dct", str(w), str(h), a, b], check=True, timeout=120)
+        return np.fromfile(b, np.int32).reshape(3, n, h, w)
 
 
 def run_oracle(frames, pics, enc_mode, **kw):

@@ -66,44 +66,57 @@ static int dc_value(const plane *cur, int x, int y, int size) {
 }
 
 
-/* ---- the 16x16 forward DCT the dispenser costs residuals with: svt_av1_wht_fwd_txfm (EbTransforms.c:3815-3830) ->
- * svt_av1_fwd_txfm2d_16x16 (av1_tranform_two_d_core_c, :2301-2370, with fwd_shift_16x16 = {2, -2, 0} and cosine bits 13 for
- * the columns and 12 for the rows, EbTransforms.h:28, :46-57) over the 16-point butterfly network of svt_av1_fdct16_new
- * (:183-336). Every rounding of the network is a two-term rotation r(a, ca, b, cb) = (a ca + b cb + 2^(bit-1)) >> bit
- * (half_btf, EbInvTransforms.h:289-300); sums and differences are exact, so the network may be written part by part
- * (4-point core, odd half of the 8-point, odd half of the 16-point) instead of stage by stage. c[k] = cos(k pi / 128)
- * rounded to `bit` fractional bits (cospi_arr). The N2 / N4 shapes (:5392, :6998) keep the top-left 8x8 / 4x4
- * coefficients of the same transform and zero the rest. */
+/* ---- the forward DCT the dispenser costs residuals with: svt_av1_wht_fwd_txfm (EbTransforms.c:3815-3830) ->
+ * svt_av1_fwd_txfm2d_WxH (av1_tranform_two_d_core_c, :2301-2370): input << shift[0], an H-point transform of every column,
+ * rounded >> -shift[1], a W-point transform of every row, x sqrt(2) where W : H is 2 : 1; shifts and cosine bits per size:
+ * EbTransforms.h:26-57. The 1-D transforms are the butterfly networks of svt_av1_fdct4_new .. svt_av1_fdct32_new
+ * (:183-677). Every rounding of a network is a two-term rotation r(a, ca, b, cb) = (a ca + b cb + 2^(bit-1)) >> bit
+ * (half_btf, EbInvTransforms.h:289-300); sums and differences are exact, so a network may be written part by part - the
+ * N-point transform is the N/2-point transform of the mirrored sums (even outputs) plus an "odd half" of the mirrored
+ * differences - instead of stage by stage. c[k] = cos(k pi / 128) rounded to `bit` fractional bits (cospi_arr). The
+ * N2 / N4 shapes (:5392, :6998) keep the top-left (W/2 x H/2) / (W/4 x H/4) coefficients of the same transform and zero
+ * the rest. */
 static int32_t rot(int32_t a, int32_t ca, int32_t b, int32_t cb, int bit) {
     return (int32_t)(((int64_t)a * ca + (int64_t)b * cb + ((int64_t)1 << (bit - 1))) >> bit);
 }
 
-static void fdct16(const int32_t *x, int32_t *X, int bit) {
-    int32_t c[64];
+static void cos_table(int32_t c[64], int bit) {
     for (int k = 0; k < 64; ++k) c[k] = (int32_t)lround(cos(k * 3.14159265358979323846 / 128.0) * (double)(1 << bit));
-    int32_t s[8], d[8];
+}
+
+/* X[0], X[1], X[2], X[3] of the 4-point transform */
+static void fdct4(const int32_t *x, int32_t *X, const int32_t *c, int bit) {
+    const int32_t a0 = x[0] + x[3], a1 = x[1] + x[2], a2 = x[1] - x[2], a3 = x[0] - x[3];
+    X[0] = rot(a0, c[32], a1, c[32], bit);
+    X[2] = rot(a0, c[32], a1, -c[32], bit);
+    X[1] = rot(a2, c[48], a3, c[16], bit);
+    X[3] = rot(a3, c[48], a2, -c[16], bit);
+}
+
+static void fdct8(const int32_t *x, int32_t *X, const int32_t *c, int bit) {
+    int32_t p[4], q[4], E[4];
+    for (int i = 0; i < 4; ++i) {
+        p[i] = x[i] + x[7 - i];
+        q[i] = x[3 - i] - x[4 + i];
+    }
+    fdct4(p, E, c, bit);
+    for (int i = 0; i < 4; ++i) X[2 * i] = E[i];
+    const int32_t m1 = rot(q[2], c[32], q[1], -c[32], bit), m2 = rot(q[2], c[32], q[1], c[32], bit);
+    const int32_t e0 = q[0] + m1, e1 = q[0] - m1, e2 = q[3] - m2, e3 = q[3] + m2;
+    X[1] = rot(e0, c[56], e3, c[8], bit);
+    X[5] = rot(e1, c[24], e2, c[40], bit);
+    X[3] = rot(e2, c[24], e1, -c[40], bit);
+    X[7] = rot(e3, c[56], e0, -c[8], bit);
+}
+
+static void fdct16(const int32_t *x, int32_t *X, const int32_t *c, int bit) {
+    int32_t s[8], d[8], E[8];
     for (int i = 0; i < 8; ++i) {
         s[i] = x[i] + x[15 - i];
         d[i] = x[7 - i] - x[8 + i];
     }
-    /* even half: the 8-point transform of s */
-    int32_t p[4], q[4];
-    for (int i = 0; i < 4; ++i) {
-        p[i] = s[i] + s[7 - i];
-        q[i] = s[3 - i] - s[4 + i];
-    }
-    const int32_t a0 = p[0] + p[3], a1 = p[1] + p[2], a2 = p[1] - p[2], a3 = p[0] - p[3];
-    X[0]  = rot(a0, c[32], a1, c[32], bit);
-    X[8]  = rot(a0, c[32], a1, -c[32], bit);
-    X[4]  = rot(a2, c[48], a3, c[16], bit);
-    X[12] = rot(a3, c[48], a2, -c[16], bit);
-    const int32_t m1 = rot(q[2], c[32], q[1], -c[32], bit), m2 = rot(q[2], c[32], q[1], c[32], bit);
-    const int32_t e0 = q[0] + m1, e1 = q[0] - m1, e2 = q[3] - m2, e3 = q[3] + m2;
-    X[2]  = rot(e0, c[56], e3, c[8], bit);
-    X[10] = rot(e1, c[24], e2, c[40], bit);
-    X[6]  = rot(e2, c[24], e1, -c[40], bit);
-    X[14] = rot(e3, c[56], e0, -c[8], bit);
-    /* odd half */
+    fdct8(s, E, c, bit);
+    for (int i = 0; i < 8; ++i) X[2 * i] = E[i];
     const int32_t g2 = rot(d[5], c[32], d[2], -c[32], bit), g5 = rot(d[5], c[32], d[2], c[32], bit);
     const int32_t g3 = rot(d[4], c[32], d[3], -c[32], bit), g4 = rot(d[4], c[32], d[3], c[32], bit);
     const int32_t h0 = d[0] + g3, h3 = d[0] - g3, h1 = d[1] + g2, h2 = d[1] - g2;
@@ -122,18 +135,95 @@ static void fdct16(const int32_t *x, int32_t *X, int bit) {
     X[15] = rot(n7, c[60], n0, -c[4], bit);
 }
 
-/* residual [16][16] (row-major) -> coefficients [16][16]; shape 0 / 1 / 2 = all / top-left 8x8 / top-left 4x4 */
-void orc_tpl_fwd_dct16x16(const int16_t *residual, int32_t *coeff, int shape) {
-    int32_t buf[256], in[16], out[16];
-    for (int col = 0; col < 16; ++col) {
-        for (int r = 0; r < 16; ++r) in[r] = residual[r * 16 + col] * 4; /* shift[0] = 2 */
-        fdct16(in, out, 13);
-        for (int r = 0; r < 16; ++r) buf[r * 16 + col] = (out[r] + 2) >> 2; /* shift[1] = -2 */
+static void fdct32(const int32_t *x, int32_t *X, const int32_t *c, int bit) {
+    int32_t s[16], o[16], t[16], E[16];
+    for (int i = 0; i < 16; ++i) {
+        s[i] = x[i] + x[31 - i];
+        o[i] = x[15 - i] - x[16 + i];
     }
-    for (int r = 0; r < 16; ++r) fdct16(buf + r * 16, coeff + r * 16, 12); /* shift[2] = 0 */
-    const int keep = shape == 2 ? 4 : (shape == 1 ? 8 : 16);
-    for (int i = 0; i < 256; ++i)
-        if ((i & 15) >= keep || (i >> 4) >= keep) coeff[i] = 0;
+    fdct16(s, E, c, bit);
+    for (int i = 0; i < 16; ++i) X[2 * i] = E[i];
+    /* the odd half: rotations by pi/4 of the inner eight, sums, rotations by pi/8 multiples, sums, by pi/16 multiples,
+     * sums, and the sixteen output rotations */
+    for (int j = 4; j < 8; ++j) {
+        const int32_t lo = o[j], hi = o[15 - j];
+        o[j]      = rot(hi, c[32], lo, -c[32], bit);
+        o[15 - j] = rot(hi, c[32], lo, c[32], bit);
+    }
+    for (int j = 0; j < 4; ++j) {
+        t[j]      = o[j] + o[7 - j];
+        t[7 - j]  = o[j] - o[7 - j];
+        t[8 + j]  = o[15 - j] - o[8 + j];
+        t[15 - j] = o[15 - j] + o[8 + j];
+    }
+    o[0] = t[0], o[1] = t[1], o[6] = t[6], o[7] = t[7], o[8] = t[8], o[9] = t[9], o[14] = t[14], o[15] = t[15];
+    o[2]  = rot(t[13], c[48], t[2], -c[16], bit);
+    o[3]  = rot(t[12], c[48], t[3], -c[16], bit);
+    o[4]  = rot(t[4], -c[48], t[11], -c[16], bit);
+    o[5]  = rot(t[5], -c[48], t[10], -c[16], bit);
+    o[10] = rot(t[10], c[48], t[5], -c[16], bit);
+    o[11] = rot(t[11], c[48], t[4], -c[16], bit);
+    o[12] = rot(t[12], c[16], t[3], c[48], bit);
+    o[13] = rot(t[13], c[16], t[2], c[48], bit);
+    t[0] = o[0] + o[3], t[1] = o[1] + o[2], t[2] = o[1] - o[2], t[3] = o[0] - o[3];
+    t[4] = o[7] - o[4], t[5] = o[6] - o[5], t[6] = o[6] + o[5], t[7] = o[7] + o[4];
+    t[8] = o[8] + o[11], t[9] = o[9] + o[10], t[10] = o[9] - o[10], t[11] = o[8] - o[11];
+    t[12] = o[15] - o[12], t[13] = o[14] - o[13], t[14] = o[14] + o[13], t[15] = o[15] + o[12];
+    o[0] = t[0], o[3] = t[3], o[4] = t[4], o[7] = t[7], o[8] = t[8], o[11] = t[11], o[12] = t[12], o[15] = t[15];
+    o[1]  = rot(t[14], c[56], t[1], -c[8], bit);
+    o[2]  = rot(t[2], -c[56], t[13], -c[8], bit);
+    o[5]  = rot(t[10], c[24], t[5], -c[40], bit);
+    o[6]  = rot(t[6], -c[24], t[9], -c[40], bit);
+    o[9]  = rot(t[9], c[24], t[6], -c[40], bit);
+    o[10] = rot(t[10], c[40], t[5], c[24], bit);
+    o[13] = rot(t[13], c[56], t[2], -c[8], bit);
+    o[14] = rot(t[14], c[8], t[1], c[56], bit);
+    t[0] = o[0] + o[1], t[1] = o[0] - o[1], t[2] = o[3] - o[2], t[3] = o[3] + o[2];
+    t[4] = o[4] + o[5], t[5] = o[4] - o[5], t[6] = o[7] - o[6], t[7] = o[7] + o[6];
+    t[8] = o[8] + o[9], t[9] = o[8] - o[9], t[10] = o[11] - o[10], t[11] = o[11] + o[10];
+    t[12] = o[12] + o[13], t[13] = o[12] - o[13], t[14] = o[15] - o[14], t[15] = o[15] + o[14];
+    /* output 2 m + 1 comes from the pair (t[j], t[15 - j]) with j the 4-bit reversal of m for m < 8, mirrored above */
+    static const uint8_t angle[8] = {62, 30, 46, 14, 54, 22, 38, 6}; /* cosine index of t[j] in output rotation j */
+    static const uint8_t where[8] = {1, 17, 9, 25, 5, 21, 13, 29};   /* output index of rotation j (bit reversal) */
+    for (int j = 0; j < 8; ++j) {
+        X[where[j]]      = rot(t[j], c[angle[j]], t[15 - j], c[64 - angle[j]], bit);
+        X[32 - where[j]] = rot(t[15 - j], c[angle[j]], t[j], -c[64 - angle[j]], bit);
+    }
+}
+
+static void fdct(int n, const int32_t *x, int32_t *X, const int32_t *c, int bit) {
+    if (n == 4) fdct4(x, X, c, bit);
+    else if (n == 8) fdct8(x, X, c, bit);
+    else if (n == 16) fdct16(x, X, c, bit);
+    else fdct32(x, X, c, bit);
+}
+
+/* residual [h][w] (row-major, pitch w) -> coefficients [h][w]; (w, h) one of (16, 16), (16, 8), (16, 4), (32, 8);
+ * shape 0 / 1 / 2 = all / the top-left half / quarter in each direction. Returns 0, or -1 for another size. */
+int orc_tpl_fwd_dct(const int16_t *residual, int w, int h, int32_t *coeff, int shape) {
+    int shift1, bit_col = 13, bit_row; /* shift[0] = 2 and shift[2] = 0 for all four */
+    if (w == 16 && h == 16) shift1 = 2, bit_row = 12;
+    else if (w == 16 && h == 8) shift1 = 2, bit_row = 13;
+    else if (w == 16 && h == 4) shift1 = 1, bit_row = 13;
+    else if (w == 32 && h == 8) shift1 = 2, bit_row = 12;
+    else return -1;
+    int32_t cc[64], cr[64], buf[32 * 16], in[32], out[32];
+    cos_table(cc, bit_col);
+    cos_table(cr, bit_row);
+    for (int col = 0; col < w; ++col) {
+        for (int r = 0; r < h; ++r) in[r] = residual[r * w + col] * 4;
+        fdct(h, in, out, cc, bit_col);
+        for (int r = 0; r < h; ++r) buf[r * w + col] = (out[r] + (1 << (shift1 - 1))) >> shift1;
+    }
+    for (int r = 0; r < h; ++r) {
+        fdct(w, buf + r * w, coeff + r * w, cr, bit_row);
+        if (w == 2 * h) /* NewSqrt2 = 5793 with 12 fractional bits */
+            for (int col = 0; col < w; ++col) coeff[r * w + col] = (int32_t)(((int64_t)coeff[r * w + col] * 5793 + 2048) >> 12);
+    }
+    const int kw = w >> shape, kh = h >> shape;
+    for (int i = 0; i < w * h; ++i)
+        if (i % w >= kw || i / w >= kh) coeff[i] = 0;
+    return 0;
 }
 
 /* svt_aom_satd: common_dsp_rtcd.c:47-54 */
@@ -143,11 +233,11 @@ static int64_t satd256(const int32_t *coeff) {
     return sum;
 }
 
-/* get_quantize_error (:167-193) for TX_16X16: svt_av1_quantize_fp_c (EbFullLoop.c:318-405, no quantisation matrix, log
- * scale 0), svt_av1_block_error_c, >> 2, at least 1 */
-int64_t orc_tpl_quantize_error16x16(const int32_t *coeff, const int16_t round_fp[2], const int16_t quant_fp[2], const int16_t dequant[2]) {
+/* get_quantize_error (:167-193) for a transform of n coefficients other than TX_32X32: svt_av1_quantize_fp_c
+ * (EbFullLoop.c:318-405, no quantisation matrix, log scale 0), svt_av1_block_error_c, >> 2, at least 1 */
+int64_t orc_tpl_quantize_error(const int32_t *coeff, int n, const int16_t round_fp[2], const int16_t quant_fp[2], const int16_t dequant[2]) {
     int64_t err = 0;
-    for (int i = 0; i < 256; ++i) {
+    for (int i = 0; i < n; ++i) {
         const int     ac = i != 0, v = coeff[i], neg = v < 0;
         int64_t       a = neg ? -(int64_t)v : v;
         int32_t       dq = 0;
@@ -168,8 +258,11 @@ int orc_tpl_search(const uint8_t *cur_pix, int stride, const uint8_t *const ref_
                    const svtme_tpl_picture *p, svtme_tpl_block *out) {
     if (!p->tpl_opt_flag || p->pf_shape > 2) return SVTME_ERR_UNSUPPORTED;
     const int sad_intra = p->use_pred_sad_in_intra_search, sad_inter = p->use_pred_sad_in_inter_search;
-    /* transform-domain costs and the source distortion: 16x16 blocks, whole transforms */
-    if ((!sad_intra || !sad_inter || p->src_dist) && (p->dispenser_search_level != 0 || p->subsample_tx != 0)) return SVTME_ERR_UNSUPPORTED;
+    /* transform-domain costs: 16x16 blocks, whole transforms. The source distortion: the transforms the tpl levels use
+     * (:543-545): 16x16, 16x8 and 16x4 (every 2nd / 4th row of a 16x16 block), 32x8 (every 4th row of a 32x32 block) */
+    if ((!sad_intra || !sad_inter) && (p->dispenser_search_level != 0 || p->subsample_tx != 0)) return SVTME_ERR_UNSUPPORTED;
+    if (p->src_dist && (p->subsample_tx > 2 || p->dispenser_search_level > 1 || (p->dispenser_search_level == 1 && p->subsample_tx != 2)))
+        return SVTME_ERR_UNSUPPORTED;
     const int   w = (int)p->width, h = (int)p->height, b64_w = (w + 63) / 64, b64_h = (h + 63) / 64;
     const plane cur = {cur_pix, stride, w, h};
     memset(out, 0, sizeof(*out) * (size_t)b64_w * b64_h * SVTME_TPL_BLOCKS);
@@ -203,7 +296,7 @@ int orc_tpl_search(const uint8_t *cur_pix, int stride, const uint8_t *const ref_
                         if (!sad_intra) res[r * 16 + c] = (int16_t)d;
                     }
                 if (!sad_intra) { /* :790-813 */
-                    orc_tpl_fwd_dct16x16(res, coeff, p->pf_shape);
+                    orc_tpl_fwd_dct(res, 16, 16, coeff, p->pf_shape);
                     sad = satd256(coeff);
                 }
                 o->best_intra_cost = sad;
@@ -228,22 +321,23 @@ int orc_tpl_search(const uint8_t *cur_pix, int stride, const uint8_t *const ref_
                 if (y + size + (mvy >> 3) > TPL_PAD + h - 1) mvy = (int16_t)(((TPL_PAD + h - 1) - (y + size)) << 3);
                 const plane rp = {ref_pix[list * SVTME_MAX_REFS + ref], stride, w, h};
                 int64_t     sad = 0;
-                int16_t     res[256];
-                int32_t     coeff[256];
+                int16_t     res[32 * 16];
+                int32_t     coeff[32 * 16];
+                const int   step = 1 << p->subsample_tx, tx_h = size >> p->subsample_tx; /* svt_aom_subtract_block, :950-957 */
                 for (int r = 0; r < size; ++r)
                     for (int cc = 0; cc < size; ++cc) {
                         const int d = pel(&cur, x + cc, y + r) - pel(&rp, x + (mvx >> 3) + cc, y + (mvy >> 3) + r);
                         sad += d < 0 ? -d : d;
-                        if (size == 16) res[r * 16 + cc] = (int16_t)d;
+                        if (size <= 32 && r % step == 0 && r / step < 16) res[(r / step) * size + cc] = (int16_t)d;
                     }
                 if (!sad_inter) { /* :894-917 */
-                    orc_tpl_fwd_dct16x16(res, coeff, p->pf_shape);
+                    orc_tpl_fwd_dct(res, 16, 16, coeff, p->pf_shape);
                     sad = satd256(coeff);
                 }
                 if (sad < o->best_inter_cost) {
                     if (p->src_dist) { /* what :935-982 make of the best candidate */
-                        if (sad_inter) orc_tpl_fwd_dct16x16(res, coeff, p->pf_shape);
-                        best_err = orc_tpl_quantize_error16x16(coeff, p->y_round_fp, p->y_quant_fp, p->y_dequant);
+                        if (sad_inter && orc_tpl_fwd_dct(res, size, tx_h, coeff, p->pf_shape)) return SVTME_ERR_UNSUPPORTED;
+                        best_err = orc_tpl_quantize_error(coeff, size * tx_h, p->y_round_fp, p->y_quant_fp, p->y_dequant);
                     }
                     o->best_inter_cost = sad;
                     o->best_rf_idx     = (int8_t)(list == 0 ? ref : 4 + ref); /* svt_get_ref_frame_type(list, ref) - 1 */

@@ -112,8 +112,9 @@ def controls_of(tp):
 
 
 def src_dist_available(ctrl):
-    """The source distortion (and transform-domain costs) exist for whole 16x16 transforms only."""
-    return ctrl["dispenser_search_level"] == 0 and ctrl["subsample_tx"] == 0
+    """The source distortion exists for the transforms the tpl levels use: 16x16, 16x8, 16x4 on 16x16 blocks, 32x8 on 32x32
+    blocks (whose incomplete 64x64 blocks fall back to 16x16 blocks with 16x4)."""
+    return ctrl["dispenser_search_level"] == 0 or (ctrl["dispenser_search_level"] == 1 and ctrl["subsample_tx"] == 2)
 
 
 def quant_of(tp):
@@ -146,12 +147,14 @@ def expected_from_reference(tb, ctrl, src_dist=False):
     return out
 
 
-def oracle_fwd_dct16x16(residual, shape=0):
-    """residual: int16 [16, 16] -> int32 [16, 16] coefficients of the restatement's forward DCT."""
+def oracle_fwd_dct(residual, shape=0):
+    """residual: int16 [h, w] -> int32 [h, w] coefficients of the restatement's forward DCT."""
     global _lib
     if _lib is None:
         _lib = ctypes.CDLL(ORACLE_LIB)
     r = np.ascontiguousarray(residual, np.int16)
-    out = np.zeros((16, 16), np.int32)
-    _lib.orc_tpl_fwd_dct16x16(r.ctypes.data_as(ctypes.c_void_p), out.ctypes.data_as(ctypes.c_void_p), int(shape))
+    h, w = r.shape
+    out = np.zeros((h, w), np.int32)
+    rc = _lib.orc_tpl_fwd_dct(r.ctypes.data_as(ctypes.c_void_p), w, h, out.ctypes.data_as(ctypes.c_void_p), int(shape))
+    assert rc == 0, (w, h)
     return out

@@ -1217,11 +1217,12 @@ extern "C" int svtme_tpl_search(svtme_engine *e, const svtme_tpl_picture *pic, s
         (pic->n_pu != SVTME_PU_COUNT && pic->n_pu != 21) || pic->max_cand == 0 || pic->max_refs == 0 ||
         pic->max_l0 + (pic->n_ref[1] ? pic->n_ref[1] : 0) > pic->max_refs || pic->n_ref[0] > pic->max_l0)
         return SVTME_ERR_BAD_ARG;
-    // the intra modes beyond DC are not on the device; transform-domain costs and the source distortion are there for whole
-    // 16x16 transforms
+    // the intra modes beyond DC are not on the device; transform-domain costs are there for whole 16x16 transforms, the
+    // source distortion for the transforms the tpl levels use: 16x16, 16x8, 16x4 on 16x16 blocks, 32x8 on 32x32 blocks
     if (!pic->tpl_opt_flag || pic->pf_shape > 2) return SVTME_ERR_UNSUPPORTED;
-    if ((!pic->use_pred_sad_in_intra_search || !pic->use_pred_sad_in_inter_search || pic->src_dist) &&
-        (pic->dispenser_search_level != 0 || pic->subsample_tx != 0))
+    if ((!pic->use_pred_sad_in_intra_search || !pic->use_pred_sad_in_inter_search) && (pic->dispenser_search_level != 0 || pic->subsample_tx != 0))
+        return SVTME_ERR_UNSUPPORTED;
+    if (pic->src_dist && (pic->subsample_tx > 2 || pic->dispenser_search_level > 1 || (pic->dispenser_search_level == 1 && pic->subsample_tx != 2)))
         return SVTME_ERR_UNSUPPORTED;
     DEVICE_OR_FAIL(e->cfg.device);
     std::lock_guard<std::mutex> gm_lock(e->gm.mu);
@@ -1229,7 +1230,8 @@ extern "C" int svtme_tpl_search(svtme_engine *e, const svtme_tpl_picture *pic, s
     const int b64_w = (int)(pic->width + 63) / 64, n_b64 = b64_w * ((int)(pic->height + 63) / 64);
     const size_t cnt_bytes = (size_t)n_b64 * pic->n_pu, cand_bytes = cnt_bytes * pic->max_cand, mv_bytes = cnt_bytes * pic->max_refs * 4;
     const size_t mv_off = (cnt_bytes + cand_bytes + 63) / 64 * 64, out_off = (mv_off + mv_bytes + 63) / 64 * 64;
-    const size_t out_bytes = (size_t)n_b64 * SVTME_TPL_BLOCKS * sizeof(svtme_tpl_block), err_off = out_off + out_bytes, total = err_off + 64;
+    const size_t out_bytes = (size_t)n_b64 * SVTME_TPL_BLOCKS * sizeof(svtme_tpl_block), err_off = out_off + out_bytes;
+    const size_t par_off = err_off + 64, total = par_off + (sizeof(TplParams) + 63) / 64 * 64; // the record travels with the ME results
     if (g.tpl_bytes < total) {
         if (g.d_tpl) (void)hipFree(g.d_tpl);
         if (g.h_tpl) (void)hipHostFree(g.h_tpl);
@@ -1276,14 +1278,15 @@ extern "C" int svtme_tpl_search(svtme_engine *e, const svtme_tpl_picture *pic, s
     p.sad_inter = pic->use_pred_sad_in_inter_search != 0;
     p.pf_shape  = pic->pf_shape;
     p.src_dist  = pic->src_dist != 0;
+    p.subsample_tx = pic->subsample_tx;
     for (int k = 0; k < 2; ++k) {
         p.round_fp[k] = pic->y_round_fp[k];
         p.quant_fp[k] = pic->y_quant_fp[k];
         p.dequant[k]  = pic->y_dequant[k];
     }
-    for (int k = 0; k < 16; ++k) { // cospi_arr(13) / (12) at every fourth angle (EbInvTransforms.h)
-        p.cos13[k] = (int32_t)lround(cos(4 * k * 3.14159265358979323846 / 128.0) * 8192.0);
-        p.cos12[k] = (int32_t)lround(cos(4 * k * 3.14159265358979323846 / 128.0) * 4096.0);
+    for (int k = 0; k < 32; ++k) { // cospi_arr(13) / (12) at every second angle (EbInvTransforms.h)
+        p.cos13[k] = (int32_t)lround(cos(2 * k * 3.14159265358979323846 / 128.0) * 8192.0);
+        p.cos12[k] = (int32_t)lround(cos(2 * k * 3.14159265358979323846 / 128.0) * 4096.0);
     }
     p.cnt   = g.d_tpl;
     p.cand  = g.d_tpl + cnt_bytes;
@@ -1293,11 +1296,13 @@ extern "C" int svtme_tpl_search(svtme_engine *e, const svtme_tpl_picture *pic, s
     memcpy(g.h_tpl, pic->total_me_candidate_index, cnt_bytes);
     memcpy(g.h_tpl + cnt_bytes, pic->me_candidate_array, cand_bytes);
     memcpy(g.h_tpl + mv_off, pic->me_mv_array, mv_bytes);
+    memcpy(g.h_tpl + par_off, &p, sizeof(p));
     const hipStream_t st = e->s_me[3];
     for (int k = 0; k < n_keys; ++k) GM_TRY(hipStreamWaitEvent(st, pl.ready[k], 0));
     GM_TRY(hipMemcpyAsync(g.d_tpl, g.h_tpl, mv_off + mv_bytes, hipMemcpyHostToDevice, st));
+    GM_TRY(hipMemcpyAsync(g.d_tpl + par_off, g.h_tpl + par_off, sizeof(p), hipMemcpyHostToDevice, st));
     GM_TRY(hipMemsetAsync(g.d_tpl + out_off, 0, out_bytes + 64, st));
-    launch_tpl_search(p, st);
+    launch_tpl_search(reinterpret_cast<const TplParams *>(g.d_tpl + par_off), n_b64, st);
     GM_TRY(hipGetLastError());
     GM_TRY(hipMemcpyAsync(g.h_tpl + out_off, g.d_tpl + out_off, out_bytes + 64, hipMemcpyDeviceToHost, st));
     GM_TRY(hipStreamSynchronize(st));

@@ -171,16 +171,16 @@ struct TplParams {
     int32_t  width, height, b64_w, n_b64;
     int32_t  level, disable_intra_pred, i_slice, enable_me_16x16; // svtme_tpl_picture's fields
     int32_t  n_pu, max_cand, max_refs, max_l0;
-    int32_t  sad_intra, sad_inter, pf_shape, src_dist;
+    int32_t  sad_intra, sad_inter, pf_shape, src_dist, subsample_tx;
     int32_t  round_fp[2], quant_fp[2], dequant[2]; // [dc, ac]
-    int32_t  cos13[16], cos12[16]; // cos(4 k pi / 128) with 13 / 12 fractional bits, k = 0..15
+    int32_t  cos13[32], cos12[32]; // cos(2 k pi / 128) with 13 / 12 fractional bits, k = 0..31
     const uint8_t  *cnt; // [n_b64][n_pu]
     const uint8_t  *cand; // [n_b64][n_pu * max_cand]
     const uint32_t *mv; // [n_b64][n_pu * max_refs]
     svtme_tpl_block *out; // [n_b64][SVTME_TPL_BLOCKS], zeroed
     int             *error; // bit 0: a candidate named a reference beyond n_ref
 };
-void launch_tpl_search(const TplParams &p, hipStream_t s);
+void launch_tpl_search(const TplParams *dev, int n_b64, hipStream_t s); // dev: the record in device memory
 
 int  occupancy_me_search();
 void occupancy_hme_items(int out[2]);

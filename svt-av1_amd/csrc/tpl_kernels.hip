@@ -17,93 +17,201 @@ constexpr int kTplPad = 32; // TPL_PADX, TPL_PADY: EbEncodeContext.h:43-44
 __constant__ const uint8_t kTplMeIndex[SVTME_TPL_BLOCKS] = {0, 1, 2, 3, 4, 5, 6, 9, 10, 7, 8, 11, 12, 13, 14, 17, 18, 15, 16, 19, 20};
 
 
-// ---- the 16x16 forward DCT of svt_av1_wht_fwd_txfm (EbTransforms.c:3815-3830 -> av1_tranform_two_d_core_c, :2301-2370:
-// input << 2, 16-point transform of every column with 13-bit cosines, rounded >> 2, 16-point transform of every row with
-// 12-bit cosines; fwd_shift_16x16 and the cosine bits: EbTransforms.h:28, :46-57). The 16-point network is
-// svt_av1_fdct16_new's (:183-336), written part by part: its only roundings are the two-term rotations
-// (a ca + b cb + 2^(bit-1)) >> bit (half_btf, EbInvTransforms.h:289-300), sums and differences are exact. With 8-bit
-// residuals every product stays below 2^30, so 32-bit arithmetic gives what the reference's 64-bit sums give.
+// ---- the forward DCT of svt_av1_wht_fwd_txfm (EbTransforms.c:3815-3830 -> av1_tranform_two_d_core_c, :2301-2370: input
+// << 2, an H-point transform of every column with 13-bit cosines, rounded >> 2 (>> 1 for 16x4), a W-point transform of every
+// row, x sqrt(2) where W : H is 2 : 1; shifts and cosine bits per size: EbTransforms.h:26-57). The 1-D transforms are the
+// butterfly networks of svt_av1_fdct4_new .. svt_av1_fdct32_new (:183-677), written part by part: the N-point transform is
+// the N/2-point transform of the mirrored sums (even outputs) plus an odd half of the mirrored differences; a network's
+// only roundings are its two-term rotations (a ca + b cb + 2^(bit-1)) >> bit (half_btf, EbInvTransforms.h:289-300), sums
+// and differences are exact. With 8-bit residuals every product stays below 2^30, so 32-bit arithmetic gives what the
+// reference's 64-bit sums give. c[k / 2] = cos(k pi / 128) with BIT fractional bits, k even.
 template <int BIT>
 __device__ __forceinline__ int32_t rot(int32_t a, int32_t ca, int32_t b, int32_t cb) {
     return (a * ca + b * cb + (1 << (BIT - 1))) >> BIT;
 }
+#define TPL_C(k) c[(k) >> 1]
 
-// c[k] = cos(4 k pi / 128) with BIT fractional bits
+typedef const int32_t __attribute__((address_space(4))) *CosTable; // a table of the picture's record (see ConstTplParams)
+
 template <int BIT>
-__device__ __forceinline__ void fdct16(const int32_t (&x)[16], int32_t (&X)[16], const int32_t *c) {
-    int32_t s[8], d[8];
+__device__ __forceinline__ void fdct_n(const int32_t (&x)[4], int32_t (&X)[4], CosTable c) {
+    const int32_t a0 = x[0] + x[3], a1 = x[1] + x[2], a2 = x[1] - x[2], a3 = x[0] - x[3];
+    X[0] = rot<BIT>(a0, TPL_C(32), a1, TPL_C(32));
+    X[2] = rot<BIT>(a0, TPL_C(32), a1, -TPL_C(32));
+    X[1] = rot<BIT>(a2, TPL_C(48), a3, TPL_C(16));
+    X[3] = rot<BIT>(a3, TPL_C(48), a2, -TPL_C(16));
+}
+
+template <int BIT>
+__device__ __forceinline__ void fdct_n(const int32_t (&x)[8], int32_t (&X)[8], CosTable c) {
+    int32_t p[4], q[4], E[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        p[i] = x[i] + x[7 - i];
+        q[i] = x[3 - i] - x[4 + i];
+    }
+    fdct_n<BIT>(p, E, c);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) X[2 * i] = E[i];
+    const int32_t m1 = rot<BIT>(q[2], TPL_C(32), q[1], -TPL_C(32)), m2 = rot<BIT>(q[2], TPL_C(32), q[1], TPL_C(32));
+    const int32_t e0 = q[0] + m1, e1 = q[0] - m1, e2 = q[3] - m2, e3 = q[3] + m2;
+    X[1] = rot<BIT>(e0, TPL_C(56), e3, TPL_C(8));
+    X[5] = rot<BIT>(e1, TPL_C(24), e2, TPL_C(40));
+    X[3] = rot<BIT>(e2, TPL_C(24), e1, -TPL_C(40));
+    X[7] = rot<BIT>(e3, TPL_C(56), e0, -TPL_C(8));
+}
+
+template <int BIT>
+__device__ __forceinline__ void fdct_n(const int32_t (&x)[16], int32_t (&X)[16], CosTable c) {
+    int32_t s[8], d[8], E[8];
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
         s[i] = x[i] + x[15 - i];
         d[i] = x[7 - i] - x[8 + i];
     }
-    // even half: the 8-point transform of s
-    const int32_t p0 = s[0] + s[7], p1 = s[1] + s[6], p2 = s[2] + s[5], p3 = s[3] + s[4];
-    const int32_t q0 = s[3] - s[4], q1 = s[2] - s[5], q2 = s[1] - s[6], q3 = s[0] - s[7];
-    const int32_t a0 = p0 + p3, a1 = p1 + p2, a2 = p1 - p2, a3 = p0 - p3;
-    X[0]  = rot<BIT>(a0, c[8], a1, c[8]);
-    X[8]  = rot<BIT>(a0, c[8], a1, -c[8]);
-    X[4]  = rot<BIT>(a2, c[12], a3, c[4]);
-    X[12] = rot<BIT>(a3, c[12], a2, -c[4]);
-    const int32_t m1 = rot<BIT>(q2, c[8], q1, -c[8]), m2 = rot<BIT>(q2, c[8], q1, c[8]);
-    const int32_t e0 = q0 + m1, e1 = q0 - m1, e2 = q3 - m2, e3 = q3 + m2;
-    X[2]  = rot<BIT>(e0, c[14], e3, c[2]);
-    X[10] = rot<BIT>(e1, c[6], e2, c[10]);
-    X[6]  = rot<BIT>(e2, c[6], e1, -c[10]);
-    X[14] = rot<BIT>(e3, c[14], e0, -c[2]);
-    // odd half
-    const int32_t g2 = rot<BIT>(d[5], c[8], d[2], -c[8]), g5 = rot<BIT>(d[5], c[8], d[2], c[8]);
-    const int32_t g3 = rot<BIT>(d[4], c[8], d[3], -c[8]), g4 = rot<BIT>(d[4], c[8], d[3], c[8]);
+    fdct_n<BIT>(s, E, c);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) X[2 * i] = E[i];
+    const int32_t g2 = rot<BIT>(d[5], TPL_C(32), d[2], -TPL_C(32)), g5 = rot<BIT>(d[5], TPL_C(32), d[2], TPL_C(32));
+    const int32_t g3 = rot<BIT>(d[4], TPL_C(32), d[3], -TPL_C(32)), g4 = rot<BIT>(d[4], TPL_C(32), d[3], TPL_C(32));
     const int32_t h0 = d[0] + g3, h3 = d[0] - g3, h1 = d[1] + g2, h2 = d[1] - g2;
     const int32_t h4 = d[7] - g4, h7 = d[7] + g4, h5 = d[6] - g5, h6 = d[6] + g5;
-    const int32_t k1 = rot<BIT>(h6, c[12], h1, -c[4]), k6 = rot<BIT>(h6, c[4], h1, c[12]);
-    const int32_t k2 = rot<BIT>(h2, -c[12], h5, -c[4]), k5 = rot<BIT>(h5, c[12], h2, -c[4]);
+    const int32_t k1 = rot<BIT>(h6, TPL_C(48), h1, -TPL_C(16)), k6 = rot<BIT>(h6, TPL_C(16), h1, TPL_C(48));
+    const int32_t k2 = rot<BIT>(h2, -TPL_C(48), h5, -TPL_C(16)), k5 = rot<BIT>(h5, TPL_C(48), h2, -TPL_C(16));
     const int32_t n0 = h0 + k1, n1 = h0 - k1, n2 = h3 - k2, n3 = h3 + k2;
     const int32_t n4 = h4 + k5, n5 = h4 - k5, n6 = h7 - k6, n7 = h7 + k6;
-    X[1]  = rot<BIT>(n0, c[15], n7, c[1]);
-    X[9]  = rot<BIT>(n1, c[7], n6, c[9]);
-    X[5]  = rot<BIT>(n2, c[11], n5, c[5]);
-    X[13] = rot<BIT>(n3, c[3], n4, c[13]);
-    X[3]  = rot<BIT>(n4, c[3], n3, -c[13]);
-    X[11] = rot<BIT>(n5, c[11], n2, -c[5]);
-    X[7]  = rot<BIT>(n6, c[7], n1, -c[9]);
-    X[15] = rot<BIT>(n7, c[15], n0, -c[1]);
+    X[1]  = rot<BIT>(n0, TPL_C(60), n7, TPL_C(4));
+    X[9]  = rot<BIT>(n1, TPL_C(28), n6, TPL_C(36));
+    X[5]  = rot<BIT>(n2, TPL_C(44), n5, TPL_C(20));
+    X[13] = rot<BIT>(n3, TPL_C(12), n4, TPL_C(52));
+    X[3]  = rot<BIT>(n4, TPL_C(12), n3, -TPL_C(52));
+    X[11] = rot<BIT>(n5, TPL_C(44), n2, -TPL_C(20));
+    X[7]  = rot<BIT>(n6, TPL_C(28), n1, -TPL_C(36));
+    X[15] = rot<BIT>(n7, TPL_C(60), n0, -TPL_C(4));
 }
 
-constexpr int kTplPitch = 17; // LDS row pitch in dwords: the 16 lanes of a pass read a column without bank conflicts
+template <int BIT>
+__device__ __forceinline__ void fdct_n(const int32_t (&x)[32], int32_t (&X)[32], CosTable c) {
+    int32_t s[16], o[16], t[16], E[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        s[i] = x[i] + x[31 - i];
+        o[i] = x[15 - i] - x[16 + i];
+    }
+    fdct_n<BIT>(s, E, c);
+#pragma unroll
+    for (int i = 0; i < 16; ++i) X[2 * i] = E[i];
+    // the odd half: rotations by pi/4 of the inner eight, sums, rotations by multiples of pi/8, sums, of pi/16, sums, and
+    // the sixteen output rotations
+#pragma unroll
+    for (int j = 4; j < 8; ++j) {
+        const int32_t lo = o[j], hi = o[15 - j];
+        o[j]      = rot<BIT>(hi, TPL_C(32), lo, -TPL_C(32));
+        o[15 - j] = rot<BIT>(hi, TPL_C(32), lo, TPL_C(32));
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        t[j]      = o[j] + o[7 - j];
+        t[7 - j]  = o[j] - o[7 - j];
+        t[8 + j]  = o[15 - j] - o[8 + j];
+        t[15 - j] = o[15 - j] + o[8 + j];
+    }
+    o[0] = t[0], o[1] = t[1], o[6] = t[6], o[7] = t[7], o[8] = t[8], o[9] = t[9], o[14] = t[14], o[15] = t[15];
+    o[2]  = rot<BIT>(t[13], TPL_C(48), t[2], -TPL_C(16));
+    o[3]  = rot<BIT>(t[12], TPL_C(48), t[3], -TPL_C(16));
+    o[4]  = rot<BIT>(t[4], -TPL_C(48), t[11], -TPL_C(16));
+    o[5]  = rot<BIT>(t[5], -TPL_C(48), t[10], -TPL_C(16));
+    o[10] = rot<BIT>(t[10], TPL_C(48), t[5], -TPL_C(16));
+    o[11] = rot<BIT>(t[11], TPL_C(48), t[4], -TPL_C(16));
+    o[12] = rot<BIT>(t[12], TPL_C(16), t[3], TPL_C(48));
+    o[13] = rot<BIT>(t[13], TPL_C(16), t[2], TPL_C(48));
+    t[0] = o[0] + o[3], t[1] = o[1] + o[2], t[2] = o[1] - o[2], t[3] = o[0] - o[3];
+    t[4] = o[7] - o[4], t[5] = o[6] - o[5], t[6] = o[6] + o[5], t[7] = o[7] + o[4];
+    t[8] = o[8] + o[11], t[9] = o[9] + o[10], t[10] = o[9] - o[10], t[11] = o[8] - o[11];
+    t[12] = o[15] - o[12], t[13] = o[14] - o[13], t[14] = o[14] + o[13], t[15] = o[15] + o[12];
+    o[0] = t[0], o[3] = t[3], o[4] = t[4], o[7] = t[7], o[8] = t[8], o[11] = t[11], o[12] = t[12], o[15] = t[15];
+    o[1]  = rot<BIT>(t[14], TPL_C(56), t[1], -TPL_C(8));
+    o[2]  = rot<BIT>(t[2], -TPL_C(56), t[13], -TPL_C(8));
+    o[5]  = rot<BIT>(t[10], TPL_C(24), t[5], -TPL_C(40));
+    o[6]  = rot<BIT>(t[6], -TPL_C(24), t[9], -TPL_C(40));
+    o[9]  = rot<BIT>(t[9], TPL_C(24), t[6], -TPL_C(40));
+    o[10] = rot<BIT>(t[10], TPL_C(40), t[5], TPL_C(24));
+    o[13] = rot<BIT>(t[13], TPL_C(56), t[2], -TPL_C(8));
+    o[14] = rot<BIT>(t[14], TPL_C(8), t[1], TPL_C(56));
+    t[0] = o[0] + o[1], t[1] = o[0] - o[1], t[2] = o[3] - o[2], t[3] = o[3] + o[2];
+    t[4] = o[4] + o[5], t[5] = o[4] - o[5], t[6] = o[7] - o[6], t[7] = o[7] + o[6];
+    t[8] = o[8] + o[9], t[9] = o[8] - o[9], t[10] = o[11] - o[10], t[11] = o[11] + o[10];
+    t[12] = o[12] + o[13], t[13] = o[12] - o[13], t[14] = o[15] - o[14], t[15] = o[15] + o[14];
+    // rotation j pairs t[j] with t[15 - j]; the outputs are in bit-reversed order
+#define TPL_OUT(j, angle, where)                                                          \
+    X[where]      = rot<BIT>(t[j], TPL_C(angle), t[15 - j], TPL_C(64 - angle));            \
+    X[32 - where] = rot<BIT>(t[15 - j], TPL_C(angle), t[j], -TPL_C(64 - angle))
+    TPL_OUT(0, 62, 1);
+    TPL_OUT(1, 30, 17);
+    TPL_OUT(2, 46, 9);
+    TPL_OUT(3, 14, 25);
+    TPL_OUT(4, 54, 5);
+    TPL_OUT(5, 22, 21);
+    TPL_OUT(6, 38, 13);
+    TPL_OUT(7, 6, 29);
+#undef TPL_OUT
+}
+#undef TPL_C
 
-// The residual src - prd of a 16x16 block (a lane holds 4 pixels of row lane >> 2) -> sum of the absolute coefficients of
-// its forward DCT (svt_aom_satd, common_dsp_rtcd.c:47-54) and, when `quant`, get_quantize_error's recon_error
-// (:167-193: svt_av1_quantize_fp_c without quantisation matrix, EbFullLoop.c:318-405, block error >> 2, at least 1), in
-// every lane. pf_shape N2 / N4 keep the top-left 8x8 / 4x4 coefficients (av1_tranform_two_d_core_N2_c / _N4_c).
-__device__ __forceinline__ void tpl_transform16(const TplParams &p, uint32_t src, uint32_t prd, int32_t *lds, bool quant, long long &satd,
-                                                long long &recon_error) {
-    const int lane = threadIdx.x & 63, r = lane >> 2, c4 = (lane & 3) * 4;
+constexpr int kTplLdsInts = 16 * 33; // a 32x8 or 16x16 residual with a pitch one dword over the width (no bank conflicts)
+
+// The residual src - prd of a block of side W whose transform takes every (W / H)-th row (a lane holds N dwords of 4 pixels:
+// dword lane + 64 k of the block's rows) -> sum of the absolute coefficients of its W x H forward DCT (svt_aom_satd,
+// common_dsp_rtcd.c:47-54) and, when `quant`, get_quantize_error's recon_error (:167-193: svt_av1_quantize_fp_c without
+// quantisation matrix, EbFullLoop.c:318-405, block error >> 2, at least 1), in every lane. pf_shape N2 / N4 keep the top-left
+// half / quarter of the coefficients in each direction (av1_tranform_two_d_core_N2_c / _N4_c). A lane per column, then a
+// lane per row, through LDS.
+// The picture's record lies in device memory and is read through the constant address space: lanes index its arrays
+// (reference planes, quantiser) with run-time values, which a kernel argument of this size would pay for with a private copy.
+typedef const TplParams __attribute__((address_space(4))) ConstTplParams;
+
+template <int W, int H, int N>
+__device__ __forceinline__ void tpl_transform(ConstTplParams &p, const uint32_t (&src)[N], const uint32_t (&prd)[N], int32_t *lds, bool quant,
+                                              long long &satd, long long &recon_error) {
+    constexpr int PITCH = W + 1, DW = W / 4, STEP = W / H, SHIFT1 = (W == 16 && H == 4) ? 1 : 2;
+    constexpr int BIT_ROW = ((W == 16 && H == 16) || W == 32) ? 12 : 13;
+    const int     lane = threadIdx.x & 63;
     wave_sync(); // the previous use of the buffer is over
 #pragma unroll
-    for (int j = 0; j < 4; ++j) lds[r * kTplPitch + c4 + j] = (int32_t)((src >> (8 * j)) & 0xff) - (int32_t)((prd >> (8 * j)) & 0xff);
-    wave_sync();
-    int32_t in[16], out[16];
-    if (lane < 16) {
+    for (int k = 0; k < N; ++k) {
+        const int idx = lane + 64 * k, r = idx / DW, d = idx % DW;
+        if (r % STEP == 0) {
 #pragma unroll
-        for (int i = 0; i < 16; ++i) in[i] = lds[i * kTplPitch + lane] * 4;
-        fdct16<13>(in, out, p.cos13);
+            for (int j = 0; j < 4; ++j)
+                lds[(r / STEP) * PITCH + 4 * d + j] = (int32_t)((src[k] >> (8 * j)) & 0xff) - (int32_t)((prd[k] >> (8 * j)) & 0xff);
+        }
     }
     wave_sync();
-    if (lane < 16) {
+    {
+        int32_t in[H], out[H];
+        if (lane < W) {
 #pragma unroll
-        for (int i = 0; i < 16; ++i) lds[i * kTplPitch + lane] = (out[i] + 2) >> 2;
+            for (int i = 0; i < H; ++i) in[i] = lds[i * PITCH + lane] * 4;
+            fdct_n<13>(in, out, p.cos13);
+        }
+        wave_sync();
+        if (lane < W) {
+#pragma unroll
+            for (int i = 0; i < H; ++i) lds[i * PITCH + lane] = (out[i] + (1 << (SHIFT1 - 1))) >> SHIFT1;
+        }
     }
     wave_sync();
     long long a_sum = 0, e_sum = 0;
-    const int keep = p.pf_shape == 2 ? 4 : (p.pf_shape == 1 ? 8 : 16);
-    if (lane < keep) {
+    const int kw = W >> p.pf_shape, kh = H >> p.pf_shape;
+    if (lane < kh) {
+        int32_t in[W], out[W];
 #pragma unroll
-        for (int i = 0; i < 16; ++i) in[i] = lds[lane * kTplPitch + i];
-        fdct16<12>(in, out, p.cos12);
+        for (int i = 0; i < W; ++i) in[i] = lds[lane * PITCH + i];
+        fdct_n<BIT_ROW>(in, out, BIT_ROW == 12 ? p.cos12 : p.cos13);
 #pragma unroll
-        for (int i = 0; i < 16; ++i) {
-            const int32_t v = i < keep ? out[i] : 0;
+        for (int i = 0; i < W; ++i) {
+            int32_t v = i < kw ? out[i] : 0;
+            if (W == 2 * H) v = (int32_t)(((long long)v * 5793 + 2048) >> 12); // NewSqrt2, 12 fractional bits
             const int32_t a = v < 0 ? -v : v;
             a_sum += a;
             if (quant) {
@@ -124,16 +232,16 @@ __device__ __forceinline__ void tpl_transform16(const TplParams &p, uint32_t src
         a_sum += __shfl_xor(a_sum, m);
         e_sum += __shfl_xor(e_sum, m);
     }
-    satd        = a_sum;
+    satd = a_sum;
     e_sum >>= 2;
     recon_error = e_sum < 1 ? 1 : e_sum;
 }
 
 template <int S>
-__device__ __forceinline__ void tpl_block(const TplParams &p, int b64, int bi, int x, int y, int32_t *lds) {
+__device__ __forceinline__ void tpl_block(ConstTplParams &p, int b64, int bi, int x, int y, int32_t *lds) {
     constexpr int DW = S / 4, N = S * S / 256; // dwords per row, dwords per lane
     const int     lane = threadIdx.x & 63;
-    const DevPlane cur = p.cur;
+    const DevPlane cur = load_plane(p.cur);
     uint32_t       src[N];
 #pragma unroll
     for (int k = 0; k < N; ++k) {
@@ -161,8 +269,9 @@ __device__ __forceinline__ void tpl_block(const TplParams &p, int b64, int bi, i
         best_intra = wave_sum(acc);
         if constexpr (S == 16) {
             if (!p.sad_intra) { // :790-813
-                long long err;
-                tpl_transform16(p, src[0], dc * 0x01010101u, lds, false, best_intra, err);
+                long long      err;
+                const uint32_t prd[1] = {dc * 0x01010101u};
+                tpl_transform<16, 16, 1>(p, src, prd, lds, false, best_intra, err);
             }
         }
     }
@@ -187,7 +296,7 @@ __device__ __forceinline__ void tpl_block(const TplParams &p, int b64, int bi, i
         if (x + S + (mvx >> 3) > kTplPad + p.width - 1) mvx = (int16_t)(((kTplPad + p.width - 1) - (x + S)) << 3);
         if (y + (mvy >> 3) < -kTplPad) mvy = (int16_t)((-kTplPad - y) << 3);
         if (y + S + (mvy >> 3) > kTplPad + p.height - 1) mvy = (int16_t)(((kTplPad + p.height - 1) - (y + S)) << 3);
-        const DevPlane rp  = p.ref[list][ref];
+        const DevPlane rp  = load_plane(p.ref[list][ref]);
         const uint8_t *org = rp.pix + (ptrdiff_t)(y + (mvy >> 3)) * rp.stride + x + (mvx >> 3);
         uint32_t       acc = 0;
 #pragma unroll
@@ -200,9 +309,9 @@ __device__ __forceinline__ void tpl_block(const TplParams &p, int b64, int bi, i
         long long sad = wave_sum(acc), err = 0;
         if constexpr (S == 16) {
             if (!p.sad_inter) { // :894-917
-                uint32_t f;
-                __builtin_memcpy(&f, org + (ptrdiff_t)(lane >> 2) * rp.stride + 4 * (lane & 3), 4);
-                tpl_transform16(p, src[0], f, lds, p.src_dist != 0, sad, err);
+                uint32_t f[1];
+                __builtin_memcpy(&f[0], org + (ptrdiff_t)(lane >> 2) * rp.stride + 4 * (lane & 3), 4);
+                tpl_transform<16, 16, 1>(p, src, f, lds, p.src_dist != 0, sad, err);
             }
         }
         if (sad < best_inter) { // strictly smaller: the first of equal candidates stays
@@ -214,13 +323,24 @@ __device__ __forceinline__ void tpl_block(const TplParams &p, int b64, int bi, i
         }
     }
     const bool is_inter = best_inter < best_intra; // :932-933
-    if constexpr (S == 16) {
+    if constexpr (S <= 32) {
         if (p.src_dist && p.sad_inter && is_inter) { // the transform of the chosen candidate (:938-970)
-            const DevPlane rp = p.ref[best_rf >> 2][best_rf & 3];
-            uint32_t       f;
-            __builtin_memcpy(&f, rp.pix + (ptrdiff_t)(y + (best_mvy >> 3) + (lane >> 2)) * rp.stride + x + (best_mvx >> 3) + 4 * (lane & 3), 4);
+            const DevPlane rp  = load_plane(p.ref[best_rf >> 2][best_rf & 3]);
+            const uint8_t *org = rp.pix + (ptrdiff_t)(y + (best_mvy >> 3)) * rp.stride + x + (best_mvx >> 3);
+            uint32_t       f[N];
+#pragma unroll
+            for (int k = 0; k < N; ++k) {
+                const int idx = lane + 64 * k, r = idx / DW, d = idx % DW;
+                __builtin_memcpy(&f[k], org + (ptrdiff_t)r * rp.stride + 4 * d, 4);
+            }
             long long satd;
-            tpl_transform16(p, src[0], f, lds, true, satd, best_err);
+            if constexpr (S == 16) {
+                if (p.subsample_tx == 0) tpl_transform<16, 16, N>(p, src, f, lds, true, satd, best_err);
+                else if (p.subsample_tx == 1) tpl_transform<16, 8, N>(p, src, f, lds, true, satd, best_err);
+                else tpl_transform<16, 4, N>(p, src, f, lds, true, satd, best_err);
+            } else {
+                tpl_transform<32, 8, N>(p, src, f, lds, true, satd, best_err);
+            }
         }
     }
     if (lane == 0) {
@@ -240,8 +360,9 @@ __device__ __forceinline__ void tpl_block(const TplParams &p, int b64, int bi, i
 
 // grid (16, n_b64), one wave each: slot s of a 64x64 block is its s-th 16x16 block (level 0), its s-th 32x32 block
 // (level 1, s < 4) or the block itself (level 2, s == 0); blocks that are not complete run at level 0 (:2086-2088)
-__global__ void __launch_bounds__(64) tpl_search_kernel(const TplParams p) {
-    __shared__ int32_t lds[16 * kTplPitch];
+__global__ void __launch_bounds__(64) tpl_search_kernel(const TplParams *pp) {
+    __shared__ int32_t lds[kTplLdsInts];
+    ConstTplParams    &p = *(ConstTplParams *)pp;
     const int b64 = blockIdx.y, slot = blockIdx.x;
     const int sb_x = (b64 % p.b64_w) * 64, sb_y = (b64 / p.b64_w) * 64;
     const int level = (sb_x + 64 <= p.width && sb_y + 64 <= p.height) ? p.level : 0;
@@ -261,8 +382,8 @@ __global__ void __launch_bounds__(64) tpl_search_kernel(const TplParams p) {
 
 } // namespace
 
-void launch_tpl_search(const TplParams &p, hipStream_t s) {
-    hipLaunchKernelGGL(tpl_search_kernel, dim3(16, p.n_b64), dim3(64), 0, s, p);
+void launch_tpl_search(const TplParams *dev, int n_b64, hipStream_t s) {
+    hipLaunchKernelGGL(tpl_search_kernel, dim3(16, n_b64), dim3(64), 0, s, dev);
 }
 
 } // namespace svtme

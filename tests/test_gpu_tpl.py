@@ -80,11 +80,16 @@ def test_random_me_results_match_the_restatement(seed):
                 use_pred_sad_in_intra_search=1, use_pred_sad_in_inter_search=1, subsample_tx=int(rng.integers(0, 3)),
                 pf_shape=int(rng.integers(0, 3)))
     quant = None
-    if level == 0 and seed % 3:  # whole 16x16 transforms: transform-domain costs and / or the source distortion
+    dq = [int(rng.integers(4, 1400)), int(rng.integers(4, 1900))]
+    some_quant = ([int(rng.integers(0, 1 + d)) for d in dq], [min(32767, int(rng.integers(1, 3)) * 32768 // d) for d in dq], dq)
+    if level == 0 and seed % 3 == 1:  # whole 16x16 transforms: transform-domain costs and / or the source distortion
         ctrl.update(subsample_tx=0, use_pred_sad_in_intra_search=int(rng.integers(0, 2)), use_pred_sad_in_inter_search=int(rng.integers(0, 2)))
         if rng.integers(0, 3):
-            dq = [int(rng.integers(4, 1400)), int(rng.integers(4, 1900))]
-            quant = ([int(rng.integers(0, 1 + d)) for d in dq], [min(32767, int(rng.integers(1, 3)) * 32768 // d) for d in dq], dq)
+            quant = some_quant
+    elif level < 2 and seed % 3 == 2:  # the source distortion through the reduced-row transforms: 16x8, 16x4, 32x8
+        if level == 1:
+            ctrl.update(subsample_tx=2)
+        quant = some_quant
     from svtme import gop
     pic = gop.Picture(poc=0, temporal_layer=0, is_ref=1, refs=[list(range(1, 1 + n_ref[0])), list(range(1 + n_ref[0], n_frames))])
     skip = rng.integers(0, 4, (2, 4)) == 0
@@ -108,8 +113,8 @@ def test_unsupported_controls_and_bad_arguments():
     try:
         # every intra mode (tpl_opt_flag 0); transform-domain costs or the source distortion on anything but whole 16x16 transforms
         for change, q in ((dict(tpl_opt_flag=0), None), (dict(use_pred_sad_in_inter_search=0, dispenser_search_level=1), None),
-                          (dict(use_pred_sad_in_intra_search=0, subsample_tx=1), None), (dict(subsample_tx=2), quant),
-                          (dict(dispenser_search_level=2), quant), (dict(pf_shape=3), None)):
+                          (dict(use_pred_sad_in_intra_search=0, subsample_tx=1), None), (dict(dispenser_search_level=1, subsample_tx=1), quant),
+                          (dict(dispenser_search_level=2, subsample_tx=2), quant), (dict(pf_shape=3), None)):
             p, keep, refs = picture_of(frames, pic, dict(ctrl, **change), me, quant=q)
             with pytest.raises(svtme.SvtmeError) as ei:
                 eng.tpl_search(p)

@@ -36,7 +36,8 @@ def test_oracle_refuses_what_it_does_not_restate():
     frames, pics, per = load_case("tpl4_m8_200x136", CASES["tpl4_m8_200x136"])
     ctrl, me, tb, quant = per[0]
     for change, q in ((dict(tpl_opt_flag=0), None), (dict(use_pred_sad_in_inter_search=0, dispenser_search_level=1), None),
-                      (dict(use_pred_sad_in_intra_search=0, subsample_tx=1), None), (dict(subsample_tx=2), quant), (dict(pf_shape=3), None)):
+                      (dict(use_pred_sad_in_intra_search=0, subsample_tx=1), None), (dict(dispenser_search_level=1, subsample_tx=1), quant),
+                      (dict(dispenser_search_level=2, subsample_tx=2), quant), (dict(pf_shape=3), None)):
         p, keep, refs = picture_of(frames, pics[0], dict(ctrl, **change), me, quant=q)
         with pytest.raises(RuntimeError, match="-5"):
             tplio.oracle_search(frames[pics[0].poc], refs, p)
@@ -163,28 +164,29 @@ def test_reference_digest_of_the_1080p_case():
 
 
 @pytest.mark.skipif(not refio.have_reference(), reason="needs the reference build (oracle/_ref)")
-def test_forward_dct_equals_the_references_on_random_and_extreme_residuals():
-    """The restatement's 16x16 forward DCT, shape by shape, against svt_av1_wht_fwd_txfm of the reference build: random
-    residuals of every magnitude, the extremes of 8-bit residuals (+-255 everywhere, checkerboards, single rows / columns)."""
-    rng = np.random.default_rng(7)
-    blocks = [rng.integers(-m, m + 1, (40, 16, 16)) for m in (1, 7, 60, 255)]
-    ext = np.zeros((8, 16, 16), np.int64)
+@pytest.mark.parametrize("w,h", [(16, 16), (16, 8), (16, 4), (32, 8)])
+def test_forward_dct_equals_the_references_on_random_and_extreme_residuals(w, h):
+    """The restatement's forward DCT, size by size and shape by shape, against svt_av1_wht_fwd_txfm of the reference build:
+    random residuals of every magnitude, the extremes of 8-bit residuals (+-255 everywhere, checkerboards, single rows /
+    columns)."""
+    rng = np.random.default_rng(7 + w + h)
+    blocks = [rng.integers(-m, m + 1, (40, h, w)) for m in (1, 7, 60, 255)]
+    ext = np.zeros((8, h, w), np.int64)
     ext[0] = 255
     ext[1] = -255
-    ext[2] = 255 * (1 - 2 * ((np.arange(16)[:, None] + np.arange(16)[None, :]) & 1))
+    ext[2] = 255 * (1 - 2 * ((np.arange(h)[:, None] + np.arange(w)[None, :]) & 1))
     ext[3, 0, :] = 255
     ext[4, :, 0] = -255
-    ext[5] = 255 * (1 - 2 * (np.arange(16)[None, :] & 1))
-    ext[6] = -255 * (1 - 2 * (np.arange(16)[:, None] & 1))
-    ext[7, 15, 15] = 255
+    ext[5] = 255 * (1 - 2 * (np.arange(w)[None, :] & 1))
+    ext[6] = -255 * (1 - 2 * (np.arange(h)[:, None] & 1))
+    ext[7, h - 1, w - 1] = 255
     blocks = np.concatenate(blocks + [ext]).astype(np.int16)
-    want = refio.reference_dct16(blocks)
+    want = refio.reference_dct(blocks)
     for shape in range(3):
         for i, b in enumerate(blocks):
-            got = tplio.oracle_fwd_dct16x16(b, shape)
+            got = tplio.oracle_fwd_dct(b, shape)
             assert np.array_equal(got, want[shape, i]), (shape, i)
-    keep = {1: 8, 2: 4}
-    for shape, k in keep.items():  # the reduced shapes are the whole transform with everything outside the corner zeroed
-        m = np.zeros((16, 16), bool)
-        m[:k, :k] = True
+    for shape in (1, 2):  # the reduced shapes are the whole transform with everything outside the corner zeroed
+        m = np.zeros((h, w), bool)
+        m[:h >> shape, :w >> shape] = True
         assert np.array_equal(want[shape], np.where(m, want[0], 0))
