@@ -201,3 +201,62 @@ def test_reference_dispenser_runs_unchanged_on_the_engines_search(name):
         for f in DISPENSER_FIELDS:
             assert np.array_equal(tb[f], want[f]), (name, i, f)
         assert int(tb["n_costs"].sum()) == 0  # the host evaluated no cost: the search was the engine's
+
+
+def test_tpl_search_runs_beside_me_and_gm_calls():
+    """One engine, four threads at once: two submit / wait pictures of the sequence, one runs the TPL search of every picture
+    over and over, one asks for corners; everybody gets what a lone caller gets."""
+    import threading
+    import svtme
+    name = "tpl4_m8_200x136"
+    frames, pics, per = load_case(name, tpl_cases.CASES[name])
+    n, h, w = frames.shape
+    eng = svtme.Engine(w, h, store_slots=n + 1, max_in_flight=4)
+    errors = []
+    try:
+        for i in range(n):
+            eng.store_put(i + 1, i, frames[i])
+        ctrl_me = svtme.derive_controls(8, w, h, 0, 30 << 16)
+        descs = [eng.make_picture(w, h, p.poc, p.temporal_layer, p.is_ref, p.refs, ctrl_me, key_of=lambda poc: poc + 1) for p in pics]
+        alone = [eng.run_picture(d) for d in descs]
+        corners = eng.gm_corners(1, 0)
+        jobs = []
+        for pic, (ctrl, me, tb, quant) in zip(pics, per):
+            p, keep, refs = picture_of(frames, pic, ctrl, me, quant=quant)
+            jobs.append((p, keep, tplio.expected_from_reference(tb, ctrl, src_dist=True)))
+
+        def me_worker(part):
+            try:
+                for _ in range(6):
+                    for i in part:
+                        out = eng.run_picture(descs[i])
+                        for f in ("best_sad", "best_mv", "zz_sad"):
+                            assert np.array_equal(out[f], alone[i][f]), (i, f)
+            except Exception as e:  # noqa: BLE001
+                errors.append(e)
+
+        def tpl_worker():
+            try:
+                for _ in range(12):
+                    for k, (p, keep, exp) in enumerate(jobs):
+                        assert_blocks_equal(eng.tpl_search(p), exp, "picture %d beside other callers" % k)
+            except Exception as e:  # noqa: BLE001
+                errors.append(e)
+
+        def gm_worker():
+            try:
+                for k in range(60):
+                    assert np.array_equal(eng.gm_corners(1 + k % 2, 0), corners if k % 2 == 0 else eng.gm_corners(2, 0))
+            except Exception as e:  # noqa: BLE001
+                errors.append(e)
+
+        threads = [threading.Thread(target=me_worker, args=(range(0, len(descs), 2),)), threading.Thread(target=me_worker, args=(range(1, len(descs), 2),)),
+                   threading.Thread(target=tpl_worker), threading.Thread(target=gm_worker)]
+        for t in threads:
+            t.start()
+        for t in threads:
+            t.join(timeout=100)
+        assert not any(t.is_alive() for t in threads), "a caller did not come back"
+        assert not errors, errors[:2]
+    finally:
+        eng.close()
