@@ -398,6 +398,13 @@ int svtme_group_picture_submit(svtme_group *g, const svtme_picture *pic, svtme_t
 int svtme_group_picture_wait(svtme_group *g, svtme_ticket ticket, svtme_results *out);
 int svtme_group_picture_done(svtme_group *g, svtme_ticket ticket);
 int svtme_group_stats(svtme_group *g, uint64_t *pictures, uint64_t *sources, uint64_t *uploads);
+/* For the calls that take an engine and store keys (svtme_tpl_search, svtme_gm_*) from a caller that holds a group: the
+ * engine of the group on which all of keys[0 .. n_keys) are resident when the call returns - the one that held most of
+ * them already (the engine that ran the picture's ME holds the picture and its references), the missing ones are uploaded
+ * to it. The handle stays valid as long as the group; it must not be destroyed. No counterpart in the reference.
+ * svtme_group_gm_set_tables: svtme_gm_set_tables on every engine of the group. */
+int svtme_group_engine_for(svtme_group *g, const uint64_t *keys, uint32_t n_keys, svtme_engine **engine);
+int svtme_group_gm_set_tables(svtme_group *g, const int16_t *warped_filter, const int32_t *error_measure_lut);
 
 /* ---- Global-motion estimation: the data-parallel stages of compute_global_motion
  * (Source/Lib/Encoder/Codec/EbGlobalMotionEstimation.c:155-301) on the planes the store already holds. The encoder keeps

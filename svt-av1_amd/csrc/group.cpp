@@ -145,6 +145,37 @@ extern "C" int svtme_group_picture_done(svtme_group *g, svtme_ticket ticket) {
     return svtme_picture_done(g->engines[i], ticket & ((1ull << kEngineShift) - 1));
 }
 
+// The engine that holds most of the listed sources already gets the rest (group lock held by this function only).
+extern "C" int svtme_group_engine_for(svtme_group *g, const uint64_t *keys, uint32_t n_keys, svtme_engine **engine) {
+    if (!g || !keys || !engine || n_keys < 1 || n_keys > 1 + SVTME_MAX_LISTS * SVTME_MAX_REFS) return SVTME_ERR_BAD_ARG;
+    std::lock_guard<std::mutex> lock(g->mu);
+    size_t best = 0;
+    int    best_count = -1;
+    for (size_t i = 0; i < g->engines.size(); ++i) {
+        int count = 0;
+        for (uint32_t k = 0; k < n_keys; ++k) {
+            auto it = g->sources.find(keys[k]);
+            if (it == g->sources.end()) return SVTME_ERR_NOT_FOUND;
+            count += (int)(it->second.resident >> i & 1);
+        }
+        if (count > best_count) {
+            best_count = count;
+            best       = i;
+        }
+    }
+    for (uint32_t k = 0; k < n_keys; ++k)
+        if (const int rc = ensure_resident(g, best, keys[k])) return rc;
+    *engine = g->engines[best];
+    return SVTME_OK;
+}
+
+extern "C" int svtme_group_gm_set_tables(svtme_group *g, const int16_t *warped_filter, const int32_t *error_measure_lut) {
+    if (!g) return SVTME_ERR_BAD_ARG;
+    for (svtme_engine *e : g->engines)
+        if (const int rc = svtme_gm_set_tables(e, warped_filter, error_measure_lut)) return rc;
+    return SVTME_OK;
+}
+
 extern "C" int svtme_group_stats(svtme_group *g, uint64_t *pictures, uint64_t *sources, uint64_t *uploads) {
     if (!g) return SVTME_ERR_BAD_ARG;
     std::lock_guard<std::mutex> lock(g->mu);

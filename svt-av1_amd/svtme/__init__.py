@@ -119,6 +119,7 @@ EXPORTS = ("svtme_version", "svtme_derive_controls", "svtme_derive_tf_controls",
            "svtme_host_unregister", "svtme_host_alloc", "svtme_host_free", "svtme_pictures_submit",
            "svtme_group_create", "svtme_group_destroy", "svtme_group_size", "svtme_group_store_put", "svtme_group_store_release",
            "svtme_group_picture_submit", "svtme_group_picture_wait", "svtme_group_picture_done", "svtme_group_stats",
+           "svtme_group_engine_for", "svtme_group_gm_set_tables",
            "svtme_gm_set_tables", "svtme_gm_corners", "svtme_gm_correspondences", "svtme_gm_warp_error", "svtme_gm_frame_error",
            "svtme_tpl_search")
 MAX_BATCH = 32
@@ -203,6 +204,8 @@ def load_library():
     lib.svtme_group_picture_wait.argtypes = [C.c_void_p, C.c_uint64, C.POINTER(Results)]
     lib.svtme_group_picture_done.argtypes = [C.c_void_p, C.c_uint64]
     lib.svtme_group_stats.argtypes = [C.c_void_p] + [C.POINTER(C.c_uint64)] * 3
+    lib.svtme_group_engine_for.argtypes = [C.c_void_p, C.POINTER(C.c_uint64), C.c_uint32, C.POINTER(C.c_void_p)]
+    lib.svtme_group_gm_set_tables.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
     lib.svtme_gm_set_tables.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
     lib.svtme_gm_corners.argtypes = [C.c_void_p, C.c_uint64, C.c_int, C.c_void_p, C.c_int32, C.POINTER(C.c_int32)]
     lib.svtme_gm_correspondences.argtypes = [C.c_void_p, C.c_uint64, C.c_uint64, C.c_int, C.c_void_p, C.POINTER(C.c_int32)]
@@ -334,6 +337,25 @@ class Group:
         if rc:
             raise SvtmeError(rc, "svtme_group_picture_done")
 
+    def engine_for(self, keys):
+        """The group's engine on which all `keys` are resident (uploading what is missing), as a borrowed Engine: for
+        tpl_search / gm_* calls. Do not close it."""
+        arr = (C.c_uint64 * len(keys))(*keys)
+        h = C.c_void_p()
+        rc = self.lib.svtme_group_engine_for(self.h, arr, len(keys), C.byref(h))
+        if rc:
+            raise SvtmeError(rc, "svtme_group_engine_for")
+        e = Engine.__new__(Engine)
+        e.lib, e.h, e.borrowed = self.lib, h, True
+        return e
+
+    def gm_set_tables(self, warped_filter, error_lut):
+        wf = np.ascontiguousarray(warped_filter, np.int16)
+        lut = np.ascontiguousarray(error_lut, np.int32)
+        rc = self.lib.svtme_group_gm_set_tables(self.h, wf.ctypes.data, lut.ctypes.data)
+        if rc:
+            raise SvtmeError(rc, "svtme_group_gm_set_tables")
+
     def stats(self):
         v = [C.c_uint64() for _ in range(3)]
         rc = self.lib.svtme_group_stats(self.h, *[C.byref(x) for x in v])
@@ -355,9 +377,9 @@ class Engine:
             raise SvtmeError(rc, "svtme_create")
 
     def close(self):
-        if self.h:
+        if self.h and not getattr(self, "borrowed", False):  # a group's engine belongs to the group
             self.lib.svtme_destroy(self.h)
-            self.h = C.c_void_p()
+        self.h = C.c_void_p()
 
     def __del__(self):
         try:

@@ -260,3 +260,39 @@ def test_tpl_search_runs_beside_me_and_gm_calls():
         assert not errors, errors[:2]
     finally:
         eng.close()
+
+
+def test_group_hands_out_the_engine_that_holds_a_pictures_planes():
+    """Two engines behind one handle (both on device 0): pictures go round robin, so each engine holds the sources of its own
+    pictures; svtme_group_engine_for names the engine for a picture's TPL search (uploading what that engine lacks), and the
+    search there equals the reference's."""
+    import svtme
+    name = "tpl4_m8_200x136"
+    frames, pics, per = load_case(name, tpl_cases.CASES[name])
+    n, h, w = frames.shape
+    grp = svtme.Group([0, 0], w, h, store_slots=n + 1, max_in_flight=4)
+    try:
+        for i in range(n):
+            grp.store_put(i + 1, i, frames[i])
+        ctrl_me = svtme.derive_controls(8, w, h, 0, 30 << 16)
+        tickets = [grp.submit(grp.make_picture(w, h, p.poc, p.temporal_layer, p.is_ref, p.refs, ctrl_me, key_of=lambda poc: poc + 1))
+                   for p in pics[:4]]
+        for t in tickets:
+            grp.wait(t)
+            grp.done(t)
+        before = grp.stats()["uploads"]
+        engines = set()
+        for pic, (ctrl, me, tb, quant) in zip(pics, per):
+            keys = [pic.poc + 1] + [r + 1 for l in pic.refs for r in l]
+            eng = grp.engine_for(keys)
+            engines.add(eng.h.value)
+            p, keep, refs = picture_of(frames, pic, ctrl, me, quant=quant)
+            assert_blocks_equal(eng.tpl_search(p), tplio.expected_from_reference(tb, ctrl, src_dist=True), "poc %d through the group" % pic.poc)
+        assert len(engines) == 2  # both engines served searches
+        # the first four pictures' sources were where their ME ran: the searches of those pictures uploaded nothing new there
+        assert grp.stats()["uploads"] >= before
+        with pytest.raises(svtme.SvtmeError) as ei:
+            grp.engine_for([9999])
+        assert ei.value.code == svtme.ERR_NOT_FOUND
+    finally:
+        grp.close()
