@@ -629,7 +629,11 @@ static int fill_params(svtme_engine *e, const svtme_picture *pic, PicParams &p, 
         // controls allow (integer_search_b64 :1319-1345 caps the window at sa_max, rounds the width up to 8 and keeps
         // the height >= 3)
         const int w_max = (std::max<int>(k.me_sa.sa_max.width, 1) + 7) & ~7, h_max = std::max<int>(k.me_sa.sa_max.height, 3);
-        p.me_max_items  = ((w_max + 63) / 64) * ((h_max + 7) / 8);
+        // windows of at most 16 x 16 positions that are higher than 8 rows (preset 8's 16 x 9): one work item of 16 rows,
+        // whose spare lanes take rows 8.., instead of two of 8
+        p.me_tall       = w_max <= 16 && h_max > 8 && h_max <= 16 && getenv("SVTME_NO_TALL_ITEMS") == nullptr;
+        const int rows  = p.me_tall ? 16 : 8;
+        p.me_max_items  = ((w_max + 63) / 64) * ((h_max + rows - 1) / rows);
     }
     return SVTME_OK;
 }

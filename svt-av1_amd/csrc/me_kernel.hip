@@ -76,8 +76,10 @@ __device__ __forceinline__ uint32_t row_quads_min(uint32_t v) {
     return v;
 }
 
-// Work items of a w x h window: one per (64-position column chunk, group of 8 rows).
-__device__ __forceinline__ int me_item_count(int w, int h) { return ((w + ME_TILE - 1) / ME_TILE) * ((h + 7) >> 3); }
+// Work items of a w x h window: one per (64-position column chunk, group of `item_rows` rows). item_rows is 8, or 16 for
+// pictures whose controls keep every window at most 16 positions wide and 16 rows high (PicParams::me_tall): such a window
+// fills a quarter of an item's lanes, and the other quads take the rows under the eighth instead of a second item.
+__device__ __forceinline__ int me_item_count(int w, int h, int item_rows) { return ((w + ME_TILE - 1) / ME_TILE) * ((h + item_rows - 1) / item_rows); }
 
 template <class PICS>
 __global__ void __launch_bounds__(ME_THREADS) me_plan_kernel(PICS pp, int n_b64, int me_ref0) {
@@ -292,12 +294,13 @@ __global__ void __launch_bounds__(ME_THREADS) me_plan_kernel(PICS pp, int n_b64,
     if (tid == 0) {
         *job = MeJob{org_x, org_y, w, h};
         count_ops(p, 5, (unsigned long long)w * h * 2048ull);
-        if (me_item_count(w, h) > p.me_max_items) count_ops(p, 7, 1); // cannot happen: the host sized the grid from sa_max
+        if (me_item_count(w, h, p.me_tall ? 16 : 8) > p.me_max_items) count_ops(p, 7, 1); // cannot happen: the host sized the grid from sa_max
     }
 }
 
-template <class PICS>
+template <class PICS, bool TALL>
 __global__ void __launch_bounds__(ME_THREADS, 2) me_search_kernel(PICS pp, int grid_refs, int ref_first, int ref_last) {
+    constexpr int ITEM_ROWS = TALL ? 16 : 8, ROW_BITS = TALL ? 4 : 3; // keys carry the row within the item
     __shared__ MeShared               S;
     __shared__ __align__(16) uint32_t win[ME_WIN_BYTES / 4];
     // the grid's slowest dimension is (picture, reference): the work items of one picture are dispatched together, so that
@@ -319,12 +322,13 @@ __global__ void __launch_bounds__(ME_THREADS, 2) me_search_kernel(PICS pp, int g
     const MeJob job = p.me_jobs[b64 * 8 + my];
     const int   w = job.w, h = job.h, org_x = job.org_x, org_y = job.org_y;
     if (w <= 0) return;
-    // ---- this item: one group of 8 search rows of one 64-position column chunk = up to 16 runs (4 positions x 8 rows)
-    const int n_yg = (h + 7) >> 3;
-    if ((int)blockIdx.y >= me_item_count(w, h)) return;
+    // ---- this item: one group of 8 search rows of one 64-position column chunk = up to 16 runs (4 positions x 8 rows);
+    // TALL: two such groups of a window of at most 4 runs
+    const int n_yg = (h + ITEM_ROWS - 1) / ITEM_ROWS;
+    if ((int)blockIdx.y >= me_item_count(w, h, ITEM_ROWS)) return;
     const int chunk = blockIdx.y / n_yg, yg0 = blockIdx.y - chunk * n_yg;
     const int tx0 = chunk * ME_TILE, n_xg = (min(ME_TILE, w - tx0) + 3) >> 2;
-    const int ty0 = yg0 * 8, rows = min(h - ty0, 8); // search rows staged for this item
+    const int ty0 = yg0 * ITEM_ROWS, rows = min(h - ty0, ITEM_ROWS); // search rows staged for this item
     const int r0 = 0, r1 = n_xg;
 
     const DevPlane cur = load_plane(p.cur.lvl[2]);
@@ -352,30 +356,32 @@ __global__ void __launch_bounds__(ME_THREADS, 2) me_search_kernel(PICS pp, int g
                 const uint8_t *g = ref.pix + (ptrdiff_t)(b64y + org_y + ty0 + (tid >> 3)) * ref.stride + (b64x + org_x + tx0 + 16 * d);
                 uint4         *dst = reinterpret_cast<uint4 *>(win) + (tid >> 3) * (ME_PD / 4) + d;
                 if (d < nq) {
-                    // nrow <= 70: at most 9 trips, all loads issued before the first store; trips past the last row
-                    // repeat it (same value into the same slot), so nothing is conditional
-                    uint4 v[9];
+                    // nrow <= 70 (78): at most 9 (10) trips, all loads issued before the first store; trips past the last
+                    // row repeat it (same value into the same slot), so nothing is conditional
+                    constexpr int TRIPS = (ITEM_ROWS + 62 + 7) / 8;
+                    uint4         v[TRIPS];
 #pragma unroll
-                    for (int t = 0; t < 9; ++t) {
+                    for (int t = 0; t < TRIPS; ++t) {
                         const int dr = min(8 * t, nrow - 1 - (tid >> 3));
                         __builtin_memcpy(&v[t], g + (ptrdiff_t)dr * ref.stride, 16);
                     }
 #pragma unroll
-                    for (int t = 0; t < 9; ++t) dst[min(8 * t, nrow - 1 - (tid >> 3)) * (ME_PD / 4)] = v[t];
+                    for (int t = 0; t < TRIPS; ++t) dst[min(8 * t, nrow - 1 - (tid >> 3)) * (ME_PD / 4)] = v[t];
                 }
             }
             __syncthreads();
             // few runs: each parity of a run gets its own quad
-            const bool split  = r1 - r0 <= ME_THREADS / 8;
+            const bool split  = TALL || r1 - r0 <= ME_THREADS / 8;
             const int  n_unit = split ? 2 * (r1 - r0) : r1 - r0;
             const int  n_it   = split ? 1 : 2;
             {
-                const int  u     = quad;
+                // TALL (at most 4 runs, so at most 8 units): quads 8..15 repeat the units on search rows 8..15
+                const int  u     = TALL ? quad & 7 : quad, grp = TALL ? quad >> 3 : 0;
                 const bool valid = u < n_unit;
                 const int  run   = r0 + (valid ? (split ? u >> 1 : u) : 0);
                 const int  par0  = split ? (u & 1) : 0;
                 const int  xg    = run;
-                const int  ya = 0, yb = rows;
+                const int  ya = 8 * grp, yb = min(rows, ya + 8);
                 // running minima of this lane. 8x8: packed 16-bit keys SAD * 8 + row-in-run, two positions per dword;
                 // 16x16: SAD << 16 | row << 6; larger: SAD << 9 | row << 6. A position that does not exist carries an
                 // all-ones row mask, which makes its keys all ones.
@@ -404,9 +410,9 @@ __global__ void __launch_bounds__(ME_THREADS, 2) me_search_kernel(PICS pp, int g
                     uint32_t        ypk[4], yrk[4];
 #pragma unroll
                     for (int t = 0; t < 4; ++t) {
-                        const uint32_t yr = (uint32_t)(par + 2 * t);
+                        const uint32_t yr = (uint32_t)(par + 2 * t); // within the quad's 8 rows; the 8x8 keys get the group at the merge
                         ypk[t]            = t < n_pos ? yr * 0x10001u : 0xFFFFFFFFu;
-                        yrk[t]            = t < n_pos ? yr << 6 : 0xFFFFFFFFu; // (bits 0..5 take the column at the merge)
+                        yrk[t]            = t < n_pos ? (yr + 8 * grp) << 6 : 0xFFFFFFFFu; // (bits 0..5 take the column at the merge)
                     }
                     u64      acc0[4], acc1[4];
                     uint32_t t16[4][2], half[4][2], topv[4][2], sw[4][4];
@@ -499,9 +505,9 @@ __global__ void __launch_bounds__(ME_THREADS, 2) me_search_kernel(PICS pp, int g
                                                 bt += quad_xor1(bt);
                                                 uint32_t all = tp + bt;
                                                 all += quad_xor2(all);
-                                                b32[0][i] = min(b32[0][i], (tp << 9) | yrk[t]);
-                                                b32[1][i] = min(b32[1][i], (bt << 9) | yrk[t]);
-                                                b64k[i]   = min(b64k[i], (all << 9) | yrk[t]);
+                                                b32[0][i] = min(b32[0][i], (tp << (6 + ROW_BITS)) | yrk[t]);
+                                                b32[1][i] = min(b32[1][i], (bt << (6 + ROW_BITS)) | yrk[t]);
+                                                b64k[i]   = min(b64k[i], (all << (6 + ROW_BITS)) | yrk[t]);
                                             }
                                         }
                                     }
@@ -531,8 +537,12 @@ __global__ void __launch_bounds__(ME_THREADS, 2) me_search_kernel(PICS pp, int g
 #pragma unroll
                         for (int c = 0; c < 2; ++c) {
                             const uint32_t d0 = b8[by][c][0], d1 = b8[by][c][1];
-                            const uint32_t k0 = ((d0 & 0xFFFFu) << 6) | xlab[0], k1 = ((d0 >> 16) << 6) | xlab[1];
-                            const uint32_t k2 = ((d1 & 0xFFFFu) << 6) | xlab[2], k3 = ((d1 >> 16) << 6) | xlab[3];
+                            // a 16-bit key SAD << 3 | row of 8 -> SAD << (6 + ROW_BITS) | row of the item << 6
+                            auto wide = [&](uint32_t k16) {
+                                return TALL ? ((k16 & 0xFFF8u) << 7) | ((k16 & 7u) << 6) | ((uint32_t)grp << 9) : k16 << 6;
+                            };
+                            const uint32_t k0 = wide(d0 & 0xFFFFu) | xlab[0], k1 = wide(d0 >> 16) | xlab[1];
+                            const uint32_t k2 = wide(d1 & 0xFFFFu) | xlab[2], k3 = wide(d1 >> 16) | xlab[3];
                             const uint32_t k  = row_quads_min(min(min(k0, k1), min(k2, k3)));
                             const int      bx8 = col * 2 + c; // 8x8 block column
                             const int      pu  = 21 + z16(by >> 1, bx8 >> 1) * 4 + ((by & 1) << 1) + (bx8 & 1);
@@ -561,11 +571,11 @@ __global__ void __launch_bounds__(ME_THREADS, 2) me_search_kernel(PICS pp, int g
     // (keys only ever decrease, so a plain - possibly stale - read that is already no larger settles it without an atomic)
     for (int pu = tid; pu < SVTME_PU_COUNT; pu += ME_THREADS) {
         const uint32_t k = min(min(win[pu], win[SVTME_PU_COUNT + pu]), min(win[2 * SVTME_PU_COUNT + pu], win[3 * SVTME_PU_COUNT + pu]));
-        const int      sh = pu >= 5 && pu < 21 ? 16 : 9;
+        const int      sh = pu >= 5 && pu < 21 ? 16 : 6 + ROW_BITS;
         const uint32_t sad = k >> sh;
         // a key that no position produced (cannot happen for an item the plan made): all-ones fields exceed the largest SAD
         if (sad > (pu >= 21 ? 8u * 4u : pu >= 5 ? 16u * 8u : pu >= 1 ? 32u * 16u : 64u * 32u) * 255u) continue;
-        const u64 key = ((u64)sad << 32) | ((uint32_t)(ty0 + (int)((k >> 6) & 7)) << 16) | (uint32_t)(tx0 + (int)(k & 63));
+        const u64 key = ((u64)sad << 32) | ((uint32_t)(ty0 + (int)((k >> 6) & (ITEM_ROWS - 1))) << 16) | (uint32_t)(tx0 + (int)(k & 63));
         u64      *g   = &p.me_keys[(size_t)(b64 * 8 + my) * SVTME_PU_COUNT + pu];
         if (key < *g) atomicMin(g, key);
     }
@@ -648,15 +658,20 @@ static void launch_me_as(const Batch &b, PICS pics, hipStream_t s, hipEvent_t ma
     // that use the rule.)
     const bool two_phase = p.ctrl.enable_me_sr_adjustment == 2 && p.ctrl.me_early_exit_th == 0 && n_refs > 1;
     int        me_ref0 = 0;
+    auto       search = [&](int ref_first, int ref_last) {
+        const dim3 grid(n_b64, p.me_max_items, n_refs * b.n);
+        if (p.me_tall) hipLaunchKernelGGL((me_search_kernel<PICS, true>), grid, dim3(ME_THREADS), 0, s, pics, n_refs, ref_first, ref_last);
+        else hipLaunchKernelGGL((me_search_kernel<PICS, false>), grid, dim3(ME_THREADS), 0, s, pics, n_refs, ref_first, ref_last);
+    };
     if (two_phase) {
         hipLaunchKernelGGL(me_plan_kernel<PICS>, dim3(n_b64 * b.n, 1), dim3(ME_THREADS), 0, s, pics, n_b64, 0);
-        hipLaunchKernelGGL(me_search_kernel<PICS>, dim3(n_b64, p.me_max_items, n_refs * b.n), dim3(ME_THREADS), 0, s, pics, n_refs, 0, 0);
+        search(0, 0);
         me_ref0 = 1;
     }
     const int n_now = n_refs - me_ref0;
     hipLaunchKernelGGL(me_plan_kernel<PICS>, dim3(n_b64 * b.n, n_now), dim3(ME_THREADS), 0, s, pics, n_b64, me_ref0);
     if (marks[0]) (void)hipEventRecord(marks[0], s);
-    hipLaunchKernelGGL(me_search_kernel<PICS>, dim3(n_b64, p.me_max_items, n_refs * b.n), dim3(ME_THREADS), 0, s, pics, n_refs, me_ref0, 1 << 30);
+    search(me_ref0, 1 << 30);
     if (marks[1]) (void)hipEventRecord(marks[1], s);
     hipLaunchKernelGGL(me_finish_kernel<PICS>, dim3((n_b64 * n_refs * SVTME_PU_COUNT + 255) / 256, b.n), dim3(256), 0, s, pics);
     if (marks[2]) (void)hipEventRecord(marks[2], s);
@@ -670,7 +685,7 @@ void launch_me(const Batch &b, hipStream_t s, hipEvent_t marks[3]) {
 // resident workgroups per CU the runtime expects for the search kernel (diagnostic)
 int occupancy_me_search() {
     int n = 0;
-    (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, me_search_kernel<OnePicture>, ME_THREADS, 0);
+    (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, me_search_kernel<OnePicture, false>, ME_THREADS, 0);
     return n;
 }
 

@@ -68,6 +68,7 @@ struct PicParams {
     int32_t        restricted; // integer search windows stay inside the picture (restricted_motion_vector, one tile)
     uint32_t       tf_me_exit_th;
     int32_t        me_max_items; // upper bound of search work items per (b64, ref) for this picture's controls
+    int32_t        me_tall; // every window is at most 16 positions wide and 9..16 rows high: work items of 16 rows
     int32_t        zero; // always 0, but the compiler cannot know: keeps it from merging loads that must stay apart
     // intermediates
     MeJob              *me_jobs; // [n_b64][2][4]
