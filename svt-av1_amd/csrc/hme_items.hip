@@ -695,12 +695,108 @@ __device__ u64 strip_search_fs(const uint32_t *src, uint32_t *win, int zero, con
     return wave_min_u64(best);
 }
 
+#ifdef SVTME_HME_REGIONS_TU // (see the end of this file)
+template <int BWD, int MAXH>
+struct QuickGeo {
+    static constexpr int PD  = BWD + 2; // dwords per staged row: 8 positions + the block width - 1 more pixels, rounded up
+    static constexpr int RPC = BWD / 4; // sampled block rows per lane (rows <= 8 RPC); RPC x 4 BWD x 255 fits the 16-bit sums
+    static constexpr int PR  = (PD + 3) / 4; // 16-byte pieces per staged row; the last one carries PD - 4 (PR - 1) = 2 dwords
+    static constexpr int NB  = ((MAXH + 2 * (8 * RPC - 1)) * PR + 63) / 64; // pieces per lane
+    static constexpr int WIN = ((MAXH + 2 * (8 * RPC - 1)) * PD + 3) & ~3; // dwords of a staged window (16-byte multiple)
+    static_assert(PD - 4 * (PR - 1) == 2, "the last piece of a row is half a piece");
+};
+
+// The window of NQ searches at once: all loads of all windows are issued before the first store, so the NQ windows cost
+// one memory round trip. Window q: (sa_h[q] + 2 (rows - 1)) rows from (wx[q], wy[q]) of `ref`, staged at win + q * WIN.
+// piece i = lane + 64 k of a window, 16 bytes in one load (a third of the load instructions of dword loads, which is what
+// these kernels wait for); indices past the end repeat the last piece (same value, same slot). The LDS rows stay PD dwords
+// apart (the walk's bank pattern), so a row's last piece stores its first 8 bytes only.
+template <int BWD, int MAXH, int NQ>
+__device__ __forceinline__ void quick_stage(uint32_t *win, const DevPlane &ref, int rows, const int (&wx)[NQ], const int (&wy)[NQ],
+                                            const int (&sa_h)[NQ]) {
+    using G = QuickGeo<BWD, MAXH>;
+    const int lane = threadIdx.x & 63;
+    uint4     v[NQ][G::NB];
+    int       at[NQ][G::NB];
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) {
+        const int      n = (sa_h[q] + 2 * (rows - 1)) * G::PR;
+        const uint8_t *g = ref.pix + (ptrdiff_t)wy[q] * ref.stride + wx[q];
+#pragma unroll
+        for (int k = 0; k < G::NB; ++k) {
+            const int i = min(lane + 64 * k, n - 1), r = i / G::PR, c = i - r * G::PR;
+            __builtin_memcpy(&v[q][k], g + (ptrdiff_t)r * ref.stride + 16 * c, 16);
+            at[q][k] = (q * G::WIN + r * G::PD + 4 * c) | (c == G::PR - 1 ? (int)0x80000000 : 0);
+        }
+    }
+#pragma unroll
+    for (int q = 0; q < NQ; ++q)
+#pragma unroll
+        for (int k = 0; k < G::NB; ++k) {
+            uint2 *dst = reinterpret_cast<uint2 *>(win + (at[q][k] & 0x7FFFFFFF)); // (PD and WIN are even: 8-byte aligned)
+            dst[0]     = make_uint2(v[q][k].x, v[q][k].y);
+            if (at[q][k] >= 0) dst[1] = make_uint2(v[q][k].z, v[q][k].w);
+        }
+}
+
 // small_search for the shapes the presets use at these levels - 8 x (1..MAXH) positions (3 rows in the pre-analysis ME, 8 in
 // the first pass), full-width block of BWD dwords (8: the 32-pixel quarter-resolution block, 16: the 64-pixel
-// full-resolution block) - with everything unrolled: lane = (position quad: 2 per row x 4 rows) x (8 chunks of BWD / 4
-// sampled block rows: rows chunk, chunk + 8, .., so that the eight lanes of a position quad read eight neighbouring rows
-// of the block and of the window at a time - different banks, see kSrcPitch), 4 search rows per trip; window staged in one
-// memory round trip.
+// full-resolution block) - over a window quick_stage left at `win`, with everything unrolled: lane = (position quad: 2 per
+// row x 4 rows) x (8 chunks of BWD / 4 sampled block rows: rows chunk, chunk + 8, .., so that the eight lanes of a position
+// quad read eight neighbouring rows of the block and of the window at a time - different banks, see kSrcPitch), 4 search
+// rows per trip.
+template <int BWD, int MAXH>
+__device__ __forceinline__ u64 quick_scan(const uint32_t *src, const uint32_t *win, int rows, int sa_h) {
+    using G = QuickGeo<BWD, MAXH>;
+    constexpr int PD = G::PD, RPC = G::RPC;
+    const int     lane = threadIdx.x & 63;
+    const int     chunk = lane & 7, q = lane >> 3, xg = q & 1;
+    u64           best = ~0ull;
+#pragma unroll
+    for (int y0 = 0; y0 < MAXH; y0 += 4) {
+        if (y0 >= sa_h) break; // wave-uniform
+        const int  yl     = y0 + (q >> 1);
+        const bool active = yl < sa_h;
+        u64        a16 = 0;
+        if (active) {
+#pragma unroll
+            for (int jj = 0; jj < RPC; ++jj) {
+                const int j = jj * 8 + chunk;
+                if (j < rows) {
+                    const uint32_t *rr = win + (yl + 2 * j) * PD + xg;
+                    const uint32_t *ss = src + j * kSrcPitch<false>;
+                    uint32_t        rv[BWD + 1], sv[BWD];
+#pragma unroll
+                    for (int d = 0; d <= BWD; ++d) rv[d] = rr[d];
+#pragma unroll
+                    for (int d = 0; d < BWD; ++d) sv[d] = ss[d];
+#pragma unroll
+                    for (int d = 0; d < BWD; ++d) a16 = __builtin_amdgcn_qsad_pk_u16_u8(((u64)rv[d + 1] << 32) | rv[d], sv[d], a16);
+                }
+            }
+        }
+        uint32_t a32[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            a32[i] = (uint32_t)(a16 >> (16 * i)) & 0xFFFFu;
+            a32[i] += quad_xor1(a32[i]);
+            a32[i] += quad_xor2(a32[i]);
+            a32[i] += __shfl_xor(a32[i], 4);
+        }
+        if (active && chunk == 0) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const u64 kk = ((u64)a32[i] << 32) | (uint32_t)(yl * 8 + xg * 4 + i);
+                best         = kk < best ? kk : best;
+            }
+        }
+    }
+    return wave_min_u64(best);
+}
+
+#endif
+
+// One such search by itself (a work item per region): the same staging and scan in one piece.
 template <int BWD, int MAXH>
 __device__ u64 quick_search(const uint32_t *src, uint32_t *win, const DevPlane &ref, int rows, int wx, int wy, int sa_h) {
     constexpr int PD  = BWD + 2; // dwords per staged row: 8 positions + the block width - 1 more pixels, rounded up
@@ -885,6 +981,7 @@ __device__ __forceinline__ void stage_l12_blocks(const P &p, L12Shared<FS> &S, i
     }
 }
 
+#ifndef SVTME_HME_REGIONS_TU
 template <bool FS, class PICS>
 __global__ void __launch_bounds__(FS ? HI_THREADS_FS : HI_THREADS) hme_l12_kernel(PICS pp) {
     __shared__ L12Shared<FS>          S;
@@ -932,7 +1029,10 @@ static void launch_hme_items_as(const Batch &b, PICS pics, hipStream_t s, hipEve
     }
     if (marks[0]) (void)hipEventRecord(marks[0], s);
     if (p0.ctrl.enable_hme_flag) {
+        // sub-sampled searches over 2 x 2 regions: one work item does the four regions of a reference
+        static const bool per_region = getenv("SVTME_L12_PER_REGION") != nullptr; // diagnostic: a work item per region
         if (fs) hipLaunchKernelGGL((hme_l12_kernel<true, PICS>), g12, dim3(HI_THREADS_FS), 0, s, pics);
+        else if (n_reg == 4 && !per_region && p0.ctrl.hme_l1_sa.height <= 3 && p0.ctrl.hme_l2_sa.height <= 3) launch_hme_l12_regions(b, s);
         else hipLaunchKernelGGL((hme_l12_kernel<false, PICS>), g12, dim3(HI_THREADS), 0, s, pics);
     }
     if (marks[1]) (void)hipEventRecord(marks[1], s);
@@ -948,5 +1048,161 @@ void occupancy_hme_items(int out[2]) {
     (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&out[0], hme_l0_kernel<false, OnePicture>, HI_THREADS, 0);
     (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&out[1], hme_l12_kernel<false, OnePicture>, HI_THREADS, 0);
 }
+
+#else
+// ---- hme_regions.hip compiles this file again with SVTME_HME_REGIONS_TU defined, for the part below only: the kernel that
+// does the four regions of a reference in one work item lives in a translation unit of its own, so that adding it leaves the
+// code of the kernels above exactly as it was (with everything in one unit the compiler's inlining of the shared search
+// functions changed, and the per-region kernel lost a tenth of its speed).
+// Levels 1 and 2 of all four regions of reference (l, r) in one wave, for the shapes quick_search covers: what l12_region
+// does per region, for windows of 8 x (1..3) positions (the pre-analysis ME's), with the four level-1 windows fetched in one
+// memory round trip and the four level-2 windows in two, and the reference's record, the source blocks and the work item's
+// set-up paid once instead of four times. A block or a window outside that shape (a picture's right / bottom edge) goes
+// through small_search region by region. (The first pass's 8 x 8 windows keep a work item per region: with two trips per
+// search the saving is smaller than what the larger item costs in resident waves.)
+template <class P>
+__device__ __forceinline__ void l12_regions(const P &p, const uint32_t *src1, const uint32_t *src2, uint32_t *win, int b64x, int b64y,
+                                            int block_w, int block_h, int l, int r, HmeRefOut *rec) {
+    const auto &k    = p.ctrl;
+    const int   lane = threadIdx.x & 63;
+    const bool  early = k.me_early_exit_th && rec->zz_sad < (k.me_early_exit_th >> 2);
+    // region q = sh * 2 + sw lives at index i = sw * 2 + sh of the record's arrays
+    int16_t  cx[4] = {0, 0, 0, 0}, cy[4] = {0, 0, 0, 0};
+    uint32_t csad[4] = {0, 0, 0, 0};
+    if (k.enable_hme_level0_flag && !early) {
+        // the worst region (strict '>', sr_h outer / sr_w inner) gives way to the better pre-HME result (:1967-1999)
+        uint32_t max_sad = 0;
+        int      mi      = 0;
+        for (int h_ = 0; h_ < 2; ++h_)
+            for (int w_ = 0; w_ < 2; ++w_)
+                if (rec->raw_sad[w_ * 2 + h_] > max_sad) {
+                    max_sad = rec->raw_sad[w_ * 2 + h_];
+                    mi      = w_ * 2 + h_;
+                }
+        const int s = rec->pre_sad[0] <= rec->pre_sad[1] ? 0 : 1;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int i = (q & 1) * 2 + (q >> 1);
+            cx[q]   = rec->raw_x[i];
+            cy[q]   = rec->raw_y[i];
+            csad[q] = rec->raw_sad[i];
+            if (k.prehme_enable && mi == i && rec->pre_sad[s] < csad[q]) {
+                csad[q] = rec->pre_sad[s];
+                cx[q]   = rec->pre_x[s];
+                cy[q]   = rec->pre_y[s];
+            }
+            if (lane == 0) {
+                rec->lx[0][i]   = cx[q];
+                rec->ly[0][i]   = cy[q];
+                rec->lsad[0][i] = csad[q];
+            }
+        }
+    }
+    for (int level = 1; level <= 2; ++level) {
+        // a level that does not run, or level 1 on the early exit (:2032-2040; level 2 has none), leaves zeros
+        if ((level == 1 ? !k.enable_hme_level1_flag : !k.enable_hme_level2_flag) || (level == 1 && early)) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) cx[q] = cy[q] = 0;
+            continue;
+        }
+        const DevPlane ref   = load_plane(p.ref[l][r].lvl[level]);
+        const int      shift = 2 - level;
+        const int      ox = b64x >> shift, oy = b64y >> shift;
+        const int      bw = block_w >> shift, bh = block_h >> shift;
+        const int      rows = bh >> 1;
+        const int      pad  = level == 2 ? 63 : ref.pad - 1;
+        const int      sa_width = level == 1 ? k.hme_l1_sa.width : k.hme_l2_sa.width, sa_height = level == 1 ? k.hme_l1_sa.height : k.hme_l2_sa.height;
+        int            wx[4], wy[4], hh[4];
+        int16_t        ww[4], orgx[4], orgy[4];
+        bool           quick = block_w == 64;
+        unsigned long long ops = 0;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            int16_t w = (int16_t)(((int16_t)sa_width + 7) & ~0x07), h = (int16_t)sa_height;
+            if (level == 1) {
+                cx[q] = (int16_t)(cx[q] >> 1);
+                cy[q] = (int16_t)(cy[q] >> 1);
+            }
+            int16_t org_x = (int16_t)(-(w >> 1) + cx[q]), org_y = (int16_t)(-(h >> 1) + cy[q]);
+            clip_axis(ox, org_x, w, -pad, ref.width);
+            w = (int16_t)(w < 8 ? w : (w & ~0x07));
+            clip_axis(oy, org_y, h, -pad, ref.height);
+            ops += (unsigned long long)max((int)h, 0) * max((int)w, 0) * rows * bw;
+            ww[q] = w, orgx[q] = org_x, orgy[q] = org_y, hh[q] = h;
+            wx[q] = ox + org_x, wy[q] = oy + org_y;
+            quick = quick && w == 8 && h >= 1 && h <= 3;
+        }
+        if (lane == 0) count_ops(p, 2 + level, ops);
+        const uint32_t *src = level == 1 ? src1 : src2;
+        u64             key[4];
+        if (quick && level == 1) {
+            wave_sync();
+            quick_stage<8, 3, 4>(win, ref, rows, wx, wy, hh);
+            wave_sync();
+#pragma unroll
+            for (int q = 0; q < 4; ++q) key[q] = quick_scan<8, 3>(src, win + q * QuickGeo<8, 3>::WIN, rows, hh[q]);
+            wave_sync();
+        } else if (quick) { // the 64-pixel block's windows: two at a time
+#pragma unroll
+            for (int half = 0; half < 2; ++half) {
+                const int wxp[2] = {wx[2 * half], wx[2 * half + 1]}, wyp[2] = {wy[2 * half], wy[2 * half + 1]};
+                const int hp[2]  = {hh[2 * half], hh[2 * half + 1]};
+                wave_sync();
+                quick_stage<16, 3, 2>(win, ref, rows, wxp, wyp, hp);
+                wave_sync();
+                key[2 * half]     = quick_scan<16, 3>(src, win, rows, hp[0]);
+                key[2 * half + 1] = quick_scan<16, 3>(src, win + QuickGeo<16, 3>::WIN, rows, hp[1]);
+            }
+            wave_sync();
+        } else {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) key[q] = small_search<false>(src, win, ref, bw, rows, wx[q], wy[q], ww[q], hh[q]);
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int i = (q & 1) * 2 + (q >> 1);
+            uint32_t  sad;
+            decode_key(key[q], ww[q], orgx[q], orgy[q], level == 1 ? 2 : 1, cx[q], cy[q], sad, true);
+            if (lane == 0) {
+                rec->lx[level][i]   = cx[q];
+                rec->ly[level][i]   = cy[q];
+                rec->lsad[level][i] = sad;
+            }
+        }
+    }
+}
+
+constexpr int HI_WIN2_DWORDS_ALL = 2 * QuickGeo<16, 3>::WIN > 4 * QuickGeo<8, 3>::WIN ? 2 * QuickGeo<16, 3>::WIN : 4 * QuickGeo<8, 3>::WIN;
+static_assert(HI_WIN2_DWORDS_ALL * 4 >= HI_WIN2_BYTES, "small_search's window fits too");
+
+// One wave per (b64, reference): the 2 x 2 regions' levels 1 and 2 (sub-sampled searches only).
+template <class PICS>
+__global__ void __launch_bounds__(HI_THREADS) hme_l12_regions_kernel(PICS pp) {
+    __shared__ L12Shared<false>       S;
+    __shared__ __align__(16) uint32_t win[HI_WIN2_DWORDS_ALL + 64];
+    const auto &p = pp[blockIdx.y];
+    const auto &k = p.ctrl;
+    const int   n_refs = p.n_ref[0] + (p.n_list == 2 ? p.n_ref[1] : 0);
+    int         b64, item;
+    if (!b64_band_item(blockIdx.x, p.b64_w * p.b64_h, n_refs, b64, item)) return;
+    const int b64x = (b64 % p.b64_w) * 64, b64y = (b64 / p.b64_w) * 64;
+    const int block_w = min(p.width - b64x, 64), block_h = min(p.height - b64y, 64);
+    int       l = 0, r = item;
+    if (r >= p.n_ref[0]) {
+        r -= p.n_ref[0];
+        l = 1;
+    }
+    if (!ref_searched(p, l) || !k.enable_hme_flag) return;
+    stage_l12_blocks<false>(p, S, b64x, b64y, block_w, block_h);
+    wave_sync();
+    l12_regions(p, S.src1, S.src2, win, b64x, b64y, block_w, block_h, l, r, &p.hme_out[(b64 * SVTME_MAX_LISTS + l) * SVTME_MAX_REFS + r]);
+}
+
+void launch_hme_l12_regions(const Batch &b, hipStream_t s) {
+    const dim3 grid((b.n_b64() + 7) / 8 * 8 * b.max_refs(), b.n);
+    if (b.n == 1) hipLaunchKernelGGL((hme_l12_regions_kernel<OnePicture>), grid, dim3(HI_THREADS), 0, s, OnePicture{b.host[0]});
+    else hipLaunchKernelGGL((hme_l12_regions_kernel<ManyPictures>), grid, dim3(HI_THREADS), 0, s, ManyPictures{b.dev});
+}
+#endif
 
 } // namespace svtme

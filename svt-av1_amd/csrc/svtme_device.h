@@ -151,6 +151,7 @@ void launch_store_build(const uint8_t *luma, int luma_stride, const DevPicture &
 void launch_params_write(const PicParams *host, PicParams *dev, int n, hipStream_t s); // n records -> device memory, by kernel
 void launch_hme(const Batch &b, hipStream_t s, hipEvent_t marks[2]); // picks the serial or the itemised kernels
 void launch_hme_items(const Batch &b, hipStream_t s, hipEvent_t marks[2]);
+void launch_hme_l12_regions(const Batch &b, hipStream_t s); // hme_regions.hip: levels 1 / 2, a work item per (b64, reference)
 void launch_me(const Batch &b, hipStream_t s, hipEvent_t marks[3]);
 void launch_tail(const Batch &b, hipStream_t s); // after launch_me, when the pictures have a device tail
 

@@ -13,7 +13,7 @@ if [ "$what" != run ]; then
     /opt/rocm/bin/hipcc --offload-arch=gfx950 -O2 -g -std=c++17 -fPIC -shared -Wall -Wno-unused-function \
         -Xarch_host -fsanitize=address -Xarch_host -fsanitize=undefined -Xarch_host -fno-sanitize-recover=undefined \
         -shared-libsan -o "$OUT/libsvtme.so" \
-        "$C/engine.cpp" "$C/group.cpp" "$C/controls.cpp" "$C/store_kernels.hip" "$C/hme_kernel.hip" "$C/hme_items.hip" "$C/me_kernel.hip" "$C/tail_kernel.hip" "$C/gm_kernels.hip" "$C/tpl_kernels.hip"
+        "$C/engine.cpp" "$C/group.cpp" "$C/controls.cpp" "$C/store_kernels.hip" "$C/hme_kernel.hip" "$C/hme_items.hip" "$C/hme_regions.hip" "$C/me_kernel.hip" "$C/tail_kernel.hip" "$C/gm_kernels.hip" "$C/tpl_kernels.hip"
     /opt/rocm/lib/llvm/bin/clang -std=gnu99 -O1 -g -Wall -Wextra -fsanitize=address,undefined -fno-sanitize-recover=undefined \
         -shared-libsan -I "$ROOT/include" "$ROOT/tools/san_driver.c" -o "$OUT/san_driver" \
         -L "$OUT" -lsvtme -Wl,-rpath,'$ORIGIN' -Wl,-rpath,/opt/rocm/lib -Wl,-rpath,"$RT"
