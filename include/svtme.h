@@ -256,16 +256,32 @@ typedef struct svtme_picture {
     uint8_t  me_type; /* SVTME_ME_OPEN_LOOP (or 0), SVTME_ME_MCTF or SVTME_ME_FIRST_PASS */
     uint8_t  bypass_zz_check; /* SVTME_ME_FIRST_PASS only */
     uint8_t  restricted_motion_vector; /* scs->static_config.restricted_motion_vector: the integer search window stays inside
-                                          the tile instead of the padded picture (EbMotionEstimation.c:1405-1430, :1465-1495).
-                                          The open-loop ME always sees one tile = the picture (EbPictureControlSet.c:1684-1688);
-                                          the engine uses the picture for every me_type, so temporal-filter / first-pass
-                                          searches of multi-tile sequences with this option stay on the CPU */
+                                          the block's tile instead of the padded picture (EbMotionEstimation.c:1405-1437,
+                                          :1467-1498). The open-loop ME always sees one tile = the picture
+                                          (EbPictureControlSet.c:1684-1688); temporal-filter and first-pass searches take
+                                          the tiles of svtme_set_tile_rects() (:1408-1410), the picture when none are set */
     uint64_t ref_key[SVTME_MAX_LISTS][SVTME_MAX_REFS]; /* store keys of pcs->ref_pa_pic_ptr_array */
     uint64_t ref_picture_number[SVTME_MAX_LISTS][SVTME_MAX_REFS];
     svtme_controls ctrl;
     svtme_tail     tail;
     uint32_t       tf_me_exit_th; /* MeContext::tf_me_exit_th = pcs->tf_ctrls.me_exit_th; SVTME_ME_MCTF only */
 } svtme_picture;
+
+/* The tile of one 64x64 block: SbParams::tile_start_x, tile_start_y, tile_end_x, tile_end_y in the reference's order
+ * (EbPictureControlSet.h:483-486), in luma pixels, end exclusive. */
+typedef struct svtme_tile_rect {
+    uint32_t start_x, start_y, end_x, end_y;
+} svtme_tile_rect;
+
+/* Hands the engine scs->sb_params_array's tile fields as EbResourceCoordinationProcess.c:1304-1349 fills them for a
+ * sequence with restricted_motion_vector: rects[n_b64] in raster order for pictures of width x height. From then on the
+ * integer search of SVTME_ME_MCTF and SVTME_ME_FIRST_PASS pictures of that size submitted with restricted_motion_vector
+ * keeps each block's window inside its tile, as integer_search_b64 does with scs->sb_params_array
+ * (EbMotionEstimation.c:1405-1498); SVTME_ME_OPEN_LOOP pictures keep the picture as their tile, as the reference does with
+ * pcs->sb_params_array. A sequence-level call: it waits for the searches in flight, then replaces the table;
+ * rects == NULL clears it. Every bound must lie inside 0..width / 0..height (SVTME_ERR_BAD_ARG otherwise); a restricted
+ * temporal-filter / first-pass picture of another size than the table's is refused with SVTME_ERR_BAD_ARG. */
+int svtme_set_tile_rects(svtme_engine *e, uint32_t width, uint32_t height, const svtme_tile_rect *rects, uint32_t n_b64);
 
 /* SearchResults, EbMotionEstimationContext.h:330-337, as left by hme_prune_ref_and_adjust_sr: the same six fields at the
  * same offsets (0, 1, 2, 4, 8, 16) in the same 24 bytes on the LP64 / Win64 ABIs the encoder builds for, so an array of
@@ -405,6 +421,8 @@ int svtme_group_stats(svtme_group *g, uint64_t *pictures, uint64_t *sources, uin
  * svtme_group_gm_set_tables: svtme_gm_set_tables on every engine of the group. */
 int svtme_group_engine_for(svtme_group *g, const uint64_t *keys, uint32_t n_keys, svtme_engine **engine);
 int svtme_group_gm_set_tables(svtme_group *g, const int16_t *warped_filter, const int32_t *error_measure_lut);
+/* svtme_set_tile_rects on every engine of the group */
+int svtme_group_set_tile_rects(svtme_group *g, uint32_t width, uint32_t height, const svtme_tile_rect *rects, uint32_t n_b64);
 
 /* ---- Global-motion estimation: the data-parallel stages of compute_global_motion
  * (Source/Lib/Encoder/Codec/EbGlobalMotionEstimation.c:155-301) on the planes the store already holds. The encoder keeps

@@ -785,8 +785,8 @@ static uint32_t orc_check_00(orc_ctx *c, const orc_pic *pic, int l, int r, int o
     return hme_sad;
 }
 
-/* integer_search_b64 :1286-1570 with open_loop_me_fullpel_search_sblock :808-844 (restricted_motion_vector off) */
-static void orc_integer_search(orc_ctx *c, const orc_pic *pic, int ox, int oy) {
+/* integer_search_b64 :1286-1570 with open_loop_me_fullpel_search_sblock :808-844 */
+static void orc_integer_search(orc_ctx *c, const orc_pic *pic, uint32_t b64_index, int ox, int oy) {
     const svtme_controls *k   = &pic->ctrl;
     const orc_plane      *cur = &pic->cur->lvl[2];
     for (int l = 0; l < pic->n_list; ++l)
@@ -820,11 +820,18 @@ static void orc_integer_search(orc_ctx *c, const orc_pic *pic, int ox, int oy) {
                 }
             }
             int16_t org_x = (int16_t)(cx - (w >> 1)), org_y = (int16_t)(cy - (h >> 1));
-            /* restricted motion vectors: the tile (here: the picture) instead of the padded picture bounds the window */
-            const int lo = pic->restricted_motion_vector ? 0 : -63;
-            orc_clip_axis(ox, &org_x, &w, lo, (int)pic->width);
+            /* restricted motion vectors: the block's tile instead of the padded picture bounds the window, :1405-1498 */
+            int lo_x = -63, lo_y = -63, hi_x = (int)pic->width, hi_y = (int)pic->height;
+            if (pic->restricted_motion_vector) {
+                lo_x = lo_y = 0;
+                if (pic->tile_rects && (pic->me_type == 1 || pic->me_type == 4)) {
+                    const svtme_tile_rect *t = &pic->tile_rects[b64_index];
+                    lo_x = (int)t->start_x, lo_y = (int)t->start_y, hi_x = (int)t->end_x, hi_y = (int)t->end_y;
+                }
+            }
+            orc_clip_axis(ox, &org_x, &w, lo_x, hi_x);
             w = (int16_t)(w < 8 ? w : (w & ~0x07));
-            orc_clip_axis(oy, &org_y, &h, lo, (int)pic->height);
+            orc_clip_axis(oy, &org_y, &h, lo_y, hi_y);
 
             uint32_t *bs = c->best_sad[l][r], *bm = c->best_mv[l][r];
             for (int i = 0; i < 85; ++i) bs[i] = SVTME_MAX_SAD_VALUE; /* svt_initialize_buffer_32bits :1542 */
@@ -1071,7 +1078,7 @@ void orc_me_b64(orc_ctx *c, const orc_pic *pic, uint32_t b64_index, ref_b64_dump
     }
     const int prune_ref = k->enable_hme_flag && pic->me_type != 1;
     if (prune_ref && (k->enable_me_sr_adjustment || k->enable_me_hme_ref_pruning)) orc_hme_prune(c, pic);
-    orc_integer_search(c, pic, ox, oy);
+    orc_integer_search(c, pic, b64_index, ox, oy);
 
     if (run_tail && pic->me_type != 1) orc_tail(c, pic); /* :2977 */
     orc_dump(c, pic, out);

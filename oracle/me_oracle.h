@@ -56,9 +56,12 @@ typedef struct orc_pic {
      * bypass_zz_check), and MeContext::tf_me_exit_th */
     uint8_t  me_type;
     uint8_t  bypass_zz_check; /* scs->ipp_pass_ctrls.bypass_zz_check, ME_FIRST_PASS only */
-    uint8_t  restricted_motion_vector; /* scs->static_config.restricted_motion_vector with one tile: the integer search
-                                          window stays inside the picture (EbMotionEstimation.c:1405-1430, :1465-1495) */
+    uint8_t  restricted_motion_vector; /* scs->static_config.restricted_motion_vector: the integer search window stays
+                                          inside the block's tile (EbMotionEstimation.c:1405-1437, :1467-1498) */
     uint16_t tf_me_exit_th;
+    /* scs->sb_params_array's tile fields per 64x64 block, read by ME_MCTF and ME_FIRST_PASS searches (:1408-1410); NULL, or
+     * an open-loop search (pcs->sb_params_array, EbPictureControlSet.c:1684-1688): the picture is the tile */
+    const svtme_tile_rect *tile_rects;
 } orc_pic;
 
 typedef struct orc_ctx orc_ctx; /* per-"thread" MeContext equivalent; state persists between b64s */

@@ -34,6 +34,28 @@ static uint8_t enable_me_8x8(int m, int res) {
     return !disallow;
 }
 
+/* scs->sb_params_array's tile fields for uniform tiles of (tile_b64 & 15) x (tile_b64 >> 4) 64x64 blocks, as
+ * EbResourceCoordinationProcess.c:1304-1349 leaves them (see ref_job_pic::tile_b64) */
+static svtme_tile_rect *make_tile_rects(const ref_job_header *h, uint8_t tile_b64) {
+    const uint32_t   bw = (h->width + 63) / 64, bh = (h->height + 63) / 64, tw = tile_b64 & 15, th = tile_b64 >> 4;
+    svtme_tile_rect *t = (svtme_tile_rect *)calloc((size_t)bw * bh, sizeof(*t));
+    if (!t) die("out of memory");
+    for (uint32_t i = 0; i < bw * bh; ++i) {
+        const uint32_t bx = i % bw, by = i / bw;
+        t[i].end_x = h->width;
+        t[i].end_y = h->height;
+        if (tw) {
+            t[i].start_x = bx / tw * tw * 64;
+            t[i].end_x   = t[i].start_x + tw * 64 < h->width ? t[i].start_x + tw * 64 : h->width;
+        }
+        if (th) {
+            t[i].start_y = by / th * th * 64;
+            t[i].end_y   = t[i].start_y + th * 64 < h->height ? t[i].start_y + th * 64 : h->height;
+        }
+    }
+    return t;
+}
+
 static void fill_pic(orc_pic *p, const ref_job_header *h, const ref_job_pic *jp, const orc_planes *planes) {
     memset(p, 0, sizeof(*p));
     p->width = h->width;
@@ -77,6 +99,7 @@ static void fill_pic(orc_pic *p, const ref_job_header *h, const ref_job_pic *jp,
     p->gm_enabled = jp->gm_enabled;
     p->gm_use_distance_based_active_th = jp->gm_dist_th;
     p->restricted_motion_vector = jp->restricted_motion_vector;
+    if (jp->tile_b64) p->tile_rects = make_tile_rects(h, jp->tile_b64); /* lives as long as the process */
     if (jp->me_type == 4) { /* firstpass.c:1273-1276 and set_gm_controls(pcs, 0), :702-703 */
         p->max_cand = 3;
         p->max_refs = 2;

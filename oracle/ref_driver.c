@@ -247,7 +247,24 @@ static void setup_pic(const Job *job, uint32_t pi, PicState *st) {
         sp->height = (uint8_t)((h - by * 64) < 64 ? (h - by * 64) : 64);
         sp->tile_start_x = 0; sp->tile_start_y = 0; sp->tile_end_x = w; sp->tile_end_y = h;
     }
-    scs->sb_params_array = pcs->sb_params_array;
+    /* The sequence's own array: ME_MCTF and ME_FIRST_PASS read their tiles from it (EbMotionEstimation.c:1408-1410), the
+     * open-loop search reads the picture's array above, whose one tile is the picture (EbPictureControlSet.c:1684-1688).
+     * Tile fields as EbResourceCoordinationProcess.c:1304-1349 leaves them for uniform tiles of tw x th 64x64 blocks. */
+    scs->sb_params_array = (SbParams *)calloc(st->n_b64, sizeof(SbParams));
+    memcpy(scs->sb_params_array, pcs->sb_params_array, st->n_b64 * sizeof(SbParams));
+    const uint32_t tw = jp->tile_b64 & 15, th = jp->tile_b64 >> 4;
+    for (uint32_t i = 0; i < st->n_b64; ++i) {
+        SbParams *sp = &scs->sb_params_array[i];
+        uint32_t  bx = i % st->b64_w, by = i / st->b64_w;
+        if (tw) {
+            sp->tile_start_x = bx / tw * tw * 64;
+            sp->tile_end_x   = (sp->tile_start_x + tw * 64) < w ? (sp->tile_start_x + tw * 64) : w;
+        }
+        if (th) {
+            sp->tile_start_y = by / th * th * 64;
+            sp->tile_end_y   = (sp->tile_start_y + th * 64) < h ? (sp->tile_start_y + th * 64) : h;
+        }
+    }
 
     pcs->rc_me_distortion            = (uint32_t *)calloc(st->n_b64, 4);
     pcs->me_64x64_distortion         = (uint32_t *)calloc(st->n_b64, 4);
@@ -294,6 +311,7 @@ static void free_pic(PicState *st) {
     free(st->me_data->me_results);
     free(st->me_data);
     free(pcs->sb_params_array);
+    free(st->scs->sb_params_array);
     free(pcs->rc_me_distortion); free(pcs->me_64x64_distortion); free(pcs->me_32x32_distortion);
     free(pcs->me_16x16_distortion); free(pcs->me_8x8_distortion); free(pcs->me_8x8_cost_variance);
     free(pcs->stationary_block_present_sb); free(pcs->rc_me_allow_gm);
@@ -477,6 +495,8 @@ typedef struct Shim {
     int (*done)(svtme_engine *, svtme_ticket);
     int (*unpack)(const svtme_results *, uint32_t, uint32_t *, uint32_t *, svtme_search_result *, uint32_t *, uint32_t *);
     int (*tpl_search)(svtme_engine *, const svtme_tpl_picture *, svtme_tpl_block *);
+    int (*set_tile_rects)(svtme_engine *, uint32_t, uint32_t, const svtme_tile_rect *, uint32_t);
+    int tiles_set;
 } Shim;
 
 static void *shim_sym(Shim *s, const char *name) {
@@ -503,6 +523,7 @@ static void shim_open(Shim *s, const char *lib, const Job *job) {
     *(void **)&s->done      = shim_sym(s, "svtme_picture_done");
     *(void **)&s->unpack    = shim_sym(s, "svtme_unpack_b64");
     *(void **)&s->tpl_search = shim_sym(s, "svtme_tpl_search");
+    *(void **)&s->set_tile_rects = shim_sym(s, "svtme_set_tile_rects");
     svtme_config cfg;
     memset(&cfg, 0, sizeof(cfg));
     cfg.max_width     = job->hdr.width;
@@ -560,6 +581,19 @@ static void run_pic_shim(Shim *s, const Job *job, uint32_t pi, PicState *st) {
             d.ref_picture_number[l][r] = jp->ref_poc[l][r];
         }
     fill_controls(&d.ctrl, m);
+    /* once per sequence, where resource coordination has filled scs->sb_params_array's tiles
+     * (EbResourceCoordinationProcess.c:1304-1349): the four tile fields of every 64x64 block */
+    if (scs->static_config.restricted_motion_vector && !s->tiles_set) {
+        svtme_tile_rect *t = (svtme_tile_rect *)calloc(st->n_b64, sizeof(*t));
+        if (!t) die("out of memory");
+        for (uint32_t i = 0; i < st->n_b64; ++i) {
+            const SbParams *sp = &scs->sb_params_array[i];
+            t[i].start_x = sp->tile_start_x, t[i].start_y = sp->tile_start_y, t[i].end_x = sp->tile_end_x, t[i].end_y = sp->tile_end_y;
+        }
+        if (s->set_tile_rects(s->engine, pcs->aligned_width, pcs->aligned_height, t, st->n_b64) != SVTME_OK) die("svtme_set_tile_rects failed");
+        free(t);
+        s->tiles_set = 1;
+    }
     svtme_ticket  ticket;
     svtme_results res;
     if (s->submit(s->engine, &d, &ticket) != SVTME_OK) die("svtme_picture_submit failed");

@@ -64,10 +64,15 @@ typedef struct ref_job_pic {
     uint8_t  me_type;
     uint8_t  tf_hme_me_level;
     uint16_t tf_me_exit_th;
-    uint8_t  restricted_motion_vector; /* scs->static_config.restricted_motion_vector (single tile) */
+    uint8_t  restricted_motion_vector; /* scs->static_config.restricted_motion_vector */
     uint8_t  tpl_level; /* REF_MODE_TPL: set_tpl_extended_controls' level (EbResourceCoordinationProcess.c:161-341) */
     uint8_t  tpl_qp; /* REF_MODE_TPL: scs->static_config.qp */
-    uint8_t  pad[1];
+    /* Uniform tiles of (tile_b64 & 15) x (tile_b64 >> 4) 64x64 blocks, 0 = the picture is one tile in that direction.
+     * The drivers fill scs->sb_params_array[].tile_{start,end}_{x,y} with what EbResourceCoordinationProcess.c:1304-1349
+     * leaves there for such a grid (tile ends clipped to the picture). With restricted_motion_vector the temporal filter's
+     * and the first pass's integer searches keep their windows inside a block's tile (EbMotionEstimation.c:1405-1498); the
+     * open-loop search reads pcs->sb_params_array, whose one tile is the picture (EbPictureControlSet.c:1684-1688). */
+    uint8_t  tile_b64;
 } ref_job_pic;
 
 typedef struct ref_out_header {

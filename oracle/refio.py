@@ -70,20 +70,22 @@ TPL_BLK_DUMP = np.dtype([
 ])
 
 _HDR = "<8sIIIIIIIIII"
-_PIC = "<IIQiBBBBBBBB8I8QBBHBBBx"
+_PIC = "<IIQiBBBBBBBB8I8QBBHBBBB"
 _OUT = "<8sIIIIIIdQ"
 
 
 def write_job(path, frames, pics, enc_mode, *, mode=MODE_DUMP, threads=1, use_avx2=0, reps=1,
               frame_rate=30 << 16, sc_class1=0, gm_enabled=0, gm_dist_th=0, ref_counts=(4, 3), tf=None, first_pass=None,
-              restricted_motion_vector=0, number_scale=1, tpl=(0, 0)):
+              restricted_motion_vector=0, number_scale=1, tpl=(0, 0), tiles=(0, 0)):
     """frames: uint8 [n, h, w]; pics: list of svtme.gop.Picture (refs are POCs = frame indices).
     tf = (hme_me_level, me_exit_th) runs every picture as a temporal-filter search (ME_MCTF) of its first list-0
     reference: the controls then come from tf_signal_derivation_me_kernel_oq and enc_mode is not used.
     first_pass = (bypass_zz_check, reduce_me_search) runs every picture as first-pass ME (ME_FIRST_PASS): controls from
     first_pass_signal_derivation_me_kernel; enc_mode only selects the HME level flags.
     number_scale: picture numbers are poc * number_scale (frames stay indexed by poc): stretches the picture distances.
-    tpl = (tpl_level, qp): MODE_TPL runs the TPL dispenser with these after every picture's ME."""
+    tpl = (tpl_level, qp): MODE_TPL runs the TPL dispenser with these after every picture's ME.
+    tiles = (w, h): uniform tiles of w x h 64x64 blocks (0 = one tile in that direction), at most 15 each; they bound the
+    windows of temporal-filter and first-pass searches when restricted_motion_vector is set."""
     variant = (1, tf[0], tf[1]) if tf else ((4, (first_pass[0] & 1) | ((first_pass[1] & 1) << 1), 0) if first_pass else (0, 0, 0))
     n, h, w = frames.shape
     with open(path, "wb") as f:
@@ -99,7 +101,7 @@ def write_job(path, frames, pics, enc_mode, *, mode=MODE_DUMP, threads=1, use_av
             f.write(struct.pack(_PIC, p.poc, frame_rate, p.poc * number_scale, enc_mode, p.temporal_layer, p.is_ref, n_list,
                                 len(p.refs[0]), len(p.refs[1]), sc_class1, gm_enabled, gm_dist_th,
                                 *rf[0], *rf[1], *[r * number_scale for r in rf[0] + rf[1]], *variant, restricted_motion_vector,
-                                tpl[0], tpl[1]))
+                                tpl[0], tpl[1], (tiles[0] & 15) | ((tiles[1] & 15) << 4)))
 
 
 def read_dump(path):

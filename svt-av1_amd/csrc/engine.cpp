@@ -193,6 +193,10 @@ struct svtme_engine {
     size_t              upload_bytes = 0;
     GmState             gm;
     uint64_t            put_gen = 0;
+    // the sequence's tiles per 64x64 block (svtme_set_tile_rects): room for max_b64 records, valid for pictures of
+    // tiles_w x tiles_h (0: none set)
+    svtme_tile_rect    *d_tiles = nullptr;
+    uint32_t            tiles_w = 0, tiles_h = 0;
 };
 
 namespace {
@@ -324,7 +328,8 @@ extern "C" int svtme_create(const svtme_config *cfg, svtme_engine **out) {
     const size_t n_params = 2 * (size_t)cfg->max_in_flight + SVTME_MAX_BATCH;
     e->param_busy.assign(n_params, 0);
     if (hipMalloc((void **)&e->d_params, (n_params + 1) * sizeof(PicParams)) != hipSuccess ||
-        hipHostMalloc((void **)&e->h_params, (n_params + 1) * sizeof(PicParams), hipHostMallocDefault) != hipSuccess)
+        hipHostMalloc((void **)&e->h_params, (n_params + 1) * sizeof(PicParams), hipHostMallocDefault) != hipSuccess ||
+        hipMalloc((void **)&e->d_tiles, e->max_b64 * sizeof(svtme_tile_rect)) != hipSuccess)
         return fail(SVTME_ERR_NO_RESOURCES);
 
     *out = e;
@@ -352,6 +357,7 @@ extern "C" void svtme_destroy(svtme_engine *e) {
             if (ev) (void)hipEventDestroy(ev);
     if (e->d_params) (void)hipFree(e->d_params);
     if (e->h_params) (void)hipHostFree(e->h_params);
+    if (e->d_tiles) (void)hipFree(e->d_tiles);
     {
         GmState &g = e->gm;
         void    *dev[] = {g.d_score, g.d_keep, g.d_rows, g.d_corners[0], g.d_corners[1], g.d_match, g.d_block_err, g.d_result, g.d_filter, g.d_lut, g.d_tpl};
@@ -552,6 +558,30 @@ extern "C" int svtme_store_read(svtme_engine *e, uint64_t key, int level, uint8_
     return SVTME_OK;
 }
 
+extern "C" int svtme_set_tile_rects(svtme_engine *e, uint32_t width, uint32_t height, const svtme_tile_rect *rects, uint32_t n_b64) {
+    if (!e) return SVTME_ERR_BAD_ARG;
+    if (rects) {
+        if (width < 64 || height < 64 || width > e->cfg.max_width || height > e->cfg.max_height ||
+            n_b64 != ((width + 63) / 64) * ((height + 63) / 64))
+            return SVTME_ERR_BAD_ARG;
+        // the bounds keep every window the plan kernel derives from them on the padded planes
+        for (uint32_t i = 0; i < n_b64; ++i)
+            if (rects[i].start_x > width || rects[i].end_x > width || rects[i].start_y > height || rects[i].end_y > height)
+                return SVTME_ERR_BAD_ARG;
+    }
+    std::lock_guard<std::mutex> lock(e->mu);
+    DEVICE_OR_FAIL(e->cfg.device);
+    // pictures in flight may still read the table
+    for (auto sm : e->s_me)
+        if (sm) HIP_TRY(hipStreamSynchronize(sm));
+    e->tiles_w = e->tiles_h = 0;
+    if (!rects) return SVTME_OK;
+    HIP_TRY(hipMemcpy(e->d_tiles, rects, (size_t)n_b64 * sizeof(svtme_tile_rect), hipMemcpyHostToDevice));
+    e->tiles_w = width;
+    e->tiles_h = height;
+    return SVTME_OK;
+}
+
 // What both submit forms check of one picture description before anything is touched.
 static int check_picture(const svtme_picture *pic) {
     const svtme_controls &k = pic->ctrl;
@@ -617,6 +647,12 @@ static int fill_params(svtme_engine *e, const svtme_picture *pic, PicParams &p, 
     p.me_type       = pic->me_type ? pic->me_type : SVTME_ME_OPEN_LOOP;
     p.bypass_zz_check = pic->me_type == SVTME_ME_FIRST_PASS && pic->bypass_zz_check;
     p.restricted      = pic->restricted_motion_vector;
+    // the open-loop search reads the picture's own block parameters, whose one tile is the picture; the temporal filter
+    // and the first pass read the sequence's (EbMotionEstimation.c:1408-1410)
+    if (p.restricted && p.me_type != SVTME_ME_OPEN_LOOP && e->tiles_w) {
+        if (e->tiles_w != pic->width || e->tiles_h != pic->height) return SVTME_ERR_BAD_ARG;
+        p.tiles = e->d_tiles;
+    }
     p.tf_me_exit_th = pic->tf_me_exit_th;
     // a reference depends on an earlier one: pre-HME list-1 early exit (:1758-1768) and the HME level-0 area
     // rescaling from the first reference's vector (:1837-1851): those items run in a second launch

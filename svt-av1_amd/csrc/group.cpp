@@ -176,6 +176,13 @@ extern "C" int svtme_group_gm_set_tables(svtme_group *g, const int16_t *warped_f
     return SVTME_OK;
 }
 
+extern "C" int svtme_group_set_tile_rects(svtme_group *g, uint32_t width, uint32_t height, const svtme_tile_rect *rects, uint32_t n_b64) {
+    if (!g) return SVTME_ERR_BAD_ARG;
+    for (svtme_engine *e : g->engines)
+        if (const int rc = svtme_set_tile_rects(e, width, height, rects, n_b64)) return rc;
+    return SVTME_OK;
+}
+
 extern "C" int svtme_group_stats(svtme_group *g, uint64_t *pictures, uint64_t *sources, uint64_t *uploads) {
     if (!g) return SVTME_ERR_BAD_ARG;
     std::lock_guard<std::mutex> lock(g->mu);

@@ -285,11 +285,19 @@ __global__ void __launch_bounds__(ME_THREADS) me_plan_kernel(PICS pp, int n_b64,
         }
     }
     int16_t org_x = (int16_t)(cx - (w >> 1)), org_y = (int16_t)(cy - (h >> 1));
-    // restricted motion vectors: the tile (the picture) instead of the padded picture bounds the window (:1405-1495)
-    const int lo = p.restricted ? 0 : -63;
-    clip_axis(b64x, org_x, w, lo, p.width);
+    // restricted motion vectors: the block's tile instead of the padded picture bounds the window (:1405-1498); the
+    // open-loop search's one tile is the picture, the other searches may come with the sequence's tiles (:1408-1410)
+    int lo_x = -63, lo_y = -63, hi_x = p.width, hi_y = p.height;
+    if (p.restricted) {
+        lo_x = lo_y = 0;
+        if (p.tiles) {
+            const uint4 t = *reinterpret_cast<const uint4 *>(&p.tiles[b64]);
+            lo_x = (int)t.x, lo_y = (int)t.y, hi_x = (int)t.z, hi_y = (int)t.w;
+        }
+    }
+    clip_axis(b64x, org_x, w, lo_x, hi_x);
     w = (int16_t)(w < 8 ? w : (w & ~0x07));
-    clip_axis(b64y, org_y, h, lo, p.height);
+    clip_axis(b64y, org_y, h, lo_y, hi_y);
 
     if (tid == 0) {
         *job = MeJob{org_x, org_y, w, h};

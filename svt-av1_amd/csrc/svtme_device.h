@@ -65,11 +65,12 @@ struct PicParams {
     int32_t        dep_l0; // the level-0 area of every reference but the first depends on the first one's vector (:1838-1850)
     int32_t        me_type; // SVTME_ME_OPEN_LOOP / SVTME_ME_MCTF / SVTME_ME_FIRST_PASS
     int32_t        bypass_zz_check; // first pass only
-    int32_t        restricted; // integer search windows stay inside the picture (restricted_motion_vector, one tile)
+    int32_t        restricted; // integer search windows stay inside the block's tile (restricted_motion_vector)
     uint32_t       tf_me_exit_th;
     int32_t        me_max_items; // upper bound of search work items per (b64, ref) for this picture's controls
     int32_t        me_tall; // every window is at most 16 positions wide and 9..16 rows high: work items of 16 rows
     int32_t        zero; // always 0, but the compiler cannot know: keeps it from merging loads that must stay apart
+    const svtme_tile_rect *tiles; // [n_b64] the blocks' tiles for restricted windows; nullptr: the picture is the tile
     // intermediates
     MeJob              *me_jobs; // [n_b64][2][4]
     unsigned long long *me_keys; // [n_b64][2][4][85] running minima (SAD << 32 | y << 16 | x), window-relative

@@ -121,7 +121,7 @@ EXPORTS = ("svtme_version", "svtme_derive_controls", "svtme_derive_tf_controls",
            "svtme_group_picture_submit", "svtme_group_picture_wait", "svtme_group_picture_done", "svtme_group_stats",
            "svtme_group_engine_for", "svtme_group_gm_set_tables",
            "svtme_gm_set_tables", "svtme_gm_corners", "svtme_gm_correspondences", "svtme_gm_warp_error", "svtme_gm_frame_error",
-           "svtme_tpl_search")
+           "svtme_tpl_search", "svtme_set_tile_rects", "svtme_group_set_tile_rects")
 MAX_BATCH = 32
 GM_MAX_CORNERS = 4096
 
@@ -212,12 +212,42 @@ def load_library():
     lib.svtme_gm_warp_error.argtypes = [C.c_void_p, C.c_uint64, C.c_uint64, C.c_int, C.POINTER(GmWarp), C.c_int64, C.POINTER(C.c_int64)]
     lib.svtme_gm_frame_error.argtypes = [C.c_void_p, C.c_uint64, C.c_uint64, C.c_int, C.POINTER(C.c_int64)]
     lib.svtme_tpl_search.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+    lib.svtme_set_tile_rects.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p, C.c_uint32]
+    lib.svtme_group_set_tile_rects.argtypes = lib.svtme_set_tile_rects.argtypes
     _lib = lib
     return lib
 
 
 def input_resolution(width, height):
     return int(load_library().svtme_input_resolution(width, height))
+
+
+def uniform_tile_rects(width, height, tile_w_b64=0, tile_h_b64=0):
+    """svtme_tile_rect records [n_b64, 4] (start_x, start_y, end_x, end_y) of a grid of tiles of tile_w_b64 x tile_h_b64
+    64x64 blocks (0 = one tile in that direction), tile ends clipped to the picture: what
+    EbResourceCoordinationProcess.c:1304-1349 leaves in scs->sb_params_array for uniform tiles."""
+    bw, bh = (width + 63) // 64, (height + 63) // 64
+    r = np.zeros((bh, bw, 4), np.uint32)
+    r[..., 2], r[..., 3] = width, height
+    if tile_w_b64:
+        sx = (np.arange(bw) // tile_w_b64) * tile_w_b64 * 64
+        r[..., 0] = sx[None, :]
+        r[..., 2] = np.minimum(sx + tile_w_b64 * 64, width)[None, :]
+    if tile_h_b64:
+        sy = (np.arange(bh) // tile_h_b64) * tile_h_b64 * 64
+        r[..., 1] = sy[:, None]
+        r[..., 3] = np.minimum(sy + tile_h_b64 * 64, height)[:, None]
+    return r.reshape(bw * bh, 4)
+
+
+def _set_tile_rects(fn, name, handle, width, height, rects):
+    if rects is None:
+        rc = fn(handle, width, height, None, 0)
+    else:
+        arr = np.ascontiguousarray(rects, np.uint32).reshape(-1, 4)
+        rc = fn(handle, width, height, arr.ctypes.data, arr.shape[0])
+    if rc:
+        raise SvtmeError(rc, name)
 
 
 def derive_controls(enc_mode, width, height, sc_class1=0, frame_rate=30 << 16):
@@ -355,6 +385,9 @@ class Group:
         rc = self.lib.svtme_group_gm_set_tables(self.h, wf.ctypes.data, lut.ctypes.data)
         if rc:
             raise SvtmeError(rc, "svtme_group_gm_set_tables")
+
+    def set_tile_rects(self, width, height, rects):
+        _set_tile_rects(self.lib.svtme_group_set_tile_rects, "svtme_group_set_tile_rects", self.h, width, height, rects)
 
     def stats(self):
         v = [C.c_uint64() for _ in range(3)]
@@ -521,6 +554,11 @@ class Engine:
         if rc:
             raise SvtmeError(rc, "svtme_picture_search_static")
         return r
+
+    def set_tile_rects(self, width, height, rects):
+        """svtme_set_tile_rects: the sequence's tiles per 64x64 block ([n_b64, 4] as uniform_tile_rects gives them), which
+        bound the windows of restricted temporal-filter and first-pass searches; None clears them."""
+        _set_tile_rects(self.lib.svtme_set_tile_rects, "svtme_set_tile_rects", self.h, width, height, rects)
 
     # ---- global-motion estimation (svtme_gm_*): downsample level 0 / 1 / 2 = full / quarter / sixteenth plane
     def gm_set_tables(self, warped_filter, error_lut):

@@ -37,6 +37,10 @@ CASES = {
     # scs->static_config.restricted_motion_vector: integer search windows stay inside the picture
     "m8_rmv_192x128": dict(width=192, height=128, n_frames=9, enc_mode=8, seed=71, structure="ra", restricted=1, motion=(6, -5)),
     "m3_rmv_128x128": dict(width=128, height=128, n_frames=5, enc_mode=3, seed=72, structure="ra", restricted=1, motion=(-7, 4)),
+    # a sequence with tiles (of 1 x 1 64x64 blocks): the open-loop search reads the picture's own block parameters, whose one
+    # tile is the picture, so the tiles do not bound its windows
+    "m8_rmv_tiles_192x128": dict(width=192, height=128, n_frames=9, enc_mode=8, seed=73, structure="ra", restricted=1,
+                                 tiles=(1, 1), motion=(6, -5)),
 }
 # larger jobs: only sha256 digests of every dumped field are stored
 DIGEST_CASES = {
@@ -63,6 +67,12 @@ TF_CASES = {
     "tf2_flat_128x128": dict(width=128, height=128, n_frames=3, level=2, exit_th=16 * 16, seed=45, kind="flat"),
     "tf0_exit_200x136": dict(width=200, height=136, n_frames=5, level=0, exit_th=16 * 16, seed=46, kind="half_static",
                              motion=(-6, 4)),
+    # restricted_motion_vector in a sequence with tiles = (width, height) in 64x64 blocks: the integer search windows stay
+    # inside each block's tile (EbMotionEstimation.c:1405-1498 with scs->sb_params_array)
+    "tf0_tiles_320x192": dict(width=320, height=192, n_frames=5, level=0, exit_th=0, seed=47, restricted=1, tiles=(2, 1),
+                              motion=(9, -6)),
+    "tf2_tiles_264x200": dict(width=264, height=200, n_frames=5, level=2, exit_th=0, seed=48, restricted=1, tiles=(1, 2),
+                              motion=(-11, 7)),
 }
 TF_DIGEST_CASES = {
     "tf0_1920x1080": dict(width=1920, height=1080, n_frames=3, level=0, exit_th=0, seed=51, motion=(7, -3)),
@@ -77,6 +87,11 @@ FP_CASES = {
     "fp_static_256x128": dict(width=256, height=128, n_frames=4, bypass_zz=0, reduce_me=1, seed=63, kind="half_static"),
     "fp_fps60_1280x720": dict(width=1280, height=720, n_frames=3, bypass_zz=1, reduce_me=0, seed=64, frame_rate=60 << 16,
                               motion=(-7, 2)),
+    # restricted_motion_vector with tiles, as for the temporal filter
+    "fp_tiles_320x192": dict(width=320, height=192, n_frames=5, bypass_zz=0, reduce_me=0, seed=65, restricted=1, tiles=(2, 2),
+                             motion=(8, 5)),
+    "fp_tiles_fast_264x136": dict(width=264, height=136, n_frames=4, bypass_zz=1, reduce_me=1, seed=66, restricted=1,
+                                  tiles=(3, 1), motion=(-9, -6)),
 }
 
 
@@ -84,13 +99,15 @@ def fp_job(c):
     frames, pics = support.make_first_pass_job(c["width"], c["height"], c["n_frames"], c["seed"], c.get("kind", "synth"),
                                                c.get("motion", (3, -2)))
     return frames, pics, dict(first_pass=(c["bypass_zz"], c["reduce_me"]), frame_rate=c.get("frame_rate", 30 << 16),
-                              ref_counts=(2, 0), gm_enabled=1, gm_dist_th=1)
+                              ref_counts=(2, 0), gm_enabled=1, gm_dist_th=1, restricted_motion_vector=c.get("restricted", 0),
+                              tiles=c.get("tiles", (0, 0)))
 
 
 def tf_job(c):
     frames, pics = support.make_tf_job(c["width"], c["height"], c["n_frames"], c["seed"], c.get("kind", "synth"),
                                        c.get("motion", (3, -2)))
-    return frames, pics, dict(tf=(c["level"], c["exit_th"]))
+    return frames, pics, dict(tf=(c["level"], c["exit_th"]), restricted_motion_vector=c.get("restricted", 0),
+                              tiles=c.get("tiles", (0, 0)))
 
 
 def run_tf_case(c, threads=1):
@@ -111,7 +128,7 @@ def run_case(c, threads=1, use_avx2=0):
                                         c.get("structure", "ra"), c.get("kind", "synth"), c.get("motion", (3, -2)),
                                         bit_depth=c.get("bit_depth", 8))
     kw = dict(ref_counts=rc, sc_class1=c.get("sc_class1", 0), frame_rate=c.get("frame_rate", 30 << 16),
-              gm_enabled=1, gm_dist_th=1, restricted_motion_vector=c.get("restricted", 0))
+              gm_enabled=1, gm_dist_th=1, restricted_motion_vector=c.get("restricted", 0), tiles=c.get("tiles", (0, 0)))
     hdr, recs = refio.run_reference(frames, pics, c["enc_mode"], threads=threads, use_avx2=use_avx2, **kw)
     assert bool(hdr["used_avx2"]) == bool(use_avx2)
     return frames, pics, recs
@@ -153,7 +170,12 @@ def main():
         sys.exit("oracle/_ref/ref_me missing: run `make -C oracle ref` where /root/reference exists")
     if "--big" in sys.argv:
         return main_big()
+    # `make_golden.py --only name ...`: just these full-dump fixtures, digests.json untouched
+    only = sys.argv[sys.argv.index("--only") + 1:] if "--only" in sys.argv else None
+    want = lambda name: only is None or name in only  # noqa: E731
     for name, c in CASES.items():
+        if not want(name):
+            continue
         frames, pics, recs = run_case(c)
         pd = np.stack([r[0] for r in recs])
         bd = np.stack([r[1] for r in recs])
@@ -161,6 +183,8 @@ def main():
                             frames_sha256=np.array(hashlib.sha256(frames.tobytes()).hexdigest()))
         print(name, "pics", len(pics), "b64", bd.shape[1], "bytes", os.path.getsize(os.path.join(HERE, name + ".npz")))
     for name, c in TF_CASES.items():
+        if not want(name):
+            continue
         frames, pics, recs = run_tf_case(c)
         pd = np.stack([r[0] for r in recs])
         bd = np.stack([r[1] for r in recs])
@@ -169,6 +193,8 @@ def main():
         print(name, "pairs", len(pics), "b64", bd.shape[1], "exits", int(bd["tf_me_exit"].sum()), "bytes",
               os.path.getsize(os.path.join(HERE, name + ".npz")))
     for name, c in FP_CASES.items():
+        if not want(name):
+            continue
         frames, pics, kw = fp_job(c)
         hdr, recs = refio.run_reference(frames, pics, 8, threads=1, use_avx2=0, **kw)
         pd = np.stack([r[0] for r in recs])
@@ -176,6 +202,8 @@ def main():
         np.savez_compressed(os.path.join(HERE, name + ".npz"), pic=pd, b64=bd,
                             frames_sha256=np.array(hashlib.sha256(frames.tobytes()).hexdigest()))
         print(name, "pics", len(pics), "b64", bd.shape[1], "bytes", os.path.getsize(os.path.join(HERE, name + ".npz")))
+    if only is not None:
+        return
     digests = {}
     for name, c in TF_DIGEST_CASES.items():
         frames, pics, recs = run_tf_case(c, threads=8)

@@ -99,7 +99,7 @@ def compare_picture(out, bd, pic, where=""):
 
 
 def run_engine_job(frames, pics, enc_mode, sc_class1=0, frame_rate=30 << 16, engine=None, tail=None, serial_hme=0,
-                   restricted=0, number_scale=1):
+                   restricted=0, number_scale=1, tiles=None):
     """Runs every picture of the job through the engine's C ABI; returns the list of output dicts. tail: an
     svtme.Tail to run the host tail on the device as well."""
     import svtme
@@ -109,6 +109,7 @@ def run_engine_job(frames, pics, enc_mode, sc_class1=0, frame_rate=30 << 16, eng
     try:
         for i in range(n):
             eng.store_put(i, i, frames[i])
+        set_uniform_tiles(eng, w, h, tiles)
         ctrl = svtme.derive_controls(enc_mode, w, h, sc_class1, frame_rate)
         outs = []
         for p in pics:
@@ -121,7 +122,14 @@ def run_engine_job(frames, pics, enc_mode, sc_class1=0, frame_rate=30 << 16, eng
             eng.close()
 
 
-def run_engine_tf_job(frames, pics, level, exit_th, engine=None, serial_hme=0):
+def set_uniform_tiles(eng, w, h, tiles):
+    """tiles = (width, height) of the sequence's tiles in 64x64 blocks (0 = one tile that way), None / (0, 0): none."""
+    import svtme
+    if tiles and (tiles[0] or tiles[1]):
+        eng.set_tile_rects(w, h, svtme.uniform_tile_rects(w, h, *tiles))
+
+
+def run_engine_tf_job(frames, pics, level, exit_th, engine=None, serial_hme=0, restricted=0, tiles=None):
     """Temporal-filter searches (ME_MCTF) of a make_tf_job window through the engine's C ABI."""
     import svtme
     n, h, w = frames.shape
@@ -130,10 +138,12 @@ def run_engine_tf_job(frames, pics, level, exit_th, engine=None, serial_hme=0):
     try:
         for i in range(n):
             eng.store_put(i, i, frames[i])
+        set_uniform_tiles(eng, w, h, tiles)
         ctrl = svtme.derive_tf_controls(level)
         outs = []
         for p in pics:
-            pic = eng.make_picture(w, h, p.poc, p.temporal_layer, p.is_ref, p.refs, ctrl, tf_me_exit_th=exit_th)
+            pic = eng.make_picture(w, h, p.poc, p.temporal_layer, p.is_ref, p.refs, ctrl, tf_me_exit_th=exit_th,
+                                   restricted_motion_vector=restricted)
             outs.append(eng.run_picture(pic))
         return outs
     finally:
@@ -141,7 +151,7 @@ def run_engine_tf_job(frames, pics, level, exit_th, engine=None, serial_hme=0):
             eng.close()
 
 
-def run_engine_first_pass_job(frames, pics, bypass_zz, reduce_me, frame_rate=30 << 16, tail=None):
+def run_engine_first_pass_job(frames, pics, bypass_zz, reduce_me, frame_rate=30 << 16, tail=None, restricted=0, tiles=None):
     """First-pass searches (ME_FIRST_PASS) of a make_first_pass_job sequence through the engine's C ABI."""
     import svtme
     n, h, w = frames.shape
@@ -149,9 +159,11 @@ def run_engine_first_pass_job(frames, pics, bypass_zz, reduce_me, frame_rate=30 
     try:
         for i in range(n):
             eng.store_put(i, i, frames[i])
+        set_uniform_tiles(eng, w, h, tiles)
         ctrl = svtme.derive_first_pass_controls(w, h, frame_rate, reduce_me)
         return [eng.run_picture(eng.make_picture(w, h, p.poc, p.temporal_layer, p.is_ref, p.refs, ctrl, tail=tail,
-                                                 first_pass_bypass_zz=bypass_zz)) for p in pics]
+                                                 first_pass_bypass_zz=bypass_zz, restricted_motion_vector=restricted))
+                for p in pics]
     finally:
         eng.close()
 
@@ -188,12 +200,21 @@ def random_case(seed):
                 motion=(int(rng.integers(-14, 15)), int(rng.integers(-9, 10))), restricted=int(rng.random() < 0.2))
 
 
+def _random_tiles(seed):
+    """restricted_motion_vector and the sequence's tiles for half of the seeds (a generator of their own, so that a seed's
+    other fields do not depend on them)."""
+    rng = np.random.default_rng(seed + 991)
+    if rng.random() < 0.5:
+        return dict(restricted=0, tiles=(0, 0))
+    return dict(restricted=1, tiles=(int(rng.integers(0, 4)), int(rng.integers(0, 3))))
+
+
 def random_tf_case(seed):
     rng = np.random.default_rng(seed)
     return dict(width=int(rng.integers(8, 57)) * 8, height=int(rng.integers(8, 41)) * 8, n_frames=int(rng.integers(2, 6)),
                 seed=int(seed), kind=str(rng.choice(["synth", "synth", "synth", "half_static", "noise", "flat"])),
                 motion=(int(rng.integers(-14, 15)), int(rng.integers(-9, 10))), level=int(rng.integers(0, 3)),
-                exit_th=int(rng.choice([0, 0, 256, 4096])))
+                exit_th=int(rng.choice([0, 0, 256, 4096])), **_random_tiles(seed))
 
 
 def random_first_pass_case(seed):
@@ -201,7 +222,7 @@ def random_first_pass_case(seed):
     return dict(width=int(rng.integers(8, 57)) * 8, height=int(rng.integers(8, 41)) * 8, n_frames=int(rng.integers(2, 6)),
                 seed=int(seed), kind=str(rng.choice(["synth", "synth", "synth", "half_static", "noise", "flat"])),
                 motion=(int(rng.integers(-14, 15)), int(rng.integers(-9, 10))), bypass_zz=int(rng.integers(0, 2)),
-                reduce_me=int(rng.integers(0, 2)), frame_rate=int(rng.choice([24, 30, 60])) << 16)
+                reduce_me=int(rng.integers(0, 2)), frame_rate=int(rng.choice([24, 30, 60])) << 16, **_random_tiles(seed))
 
 
 STAT_FIELDS = ["rc_me_distortion", "me_64x64_distortion", "me_32x32_distortion", "me_16x16_distortion",

@@ -36,7 +36,7 @@ def test_engine_matches_reference_goldens(name):
     frames, pics, _ = support.make_job(c["width"], c["height"], c["n_frames"], c["enc_mode"], c["seed"],
                                        c.get("structure", "ra"), c.get("kind", "synth"), c.get("motion", (3, -2)))
     outs = support.run_engine_job(frames, pics, c["enc_mode"], c.get("sc_class1", 0), c.get("frame_rate", 30 << 16),
-                                  restricted=c.get("restricted", 0))
+                                  restricted=c.get("restricted", 0), tiles=c.get("tiles"))
     for i, (p, out) in enumerate(zip(pics, outs)):
         bd = g["b64"][i]
         pruning = bool(g["pic"][i]["ctrl"]["enable_me_hme_ref_pruning"])
@@ -101,8 +101,9 @@ def test_device_side_host_tail_matches_oracle_on_random_jobs(seed):
 def test_temporal_filter_search_matches_oracle_on_random_jobs(seed):
     c = support.random_tf_case(seed)
     frames, pics = support.make_tf_job(c["width"], c["height"], c["n_frames"], seed=c["seed"], kind=c["kind"], motion=c["motion"])
-    _, recs = refio.run_oracle(frames, pics, 0, mode=refio.MODE_DUMP_NOTAIL, threads=8, tf=(c["level"], c["exit_th"]))
-    outs = support.run_engine_tf_job(frames, pics, c["level"], c["exit_th"])
+    _, recs = refio.run_oracle(frames, pics, 0, mode=refio.MODE_DUMP_NOTAIL, threads=8, tf=(c["level"], c["exit_th"]),
+                               restricted_motion_vector=c["restricted"], tiles=c["tiles"])
+    outs = support.run_engine_tf_job(frames, pics, c["level"], c["exit_th"], restricted=c["restricted"], tiles=c["tiles"])
     for (pd, bd), out, p in zip(recs, outs, pics):
         want = MOD.tf_canonical(bd)
         for f, v in support.tf_fields(out).items():
@@ -115,9 +116,11 @@ def test_first_pass_search_matches_oracle_on_random_jobs(seed):
     frames, pics = support.make_first_pass_job(c["width"], c["height"], c["n_frames"], seed=c["seed"], kind=c["kind"],
                                                motion=c["motion"])
     _, recs = refio.run_oracle(frames, pics, 0, mode=refio.MODE_DUMP, threads=8,
-                               first_pass=(c["bypass_zz"], c["reduce_me"]), frame_rate=c["frame_rate"], ref_counts=(2, 0))
+                               first_pass=(c["bypass_zz"], c["reduce_me"]), frame_rate=c["frame_rate"], ref_counts=(2, 0),
+                               restricted_motion_vector=c["restricted"], tiles=c["tiles"])
     outs = support.run_engine_first_pass_job(frames, pics, c["bypass_zz"], c["reduce_me"], c["frame_rate"],
-                                             tail=support.tail_of(recs[0][0], gm_enabled=0))
+                                             tail=support.tail_of(recs[0][0], gm_enabled=0), restricted=c["restricted"],
+                                             tiles=c["tiles"])
     for p, out, (_, bd) in zip(pics, outs, recs):
         sr = out["search_results"]
         nr = len(p.refs[0])
@@ -199,9 +202,9 @@ def test_engine_results_through_the_host_tail_give_the_reference_final_state(nam
     frames, pics, rc = support.make_job(c["width"], c["height"], c["n_frames"], c["enc_mode"], c["seed"],
                                         c.get("structure", "ra"), c.get("kind", "synth"), c.get("motion", (3, -2)))
     kw = dict(ref_counts=rc, sc_class1=c.get("sc_class1", 0), frame_rate=c.get("frame_rate", 30 << 16), gm_enabled=1, gm_dist_th=1,
-              restricted_motion_vector=c.get("restricted", 0))
+              restricted_motion_vector=c.get("restricted", 0), tiles=c.get("tiles", (0, 0)))
     outs = support.run_engine_job(frames, pics, c["enc_mode"], c.get("sc_class1", 0), c.get("frame_rate", 30 << 16),
-                                  restricted=c.get("restricted", 0))
+                                  restricted=c.get("restricted", 0), tiles=c.get("tiles"))
     n_b64 = g["b64"].shape[1]
     hand = [support.handover_records(o, n_b64) for o in outs]
     _, tail = refio.run_oracle_tail(frames, pics, c["enc_mode"], hand, **kw)
@@ -222,7 +225,7 @@ def test_device_side_host_tail_matches_reference_final_state(name):
                       max_refs=int(pd0["max_refs"]), max_cand=int(pd0["max_cand"]), max_l0=int(pd0["max_l0"]),
                       input_resolution=int(pd0["input_resolution"]), gm_enabled=1, gm_use_distance_based_active_th=1)
     outs = support.run_engine_job(frames, pics, c["enc_mode"], c.get("sc_class1", 0), c.get("frame_rate", 30 << 16), tail=tail,
-                                  restricted=c.get("restricted", 0))
+                                  restricted=c.get("restricted", 0), tiles=c.get("tiles"))
     stat_names = ["rc_me_distortion", "me_64x64_distortion", "me_32x32_distortion", "me_16x16_distortion",
                   "me_8x8_distortion", "me_8x8_cost_variance", "stationary_block_present_sb", "rc_me_allow_gm"]
     for i, (p, out) in enumerate(zip(pics, outs)):
@@ -304,7 +307,7 @@ def test_temporal_filter_search_matches_reference_goldens(name):
     c = MOD.TF_CASES[name]
     g = np.load(os.path.join(GOLDEN, name + ".npz"))
     frames, pics, _ = MOD.tf_job(c)
-    outs = support.run_engine_tf_job(frames, pics, c["level"], c["exit_th"])
+    outs = support.run_engine_tf_job(frames, pics, c["level"], c["exit_th"], restricted=c.get("restricted", 0), tiles=c.get("tiles"))
     for i, (p, out) in enumerate(zip(pics, outs)):
         want = MOD.tf_canonical(g["b64"][i])
         for f, v in support.tf_fields(out).items():
@@ -359,6 +362,51 @@ def test_temporal_filter_search_argument_checks():
         eng.close()
 
 
+def test_tile_rects_argument_checks_and_clearing():
+    """svtme_set_tile_rects: shapes and bounds are checked, a restricted temporal-filter picture of another size than the
+    table's is refused, clearing the table gives the one-tile results again, and an unrestricted picture never reads it."""
+    w, h = 192, 128
+    frames, pics = support.make_tf_job(w, h, 3, seed=5, motion=(9, -6))
+    eng = svtme.Engine(256, 192, store_slots=8, max_in_flight=1)
+    try:
+        for i in range(3):
+            eng.store_put(i, i, frames[i])
+        ctrl = svtme.derive_tf_controls(0)
+        p = pics[0]
+        mk = lambda restricted: eng.make_picture(w, h, p.poc, p.temporal_layer, p.is_ref, p.refs, ctrl, tf_me_exit_th=0,  # noqa: E731
+                                                 restricted_motion_vector=restricted)
+        one_tile = eng.run_picture(mk(1))
+        free = eng.run_picture(mk(0))
+        rects = svtme.uniform_tile_rects(w, h, 1, 1)
+        for bad in (rects[:-1], np.concatenate([rects, rects[:1]])):
+            with pytest.raises(svtme.SvtmeError) as ei:
+                eng.set_tile_rects(w, h, bad)
+            assert ei.value.code == svtme.ERR_BAD_ARG
+        beyond = rects.copy()
+        beyond[2, 2] = w + 8
+        with pytest.raises(svtme.SvtmeError) as ei:
+            eng.set_tile_rects(w, h, beyond)
+        assert ei.value.code == svtme.ERR_BAD_ARG
+        with pytest.raises(svtme.SvtmeError) as ei:
+            eng.set_tile_rects(512, 512, svtme.uniform_tile_rects(512, 512, 1, 1))
+        assert ei.value.code == svtme.ERR_BAD_ARG
+        eng.set_tile_rects(w, h, rects)
+        tiled = eng.run_picture(mk(1))
+        assert not np.array_equal(tiled["best_mv"], one_tile["best_mv"]), "64x64 tiles must bind"
+        again = eng.run_picture(mk(0))
+        assert np.array_equal(again["best_mv"], free["best_mv"]) and np.array_equal(again["best_sad"], free["best_sad"])
+        # a table for another picture size: restricted temporal-filter pictures of this size are refused
+        eng.set_tile_rects(256, 192, svtme.uniform_tile_rects(256, 192, 2, 1))
+        with pytest.raises(svtme.SvtmeError) as ei:
+            eng.submit(mk(1))
+        assert ei.value.code == svtme.ERR_BAD_ARG
+        eng.set_tile_rects(w, h, None)
+        cleared = eng.run_picture(mk(1))
+        assert np.array_equal(cleared["best_mv"], one_tile["best_mv"]) and np.array_equal(cleared["best_sad"], one_tile["best_sad"])
+    finally:
+        eng.close()
+
+
 @pytest.mark.parametrize("name", sorted(MOD.FP_CASES))
 def test_first_pass_search_matches_reference_goldens(name):
     """ME_FIRST_PASS: search results against the real reference's dump, and - with the device tail - the candidate
@@ -371,7 +419,8 @@ def test_first_pass_search_matches_reference_goldens(name):
                       max_refs=int(pd0["max_refs"]), max_cand=int(pd0["max_cand"]), max_l0=int(pd0["max_l0"]),
                       input_resolution=int(pd0["input_resolution"]), gm_enabled=0)
     assert (tail.max_refs, tail.max_cand, tail.max_l0) == (2, 3, 1)
-    outs = support.run_engine_first_pass_job(frames, pics, c["bypass_zz"], c["reduce_me"], c.get("frame_rate", 30 << 16), tail=tail)
+    outs = support.run_engine_first_pass_job(frames, pics, c["bypass_zz"], c["reduce_me"], c.get("frame_rate", 30 << 16), tail=tail,
+                                             restricted=c.get("restricted", 0), tiles=c.get("tiles"))
     stat_names = ["rc_me_distortion", "me_64x64_distortion", "me_32x32_distortion", "me_16x16_distortion",
                   "me_8x8_distortion", "me_8x8_cost_variance", "stationary_block_present_sb", "rc_me_allow_gm"]
     for i, (p, out) in enumerate(zip(pics, outs)):

@@ -42,7 +42,7 @@ def test_engine_plus_the_reference_host_tail_equals_the_reference(name):
     frames, pics, rc = support.make_job(c["width"], c["height"], c["n_frames"], c["enc_mode"], c["seed"],
                                         c.get("structure", "ra"), c.get("kind", "synth"), c.get("motion", (3, -2)))
     kw = dict(ref_counts=rc, sc_class1=c.get("sc_class1", 0), frame_rate=c.get("frame_rate", 30 << 16), gm_enabled=1, gm_dist_th=1,
-              restricted_motion_vector=c.get("restricted", 0))
+              restricted_motion_vector=c.get("restricted", 0), tiles=c.get("tiles", (0, 0)))
     hdr, recs = refio.run_reference_shim(frames, pics, c["enc_mode"], svtme.LIB_PATH, **kw)
     assert hdr["mode"] == refio.MODE_SHIM and len(recs) == len(pics)
     # the controls the shim copied out of the reference's MeContext are the ones the golden run used
