@@ -485,8 +485,12 @@ int svtme_gm_frame_error(svtme_engine *e, uint64_t cur_key, uint64_t ref_key, in
  * use_pred_sad_in_intra_search / use_pred_sad_in_inter_search say so (:690, :886), else the sum of the absolute
  * coefficients of the residual's forward 16x16 DCT (svt_av1_wht_fwd_txfm with pf_shape + svt_aom_satd, :790-813, :900-916):
  * on the device for dispenser_search_level 0 and subsample_tx 0, which is what the levels that use it have.
- * tpl_opt_flag = 0 (level 1: twelve more intra modes with edge filters, a rate estimate) is not on the device:
- * SVTME_ERR_UNSUPPORTED, as is every combination not named here.
+ * tpl_opt_flag = 0 (tpl level 1, presets M5 and slower, :186-198: 16x16 blocks, whole 16x16 transforms, DEFAULT_SHAPE):
+ * every intra mode from DC_PRED to intra_mode_end is tried on the source picture's own neighbours
+ * (update_neighbor_samples_array_open_loop_mb, EbEncIntraPrediction.c:1150-1235; the directional modes after
+ * filter_intra_edge, EbIntraPrediction.c:2633-2689), each costed in the transform domain, the first of the cheapest wins
+ * (:735-820, best_intra_mode); the inter candidates are costed in the transform domain too, and with src_dist the chosen
+ * one also yields rate_estimator's value (:195-209, src_rate). Every combination not named here: SVTME_ERR_UNSUPPORTED.
  *
  * src_dist = 1 adds what :935-982 derive from the chosen inter candidate: its residual's forward transform, quantised with
  * the picture's quantiser (svt_av1_quantize_fp, no quantisation matrices) and compared with the coefficients
@@ -523,7 +527,9 @@ typedef struct svtme_tpl_picture {
     /* [0] dc, [1] ac of the luma quantiser at the dispenser's qindex: scs->quants_8bit.y_round_fp[q], .y_quant_fp[q],
      * scs->deq_8bit.y_dequant_qtx[q] (:579-586); read when src_dist is set */
     int16_t  y_round_fp[2], y_quant_fp[2], y_dequant[2];
-    uint8_t  reserved[4];
+    uint8_t  intra_mode_end; /* tpl_opt_flag 0 only: the last intra mode tried (:730-733): PAETH_PRED 12 by default,
+                                SMOOTH_H_PRED 11 without scs->enable_paeth, D67_PRED 8 without enable_smooth either */
+    uint8_t  reserved[3];
     const uint8_t  *total_me_candidate_index; /* [n_b64][n_pu] */
     const uint8_t  *me_candidate_array; /* [n_b64][n_pu * max_cand], MeCandidate bytes */
     const uint32_t *me_mv_array; /* [n_b64][n_pu * max_refs], MvCandidate::as_int */
@@ -535,9 +541,11 @@ typedef struct svtme_tpl_block {
     int16_t mv_x, mv_y; /* final_best_mv.col / .row: 1/8 pel, clamped (:853-876); 0 without a candidate */
     int8_t  best_rf_idx; /* svt_get_ref_frame_type(list, ref) - 1, -1 without a candidate (:619, :850) */
     uint8_t best_is_inter; /* best_inter_cost < best_intra_cost: best_mode is NEWMV, else DC_PRED (:932-933) */
-    uint8_t best_intra_mode; /* DC_PRED (0) */
+    uint8_t best_intra_mode; /* PredictionMode of best_intra_cost: DC_PRED (0) unless tpl_opt_flag is 0 */
     uint8_t valid; /* 1: the block belongs to the dispenser's grid */
     int64_t src_recon_error; /* src_dist and best_is_inter: get_quantize_error's recon_error of the chosen candidate; else 0 */
+    int64_t src_rate; /* the same with tpl_opt_flag 0: rate_estimator(qcoeff, eob, tx_size) of the chosen candidate, from
+                         which the encoder forms srcrf_rate = (rate << TPL_DEP_COST_SCALE_LOG2) << subsample_tx; else 0 */
 } svtme_tpl_block;
 int svtme_tpl_search(svtme_engine *e, const svtme_tpl_picture *pic, svtme_tpl_block *out /* [n_b64][SVTME_TPL_BLOCKS] */);
 

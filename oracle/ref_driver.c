@@ -902,6 +902,11 @@ static void tpl_fill_from_engine(Shim *s, const Job *job, uint32_t pi, PicState 
     d.enable_me_16x16              = pcs->enable_me_16x16;
     d.subsample_tx                 = tc->subsample_tx;
     d.pf_shape                     = (uint8_t)tc->pf_shape;
+    { /* the last intra mode the dispenser tries without tpl_opt_flag (:724-733) */
+        const EbBool paeth  = scs->enable_paeth == DEFAULT ? EB_TRUE : (EbBool)scs->enable_paeth;
+        const EbBool smooth = scs->enable_smooth == DEFAULT ? EB_TRUE : (EbBool)scs->enable_smooth;
+        d.intra_mode_end    = paeth ? PAETH_PRED : (smooth ? SMOOTH_H_PRED : D67_PRED);
+    }
     /* the engine also transforms and quantises the candidate it chose, for the transforms the tpl levels use (16x16, 16x8,
      * 16x4 on 16x16 blocks, 32x8 on 32x32 blocks); for another combination the lines below do it with the reference's own */
     d.src_dist = tc->dispenser_search_level == 0 || (tc->dispenser_search_level == 1 && tc->subsample_tx == 2);
@@ -949,7 +954,8 @@ static void tpl_fill_from_engine(Shim *s, const Job *job, uint32_t pi, PicState 
                 const int l = e->best_rf_idx < 4 ? 0 : 1, r = e->best_rf_idx >= 4 ? e->best_rf_idx - 4 : e->best_rf_idx;
                 ss->ref_frame_poc = pcs->tpl_data.tpl_ref_ds_ptr_array[l][r].picture_number;
                 if (e->best_is_inter && d.src_dist) {
-                    ss->srcrf_rate = 0; /* tpl_opt_flag: no rate (:975-979) */
+                    /* rate_estimator's value without tpl_opt_flag, else no rate (:975-979) */
+                    ss->srcrf_rate = tc->tpl_opt_flag ? 0 : (e->src_rate << TPL_DEP_COST_SCALE_LOG2) << tc->subsample_tx;
                     ss->srcrf_dist = (e->src_recon_error << TPL_DEP_COST_SCALE_LOG2) << tc->subsample_tx; /* :980-981 */
                 } else if (e->best_is_inter) { /* :935-982 on the host */
                     const EbPictureBufferDesc *rp = pcs->tpl_data.tpl_ref_ds_ptr_array[l][r].picture_ptr;

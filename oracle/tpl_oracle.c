@@ -1,9 +1,9 @@
 /*
  * tpl_oracle.c - TEST INFRASTRUCTURE, not part of the product: a plain-C restatement of the source-based mode search of
  * the reference's TPL dispenser (tpl_mc_flow_dispenser_sb_generic,
- * Source/Lib/Encoder/Codec/EbSourceBasedOperationsProcess.c:632-933) for tpl_opt_flag = 1: costs as sums of absolute
- * differences or as sums of absolute 16x16 forward-DCT coefficients, and the quantisation error of the chosen inter
- * candidate (:935-982). Pinned by
+ * Source/Lib/Encoder/Codec/EbSourceBasedOperationsProcess.c:632-933): costs as sums of absolute
+ * differences or as sums of absolute 16x16 forward-DCT coefficients, the quantisation error of the chosen inter
+ * candidate (:935-982) and, for tpl_opt_flag = 0, the thirteen intra modes and the rate estimate. Pinned by
  * tests/golden/tpl_*.npz, which hold what the real reference (oracle/_ref/ref_me, REF_MODE_TPL) computed for the same
  * pictures and ME results. Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may use it.
  *
@@ -14,6 +14,7 @@
 
 #include <limits.h>
 #include <math.h>
+#include <stdlib.h>
 #include <string.h>
 
 #define TPL_PAD 32 /* TPL_PADX, TPL_PADY: EbEncodeContext.h:43-44 */
@@ -254,10 +255,197 @@ int64_t orc_tpl_quantize_error(const int32_t *coeff, int n, const int16_t round_
     return err < 1 ? 1 : err;
 }
 
+/* ---- tpl_opt_flag = 0: every intra mode of a 16x16 block (:693-821).
+ *
+ * The neighbours, update_neighbor_samples_array_open_loop_mb(1, 1, ..) (EbEncIntraPrediction.c:1150-1235): above[-1 .. 31]
+ * and left[-1 .. 31] around the block at (x, y) of the source picture. Fill values 127 / 129; the corner is the pixel at
+ * (x - 1, y - 1) or 128 on the picture's first row / column; the column left of the block as far down as the picture goes
+ * (at most 32 rows), its lower half then overwritten by entry 15; on the first column the pixel above the block stands in
+ * for the corner and the column; the row above as far right as the picture goes, its right half overwritten by entry 15
+ * unless the block lies on the first column; on the first row one entry of the left column stands in for the corner and
+ * the row. */
+static void tpl_neighbours(const plane *cur, int x, int y, uint8_t *above, uint8_t *left) {
+    memset(above - 1, 127, 33);
+    memset(left - 1, 129, 33);
+    above[-1] = left[-1] = (uint8_t)((x && y) ? pel(cur, x - 1, y - 1) : 128);
+    if (x) {
+        if (!y) left[-1] = (uint8_t)pel(cur, x - 1, y);
+        const int n = y + 32 > cur->h ? cur->h - y : 32;
+        for (int i = 0; i < n; ++i) left[i] = (uint8_t)pel(cur, x - 1, y + i);
+        for (int i = 16; i < 32; ++i) left[i] = left[15];
+    } else if (y) {
+        const int n = y + 32 > cur->h ? cur->h - y : 32;
+        for (int i = -1; i < n; ++i) left[i] = (uint8_t)pel(cur, x, y - 1);
+        above[-1] = (uint8_t)pel(cur, x, y - 1);
+    }
+    if (y) {
+        const int n = x + 32 > cur->w ? cur->w - x : 32;
+        for (int i = 0; i < n; ++i) above[i] = (uint8_t)pel(cur, x + i, y - 1);
+        if (x)
+            for (int i = 16; i < 32; ++i) above[i] = above[15];
+    } else if (x) {
+        const int     n = x + 32 > cur->w ? cur->w - x : 32;
+        const uint8_t v = left[32 - n];
+        for (int i = -1; i < n; ++i) above[i] = v;
+    }
+}
+
+/* svt_av1_filter_intra_edge_c (EbIntraPrediction.c:105-128): 5-tap smoothing of p[1 .. sz - 1], ends replicated */
+static void tpl_edge_filter(uint8_t *p, int sz, int strength) {
+    static const int taps[3][5] = {{0, 4, 8, 4, 0}, {0, 5, 6, 5, 0}, {2, 4, 4, 4, 2}};
+    if (!strength) return;
+    uint8_t edge[40];
+    memcpy(edge, p, (size_t)sz);
+    for (int i = 1; i < sz; ++i) {
+        int s = 0;
+        for (int j = 0; j < 5; ++j) {
+            int k = i - 2 + j;
+            k = k < 0 ? 0 : (k > sz - 1 ? sz - 1 : k);
+            s += edge[k] * taps[strength - 1][j];
+        }
+        p[i] = (uint8_t)((s + 8) >> 4);
+    }
+}
+
+/* intra_edge_filter_strength(16, 16, delta, 0) (:130-165, block width + height = 32) */
+static int tpl_edge_strength(int delta) {
+    const int d = delta < 0 ? -delta : delta;
+    return d >= 32 ? 3 : (d >= 4 ? 2 : (d >= 1 ? 1 : 0));
+}
+
+/* filter_intra_edge (:2633-2689) for a 16x16 block and a directional mode of angle p_angle: the corner when both edges are
+ * read, then each edge that exists in the picture (16 + corner + the 16 extension entries zone 1 / zone 3 read). A 16x16
+ * block never has its edges upsampled (use_intra_edge_upsample: width + height > 16). */
+static void tpl_filter_edges(int p_angle, int x, int y, uint8_t *above, uint8_t *left) {
+    if (p_angle == 90 || p_angle == 180) return;
+    const int need_above = p_angle < 180, need_left = p_angle > 90;
+    if (need_above && need_left) { /* filter_intra_edge_corner :2397-2404 */
+        const int s = (left[0] * 5 + above[-1] * 6 + above[0] * 5 + 8) >> 4;
+        above[-1] = left[-1] = (uint8_t)s;
+    }
+    if (need_above && y > 0) tpl_edge_filter(above - 1, 16 + 1 + (p_angle < 90 ? 16 : 0), tpl_edge_strength(p_angle - 90));
+    if (need_left && x > 0) tpl_edge_filter(left - 1, 16 + 1 + (p_angle > 180 ? 16 : 0), tpl_edge_strength(p_angle - 180));
+}
+
+/* eb_dr_intra_derivative (:194-228) at the angles the nominal modes use */
+static int tpl_derivative(int angle) { return angle == 23 ? 151 : (angle == 45 ? 64 : 27 /* 67 */); }
+
+static const uint8_t k_sm_weights16[16] = {255, 225, 196, 170, 145, 123, 102, 84, 68, 54, 43, 33, 26, 20, 17, 16}; /* sm_weight_arrays + 16, :27-45 */
+static const int     k_mode_angle[9]    = {0, 90, 180, 45, 135, 113, 157, 203, 67}; /* mode_to_angle_map, EbIntraPrediction.h:127-137 */
+
+/* intra_prediction_open_loop_mb (:2691-2712) for TX_16X16: mode 0 DC_PRED (dc_pred[x > 0][y > 0]), 1 V, 2 H, 3 D45, 4 D135,
+ * 5 D113, 6 D157, 7 D203, 8 D67 (dr_predictor :2373-2395 without upsampling: zones 1 / 2 / 3 :263-362), 9 SMOOTH,
+ * 10 SMOOTH_V, 11 SMOOTH_H (:1056-1120), 12 PAETH (:1145-1165) */
+static void tpl_intra_predict(int mode, int x, int y, const uint8_t *above, const uint8_t *left, uint8_t *dst /* [16][16] */) {
+    if (mode == 0) {
+        int sum = 0, n = 0;
+        if (y > 0) {
+            for (int i = 0; i < 16; ++i) sum += above[i];
+            n += 16;
+        }
+        if (x > 0) {
+            for (int i = 0; i < 16; ++i) sum += left[i];
+            n += 16;
+        }
+        memset(dst, n ? (sum + (n >> 1)) / n : 128, 256);
+        return;
+    }
+    const int angle = mode <= 8 ? k_mode_angle[mode] : 0;
+    for (int r = 0; r < 16; ++r)
+        for (int c = 0; c < 16; ++c) {
+            int v;
+            if (mode == 1) v = above[c];
+            else if (mode == 2) v = left[r];
+            else if (mode <= 8 && angle < 90) { /* zone 1 */
+                const int dx = tpl_derivative(angle), xx = (r + 1) * dx, base = (xx >> 6) + c, sh = (xx & 0x3F) >> 1;
+                v = base < 31 ? (above[base] * (32 - sh) + above[base + 1] * sh + 16) >> 5 : above[31];
+            } else if (mode <= 8 && angle < 180) { /* zone 2 */
+                const int dx = tpl_derivative(180 - angle), dy = tpl_derivative(angle - 90);
+                const int xx = -(r + 1) * dx, base = (xx >> 6) + c;
+                if (base >= -1) {
+                    const int sh = (xx & 0x3F) >> 1;
+                    v = (above[base] * (32 - sh) + above[base + 1] * sh + 16) >> 5;
+                } else {
+                    const int yy = (r << 6) - (c + 1) * dy, b2 = yy >> 6, sh = (yy & 0x3F) >> 1;
+                    v = (left[b2] * (32 - sh) + left[b2 + 1] * sh + 16) >> 5;
+                }
+            } else if (mode <= 8) { /* zone 3 */
+                const int dy = tpl_derivative(270 - angle), yy = (c + 1) * dy, base = (yy >> 6) + r, sh = (yy & 0x3F) >> 1;
+                v = base < 31 ? (left[base] * (32 - sh) + left[base + 1] * sh + 16) >> 5 : left[31];
+            } else if (mode == 9) {
+                v = (k_sm_weights16[r] * above[c] + (256 - k_sm_weights16[r]) * left[15] + k_sm_weights16[c] * left[r] +
+                     (256 - k_sm_weights16[c]) * above[15] + 256) >> 9;
+            } else if (mode == 10) v = (k_sm_weights16[r] * above[c] + (256 - k_sm_weights16[r]) * left[15] + 128) >> 8;
+            else if (mode == 11) v = (k_sm_weights16[c] * left[r] + (256 - k_sm_weights16[c]) * above[15] + 128) >> 8;
+            else {
+                const int tl = above[-1], base = above[c] + left[r] - tl;
+                const int pl = abs(base - left[r]), pt = abs(base - above[c]), ptl = abs(base - tl);
+                v = (pl <= pt && pl <= ptl) ? left[r] : (pt <= ptl ? above[c] : tl);
+            }
+            dst[r * 16 + c] = (uint8_t)v;
+        }
+}
+
+/* Position of coefficient (r, c) in default_scan_16x16 (EbCoefficients.h:484-502): the anti-diagonals in turn, odd ones
+ * from the top row down, even ones from the left column up */
+static int tpl_scan_pos16(int r, int c) {
+    const int d = r + c, before = d <= 15 ? d * (d + 1) / 2 : 256 - (31 - d) * (32 - d) / 2;
+    const int r_min = d > 15 ? d - 15 : 0, r_max = d < 15 ? d : 15;
+    return before + ((d & 1) ? r - r_min : r_max - r);
+}
+
+/* rate_estimator (:195-209) of the 16x16 coefficients quantised as in get_quantize_error: (eob + 1 + the sum of
+ * floor(log2(|level| + 1)) over the coefficients in front of eob) << AV1_PROB_COST_SHIFT, eob = the scan position after the
+ * last level that is not zero (svt_av1_quantize_fp_c, EbFullLoop.c:318-405) */
+int64_t orc_tpl_rate16(const int32_t *coeff, const int16_t round_fp[2], const int16_t quant_fp[2], const int16_t dequant[2]) {
+    int eob = 0, logs = 0;
+    for (int i = 0; i < 256; ++i) {
+        const int ac = i != 0;
+        int64_t   a = coeff[i] < 0 ? -(int64_t)coeff[i] : coeff[i];
+        if ((a << 1) < dequant[ac]) continue;
+        a += round_fp[ac];
+        a = a > INT16_MAX ? INT16_MAX : a;
+        const int32_t level = (int32_t)((a * quant_fp[ac]) >> 16);
+        if (!level) continue;
+        const int pos = tpl_scan_pos16(i / 16, i % 16);
+        if (pos + 1 > eob) eob = pos + 1;
+        for (uint32_t v = (uint32_t)level + 1; v > 1; v >>= 1) ++logs; /* log2f_32, EbUtility.c:233-245 */
+    }
+    return (int64_t)(eob + 1 + logs) << 9;
+}
+
+/* The transform-domain cost of every intra mode 0 .. 12 of the 16x16 block at (x, y), as the loop at :735-820 computes them:
+ * exposed so that tests can compare each one with the cost the reference recorded. */
+void orc_tpl_intra_costs(const uint8_t *cur_pix, int stride, int w, int h, int x, int y, int64_t costs[13]) {
+    const plane cur = {cur_pix, stride, w, h};
+    uint8_t     above0[40], left0[40], above1[40], left1[40], prd[256];
+    int16_t     res[256];
+    int32_t     coeff[256];
+    tpl_neighbours(&cur, x, y, above0 + 4, left0 + 4);
+    for (int mode = 0; mode <= 12; ++mode) {
+        const uint8_t *above = above0 + 4, *left = left0 + 4;
+        if (mode >= 1 && mode <= 8) {
+            memcpy(above1, above0, sizeof(above1));
+            memcpy(left1, left0, sizeof(left1));
+            tpl_filter_edges(k_mode_angle[mode], x, y, above1 + 4, left1 + 4);
+            above = above1 + 4, left = left1 + 4;
+        }
+        tpl_intra_predict(mode, x, y, above, left, prd);
+        for (int r = 0; r < 16; ++r)
+            for (int c = 0; c < 16; ++c) res[r * 16 + c] = (int16_t)(pel(&cur, x + c, y + r) - prd[r * 16 + c]);
+        orc_tpl_fwd_dct(res, 16, 16, coeff, 0);
+        costs[mode] = satd256(coeff);
+    }
+}
+
 int orc_tpl_search(const uint8_t *cur_pix, int stride, const uint8_t *const ref_pix[SVTME_MAX_LISTS * SVTME_MAX_REFS],
                    const svtme_tpl_picture *p, svtme_tpl_block *out) {
-    if (!p->tpl_opt_flag || p->pf_shape > 2) return SVTME_ERR_UNSUPPORTED;
-    const int sad_intra = p->use_pred_sad_in_intra_search, sad_inter = p->use_pred_sad_in_inter_search;
+    if (p->pf_shape > 2) return SVTME_ERR_UNSUPPORTED;
+    /* without tpl_opt_flag every cost is a transform-domain cost of the whole transform (:780-813, :878-917) */
+    const int all_modes = !p->tpl_opt_flag, pf_shape = all_modes ? 0 : p->pf_shape;
+    const int sad_intra = !all_modes && p->use_pred_sad_in_intra_search, sad_inter = !all_modes && p->use_pred_sad_in_inter_search;
+    const int mode_end  = all_modes ? p->intra_mode_end : 0; /* :730-733 */
+    if (all_modes && mode_end != 12 && mode_end != 11 && mode_end != 8) return SVTME_ERR_BAD_ARG;
     /* transform-domain costs: 16x16 blocks, whole transforms. The source distortion: the transforms the tpl levels use
      * (:543-545): 16x16, 16x8 and 16x4 (every 2nd / 4th row of a 16x16 block), 32x8 (every 4th row of a 32x32 block) */
     if ((!sad_intra || !sad_inter) && (p->dispenser_search_level != 0 || p->subsample_tx != 0)) return SVTME_ERR_UNSUPPORTED;
@@ -284,7 +472,15 @@ int orc_tpl_search(const uint8_t *cur_pix, int stride, const uint8_t *const ref_
             o->best_rf_idx     = -1;
             o->best_intra_cost = INT64_MAX;
             o->best_inter_cost = INT64_MAX;
-            if (!p->disable_intra_pred) { /* :637-692 */
+            if (!p->disable_intra_pred && all_modes) { /* :693-821 */
+                int64_t costs[13];
+                orc_tpl_intra_costs(cur_pix, stride, w, h, x, y, costs);
+                for (int mode = 0; mode <= mode_end; ++mode)
+                    if (costs[mode] < o->best_intra_cost) { /* the first of the cheapest stays (:816-819) */
+                        o->best_intra_cost = costs[mode];
+                        o->best_intra_mode = (uint8_t)mode;
+                    }
+            } else if (!p->disable_intra_pred) { /* :637-692 */
                 const int dc = dc_value(&cur, x, y, size);
                 int64_t   sad = 0;
                 int16_t   res[256];
@@ -296,12 +492,12 @@ int orc_tpl_search(const uint8_t *cur_pix, int stride, const uint8_t *const ref_
                         if (!sad_intra) res[r * 16 + c] = (int16_t)d;
                     }
                 if (!sad_intra) { /* :790-813 */
-                    orc_tpl_fwd_dct(res, 16, 16, coeff, p->pf_shape);
+                    orc_tpl_fwd_dct(res, 16, 16, coeff, pf_shape);
                     sad = satd256(coeff);
                 }
                 o->best_intra_cost = sad;
             }
-            int64_t best_err = 0;
+            int64_t best_err = 0, best_rate = 0;
             int me_off = k_me_index[bi]; /* :826-834 */
             if (!p->enable_me_16x16) me_off = (me_off - 1) / 4;
             const int n_cand = p->i_slice ? 0 : cnt[me_off];
@@ -331,13 +527,14 @@ int orc_tpl_search(const uint8_t *cur_pix, int stride, const uint8_t *const ref_
                         if (size <= 32 && r % step == 0 && r / step < 16) res[(r / step) * size + cc] = (int16_t)d;
                     }
                 if (!sad_inter) { /* :894-917 */
-                    orc_tpl_fwd_dct(res, 16, 16, coeff, p->pf_shape);
+                    orc_tpl_fwd_dct(res, 16, 16, coeff, pf_shape);
                     sad = satd256(coeff);
                 }
                 if (sad < o->best_inter_cost) {
                     if (p->src_dist) { /* what :935-982 make of the best candidate */
-                        if (sad_inter && orc_tpl_fwd_dct(res, size, tx_h, coeff, p->pf_shape)) return SVTME_ERR_UNSUPPORTED;
+                        if (sad_inter && orc_tpl_fwd_dct(res, size, tx_h, coeff, pf_shape)) return SVTME_ERR_UNSUPPORTED;
                         best_err = orc_tpl_quantize_error(coeff, size * tx_h, p->y_round_fp, p->y_quant_fp, p->y_dequant);
+                        if (all_modes) best_rate = orc_tpl_rate16(coeff, p->y_round_fp, p->y_quant_fp, p->y_dequant); /* :975-977 */
                     }
                     o->best_inter_cost = sad;
                     o->best_rf_idx     = (int8_t)(list == 0 ? ref : 4 + ref); /* svt_get_ref_frame_type(list, ref) - 1 */
@@ -347,6 +544,7 @@ int orc_tpl_search(const uint8_t *cur_pix, int stride, const uint8_t *const ref_
             }
             o->best_is_inter = o->best_inter_cost < o->best_intra_cost; /* :932-933 */
             o->src_recon_error = o->best_is_inter ? best_err : 0;
+            o->src_rate        = o->best_is_inter ? best_rate : 0;
         }
     }
     return SVTME_OK;

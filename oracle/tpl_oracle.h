@@ -13,4 +13,8 @@ int orc_tpl_search(const uint8_t *cur_pix, int stride, const uint8_t *const ref_
  * restatement's own pieces, exposed so that tests can pin them one by one. */
 int     orc_tpl_fwd_dct(const int16_t *residual, int w, int h, int32_t *coeff, int shape);
 int64_t orc_tpl_quantize_error(const int32_t *coeff, int n, const int16_t round_fp[2], const int16_t quant_fp[2], const int16_t dequant[2]);
+/* rate_estimator's value for 16x16 coefficients quantised the same way (tpl_opt_flag = 0) */
+int64_t orc_tpl_rate16(const int32_t *coeff, const int16_t round_fp[2], const int16_t quant_fp[2], const int16_t dequant[2]);
+/* the transform-domain costs of intra modes DC_PRED .. PAETH_PRED of the 16x16 block at (x, y) (tpl_opt_flag = 0) */
+void orc_tpl_intra_costs(const uint8_t *cur_pix, int stride, int w, int h, int x, int y, int64_t costs[13]);
 #endif

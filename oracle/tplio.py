@@ -16,8 +16,8 @@ BLOCK_GEOMETRY = [(0, 0, 64)] + [((i & 1) * 32, (i >> 1) * 32, 32) for i in rang
 
 TPL_BLOCK = np.dtype([("best_intra_cost", "<i8"), ("best_inter_cost", "<i8"), ("mv_x", "<i2"), ("mv_y", "<i2"),
                       ("best_rf_idx", "i1"), ("best_is_inter", "u1"), ("best_intra_mode", "u1"), ("valid", "u1"),
-                      ("src_recon_error", "<i8")])
-assert TPL_BLOCK.itemsize == 32
+                      ("src_recon_error", "<i8"), ("src_rate", "<i8")])
+assert TPL_BLOCK.itemsize == 40
 
 
 CONTROL_FIELDS = ("dispenser_search_level", "disable_intra_pred", "tpl_opt_flag", "use_pred_sad_in_intra_search",
@@ -33,7 +33,7 @@ class TplPicture(ctypes.Structure):
                 ("max_cand", ctypes.c_uint8), ("max_refs", ctypes.c_uint8), ("max_l0", ctypes.c_uint8),
                 ("n_ref", ctypes.c_uint8 * 2), ("subsample_tx", ctypes.c_uint8), ("pf_shape", ctypes.c_uint8),
                 ("src_dist", ctypes.c_uint8), ("y_round_fp", ctypes.c_int16 * 2), ("y_quant_fp", ctypes.c_int16 * 2),
-                ("y_dequant", ctypes.c_int16 * 2), ("reserved", ctypes.c_uint8 * 4),
+                ("y_dequant", ctypes.c_int16 * 2), ("intra_mode_end", ctypes.c_uint8), ("reserved", ctypes.c_uint8 * 3),
                 ("total_me_candidate_index", ctypes.POINTER(ctypes.c_uint8)),
                 ("me_candidate_array", ctypes.POINTER(ctypes.c_uint8)),
                 ("me_mv_array", ctypes.POINTER(ctypes.c_uint32))]
@@ -60,6 +60,7 @@ def make_picture(width, height, ctrl, me, cur_key=0, ref_keys=((), ()), ref_skip
     p.n_ref[0], p.n_ref[1] = n_ref if n_ref is not None else (len(ref_keys[0]), len(ref_keys[1]))
     for k in CONTROL_FIELDS:
         setattr(p, k, int(ctrl[k]))
+    p.intra_mode_end = int(ctrl.get("intra_mode_end", 12))  # PAETH_PRED: scs->enable_paeth / enable_smooth at their defaults
     if quant is not None:
         p.src_dist = 1
         for k in range(2):
@@ -130,13 +131,14 @@ def expected_from_reference(tb, ctrl, src_dist=False):
     out = np.zeros(tb.shape, TPL_BLOCK)
     out["valid"] = tb["valid"]
     v = tb["valid"] == 1
-    n_intra = 0 if ctrl["disable_intra_pred"] else 1
+    # without tpl_opt_flag every intra mode from DC_PRED to intra_mode_end is costed, in that order
+    n_intra = 0 if ctrl["disable_intra_pred"] else (1 if ctrl["tpl_opt_flag"] else ctrl.get("intra_mode_end", 12) + 1)
     costs = tb["costs"].astype(np.int64)
     k = np.arange(costs.shape[-1])
     inter_mask = (k >= n_intra) & (k < tb["n_costs"][..., None])
     inter = np.where(inter_mask, costs, INT64_MAX).min(axis=-1)
     out["best_inter_cost"] = np.where(v, inter, 0)
-    out["best_intra_cost"] = np.where(v, costs[..., 0] if n_intra else INT64_MAX, 0)
+    out["best_intra_cost"] = np.where(v, costs[..., :n_intra].min(axis=-1) if n_intra else INT64_MAX, 0)
     out["best_rf_idx"] = np.where(v, tb["best_rf_idx"], 0)
     out["mv_x"] = np.where(v, tb["mv_col"], 0)
     out["mv_y"] = np.where(v, tb["mv_row"], 0)
@@ -144,6 +146,20 @@ def expected_from_reference(tb, ctrl, src_dist=False):
     out["best_intra_mode"] = np.where(v, tb["best_intra_mode"], 0)
     if src_dist:
         out["src_recon_error"] = np.where(v & (tb["best_mode"] != 0), tb["src_srcrf_dist"] >> (4 + ctrl["subsample_tx"]), 0)
+        out["src_rate"] = np.where(v & (tb["best_mode"] != 0), tb["src_srcrf_rate"] >> (4 + ctrl["subsample_tx"]), 0)
+    return out
+
+
+def oracle_intra_costs(cur, x, y):
+    """The restatement's transform-domain costs of the thirteen intra modes of the 16x16 block at (x, y) of cur (uint8 [h, w])."""
+    global _lib
+    if _lib is None:
+        _lib = ctypes.CDLL(ORACLE_LIB)
+    cur = np.ascontiguousarray(cur, np.uint8)
+    h, w = cur.shape
+    out = np.zeros(13, np.int64)
+    _lib.orc_tpl_intra_costs.restype = None
+    _lib.orc_tpl_intra_costs(cur.ctypes.data_as(ctypes.c_void_p), w, w, h, int(x), int(y), out.ctypes.data_as(ctypes.c_void_p))
     return out
 
 

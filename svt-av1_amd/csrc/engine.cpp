@@ -1257,11 +1257,15 @@ extern "C" int svtme_tpl_search(svtme_engine *e, const svtme_tpl_picture *pic, s
         (pic->n_pu != SVTME_PU_COUNT && pic->n_pu != 21) || pic->max_cand == 0 || pic->max_refs == 0 ||
         pic->max_l0 + (pic->n_ref[1] ? pic->n_ref[1] : 0) > pic->max_refs || pic->n_ref[0] > pic->max_l0)
         return SVTME_ERR_BAD_ARG;
-    // the intra modes beyond DC are not on the device; transform-domain costs are there for whole 16x16 transforms, the
-    // source distortion for the transforms the tpl levels use: 16x16, 16x8, 16x4 on 16x16 blocks, 32x8 on 32x32 blocks
-    if (!pic->tpl_opt_flag || pic->pf_shape > 2) return SVTME_ERR_UNSUPPORTED;
-    if ((!pic->use_pred_sad_in_intra_search || !pic->use_pred_sad_in_inter_search) && (pic->dispenser_search_level != 0 || pic->subsample_tx != 0))
-        return SVTME_ERR_UNSUPPORTED;
+    // transform-domain costs are there for whole 16x16 transforms, the source distortion for the transforms the tpl levels
+    // use: 16x16, 16x8, 16x4 on 16x16 blocks, 32x8 on 32x32 blocks. Without tpl_opt_flag every cost is a transform-domain
+    // cost of the whole transform and every intra mode up to intra_mode_end is tried
+    // (EbSourceBasedOperationsProcess.c:730-733, :780-813, :878-917).
+    if (pic->pf_shape > 2) return SVTME_ERR_UNSUPPORTED;
+    const bool all_modes = !pic->tpl_opt_flag;
+    if (all_modes && pic->intra_mode_end != 12 && pic->intra_mode_end != 11 && pic->intra_mode_end != 8) return SVTME_ERR_BAD_ARG;
+    const bool sad_intra = !all_modes && pic->use_pred_sad_in_intra_search, sad_inter = !all_modes && pic->use_pred_sad_in_inter_search;
+    if ((!sad_intra || !sad_inter) && (pic->dispenser_search_level != 0 || pic->subsample_tx != 0)) return SVTME_ERR_UNSUPPORTED;
     if (pic->src_dist && (pic->subsample_tx > 2 || pic->dispenser_search_level > 1 || (pic->dispenser_search_level == 1 && pic->subsample_tx != 2)))
         return SVTME_ERR_UNSUPPORTED;
     DEVICE_OR_FAIL(e->cfg.device);
@@ -1314,9 +1318,11 @@ extern "C" int svtme_tpl_search(svtme_engine *e, const svtme_tpl_picture *pic, s
     p.max_cand = pic->max_cand;
     p.max_refs = pic->max_refs;
     p.max_l0 = pic->max_l0;
-    p.sad_intra = pic->use_pred_sad_in_intra_search != 0;
-    p.sad_inter = pic->use_pred_sad_in_inter_search != 0;
-    p.pf_shape  = pic->pf_shape;
+    p.sad_intra = sad_intra;
+    p.sad_inter = sad_inter;
+    p.pf_shape  = all_modes ? 0 : pic->pf_shape; // DEFAULT_SHAPE without tpl_opt_flag (:800-802, :909-911)
+    p.mode_end  = all_modes ? pic->intra_mode_end : 0;
+    p.rate      = all_modes && pic->src_dist;
     p.src_dist  = pic->src_dist != 0;
     p.subsample_tx = pic->subsample_tx;
     for (int k = 0; k < 2; ++k) {

@@ -175,6 +175,8 @@ struct TplParams {
     int32_t  level, disable_intra_pred, i_slice, enable_me_16x16; // svtme_tpl_picture's fields
     int32_t  n_pu, max_cand, max_refs, max_l0;
     int32_t  sad_intra, sad_inter, pf_shape, src_dist, subsample_tx;
+    int32_t  mode_end; // the last intra mode tried: 0 (DC_PRED only) with tpl_opt_flag, else svtme_tpl_picture::intra_mode_end
+    int32_t  rate; // also fill svtme_tpl_block::src_rate (no tpl_opt_flag, src_dist)
     int32_t  round_fp[2], quant_fp[2], dequant[2]; // [dc, ac]
     int32_t  cos13[32], cos12[32]; // cos(2 k pi / 128) with 13 / 12 fractional bits, k = 0..31
     const uint8_t  *cnt; // [n_b64][n_pu]

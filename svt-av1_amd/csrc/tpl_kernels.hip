@@ -170,9 +170,20 @@ constexpr int kTplLdsInts = 16 * 33; // a 32x8 or 16x16 residual with a pitch on
 // (reference planes, quantiser) with run-time values, which a kernel argument of this size would pay for with a private copy.
 typedef const TplParams __attribute__((address_space(4))) ConstTplParams;
 
+// Position of coefficient (r, c) in default_scan_16x16 (EbCoefficients.h:484-502): the anti-diagonals in turn, the odd ones
+// from the top row down, the even ones from the left column up.
+__device__ __forceinline__ int tpl_scan_pos16(int r, int c) {
+    const int d = r + c, before = d <= 15 ? d * (d + 1) / 2 : 256 - (31 - d) * (32 - d) / 2;
+    const int r_min = d > 15 ? d - 15 : 0, r_max = d < 15 ? d : 15;
+    return before + ((d & 1) ? r - r_min : r_max - r);
+}
+
+// want_rate (16x16 only): also rate_estimator's value (:195-209) for the quantised coefficients: (eob + 1 + the sum of
+// floor(log2(level + 1)) over the levels in front of eob) << AV1_PROB_COST_SHIFT, eob = the scan position after the last level
+// that is not zero.
 template <int W, int H, int N>
 __device__ __forceinline__ void tpl_transform(ConstTplParams &p, const uint32_t (&src)[N], const uint32_t (&prd)[N], int32_t *lds, bool quant,
-                                              long long &satd, long long &recon_error) {
+                                              long long &satd, long long &recon_error, bool want_rate = false, long long *rate = nullptr) {
     constexpr int PITCH = W + 1, DW = W / 4, STEP = W / H, SHIFT1 = (W == 16 && H == 4) ? 1 : 2;
     constexpr int BIT_ROW = ((W == 16 && H == 16) || W == 32) ? 12 : 13;
     const int     lane = threadIdx.x & 63;
@@ -202,6 +213,7 @@ __device__ __forceinline__ void tpl_transform(ConstTplParams &p, const uint32_t 
     }
     wave_sync();
     long long a_sum = 0, e_sum = 0;
+    int       eob = 0, logs = 0;
     const int kw = W >> p.pf_shape, kh = H >> p.pf_shape;
     if (lane < kh) {
         int32_t in[W], out[W];
@@ -221,6 +233,12 @@ __device__ __forceinline__ void tpl_transform(ConstTplParams &p, const uint32_t 
                     const int32_t t     = min(a + p.round_fp[ac], 32767);
                     const int32_t level = (int32_t)(((long long)t * p.quant_fp[ac]) >> 16);
                     dq                  = level * p.dequant[ac];
+                    if constexpr (W == 16 && H == 16) {
+                        if (want_rate && level) {
+                            eob = max(eob, tpl_scan_pos16(lane, i) + 1);
+                            logs += 31 - __clz(level + 1);
+                        }
+                    }
                 }
                 const long long diff = (long long)a - dq; // |v - sign(v) dq|: same square
                 e_sum += diff * diff;
@@ -235,10 +253,130 @@ __device__ __forceinline__ void tpl_transform(ConstTplParams &p, const uint32_t 
     satd = a_sum;
     e_sum >>= 2;
     recon_error = e_sum < 1 ? 1 : e_sum;
+    if constexpr (W == 16 && H == 16) {
+        if (want_rate) {
+#pragma unroll
+            for (int m = 32; m >= 1; m >>= 1) {
+                eob = max(eob, __shfl_xor(eob, m));
+                logs += __shfl_xor(logs, m);
+            }
+            *rate = (long long)(eob + 1 + logs) << 9;
+        }
+    }
+}
+
+// ---- without tpl_opt_flag: every intra mode of a 16x16 block (:693-821). The block's neighbours in the source picture lie in
+// LDS as two byte arrays of 33 entries, entry i = -1 .. 31 at [4 + i]: the corner and the 32 pixels above / left of the
+// block and of its right / lower neighbour.
+constexpr int kEdge = 40; // bytes per edge array
+
+// update_neighbor_samples_array_open_loop_mb(1, 1, ..) (EbEncIntraPrediction.c:1150-1235), an entry per lane: fill values
+// 127 / 129; the corner is the pixel at (x - 1, y - 1), or 128 on the picture's first row and column; the column left of the
+// block as far down as the picture goes, entries 16 .. 31 then repeat entry 15; on the first column the pixel above the
+// block stands in for the corner and the column; the row above as far right as the picture goes, entries 16 .. 31 repeating
+// entry 15 unless the block lies on the first column; on the first row one entry of the left column stands in for the corner
+// and the row.
+__device__ __forceinline__ void tpl_collect_edges(ConstTplParams &p, const DevPlane &cur, int x, int y, uint8_t *above, uint8_t *left) {
+    const int lane = threadIdx.x & 63, i = lane - 1;
+    auto      px   = [&](int xx, int yy) -> int { return cur.pix[(ptrdiff_t)yy * cur.stride + xx]; };
+    const int nl = min(32, p.height - y), na = min(32, p.width - x);
+    auto      left_at = [&](int k) -> int {
+        if (x > 0) {
+            if (k < 0) return y > 0 ? px(x - 1, y - 1) : px(x - 1, y);
+            if (k >= 16) k = 15;
+            return k < nl ? px(x - 1, y + k) : 129;
+        }
+        if (y > 0) return k < nl ? px(x, y - 1) : 129;
+        return k < 0 ? 128 : 129;
+    };
+    if (lane < 33) {
+        int a;
+        if (y > 0) {
+            if (i < 0) a = x > 0 ? px(x - 1, y - 1) : px(x, y - 1);
+            else {
+                const int k = (x > 0 && i >= 16) ? 15 : i;
+                a           = k < na ? px(x + k, y - 1) : 127;
+            }
+        } else if (x > 0) a = i < na ? left_at(32 - na) : 127;
+        else a = i < 0 ? 128 : 127;
+        above[4 + i] = (uint8_t)a;
+        left[4 + i]  = (uint8_t)left_at(i);
+    }
+}
+
+// filter_intra_edge (EbIntraPrediction.c:2633-2689) for a 16x16 block and a directional mode of angle `angle` (not 90 or
+// 180), from the collected arrays into the filtered ones, an entry per lane: the corner when both edges are read
+// (filter_intra_edge_corner :2397-2404), then svt_av1_filter_intra_edge_c (:105-128) over each edge that exists in the
+// picture - the corner, 16 entries and, for zone 1 / zone 3, the 16 of the extension - with the strength of
+// intra_edge_filter_strength(16, 16, delta, 0) (:130-165): 3 from 32 degrees on, else 2. A 16x16 block's edges are never
+// upsampled (use_intra_edge_upsample: width + height > 16).
+__device__ __forceinline__ void tpl_filter_edges(int angle, int x, int y, const uint8_t *a0, const uint8_t *l0, uint8_t *a1, uint8_t *l1) {
+    const int  lane = threadIdx.x & 63, idx = lane; // entry idx - 1
+    const bool need_above = angle < 180, need_left = angle > 90;
+    if (lane >= 33) return;
+    int ca = a0[3], cl = l0[3];
+    if (need_above && need_left) ca = cl = (l0[4] * 5 + a0[3] * 6 + a0[4] * 5 + 8) >> 4;
+    auto filtered = [&](const uint8_t *e, int corner, int sz, int delta) -> int {
+        auto at = [&](int k) -> int { return k <= 0 ? corner : e[3 + min(k, sz - 1)]; };
+        if (idx < 1 || idx >= sz) return idx == 0 ? corner : e[3 + idx];
+        const int d = delta < 0 ? -delta : delta;
+        if (d >= 32) return (2 * at(idx - 2) + 4 * at(idx - 1) + 4 * at(idx) + 4 * at(idx + 1) + 2 * at(idx + 2) + 8) >> 4;
+        return (5 * at(idx - 1) + 6 * at(idx) + 5 * at(idx + 1) + 8) >> 4;
+    };
+    a1[3 + idx] = (uint8_t)filtered(a0, ca, need_above && y > 0 ? 17 + (angle < 90 ? 16 : 0) : 0, angle - 90);
+    l1[3 + idx] = (uint8_t)filtered(l0, cl, need_left && x > 0 ? 17 + (angle > 180 ? 16 : 0) : 0, angle - 180);
+}
+
+__constant__ const uint8_t kSmWeights16[16] = {255, 225, 196, 170, 145, 123, 102, 84, 68, 54, 43, 33, 26, 20, 17, 16}; // sm_weight_arrays + 16, :27-45
+
+// intra_prediction_open_loop_mb (:2691-2712) for TX_16X16, this lane's four pixels (row lane / 4, columns 4 (lane % 4) ..):
+// mode 1 V, 2 H, 3 D45, 4 D135, 5 D113, 6 D157, 7 D203, 8 D67 (dr_predictor :2373-2395 without upsampling: zones 1 / 2 / 3,
+// :263-362, with eb_dr_intra_derivative 64 / 27 / 151 at 45 / 67 / 23 degrees), 9 SMOOTH, 10 SMOOTH_V, 11 SMOOTH_H
+// (:1056-1120), 12 PAETH (:1145-1165). above / left point at entry 0.
+__device__ __forceinline__ uint32_t tpl_intra_dword(int mode, const uint8_t *above, const uint8_t *left) {
+    const int lane = threadIdx.x & 63, r = lane >> 2;
+    // mode_to_angle_map (EbIntraPrediction.h:127-137) and the derivatives of the two edges
+    const int angle = mode == 3 ? 45 : (mode == 4 ? 135 : (mode == 5 ? 113 : (mode == 6 ? 157 : (mode == 7 ? 203 : 67))));
+    auto      deriv = [](int a) -> int { return a == 23 ? 151 : (a == 45 ? 64 : 27); };
+    uint32_t  out   = 0;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int c = 4 * (lane & 3) + j;
+        int       v;
+        if (mode == 1) v = above[c];
+        else if (mode == 2) v = left[r];
+        else if (mode <= 8 && angle < 90) {
+            const int xx = (r + 1) * deriv(angle), base = (xx >> 6) + c, sh = (xx & 0x3F) >> 1;
+            v            = base < 31 ? (above[base] * (32 - sh) + above[base + 1] * sh + 16) >> 5 : above[31];
+        } else if (mode <= 8 && angle < 180) {
+            const int xx = -(r + 1) * deriv(180 - angle), base = (xx >> 6) + c;
+            if (base >= -1) {
+                const int sh = (xx & 0x3F) >> 1;
+                v            = (above[base] * (32 - sh) + above[base + 1] * sh + 16) >> 5;
+            } else {
+                const int yy = (r << 6) - (c + 1) * deriv(angle - 90), b2 = yy >> 6, sh = (yy & 0x3F) >> 1;
+                v            = (left[b2] * (32 - sh) + left[b2 + 1] * sh + 16) >> 5;
+            }
+        } else if (mode <= 8) {
+            const int yy = (c + 1) * deriv(270 - angle), base = (yy >> 6) + r, sh = (yy & 0x3F) >> 1;
+            v            = base < 31 ? (left[base] * (32 - sh) + left[base + 1] * sh + 16) >> 5 : left[31];
+        } else if (mode == 9) {
+            v = (kSmWeights16[r] * above[c] + (256 - kSmWeights16[r]) * left[15] + kSmWeights16[c] * left[r] +
+                 (256 - kSmWeights16[c]) * above[15] + 256) >> 9;
+        } else if (mode == 10) v = (kSmWeights16[r] * above[c] + (256 - kSmWeights16[r]) * left[15] + 128) >> 8;
+        else if (mode == 11) v = (kSmWeights16[c] * left[r] + (256 - kSmWeights16[c]) * above[15] + 128) >> 8;
+        else {
+            const int tl = above[-1], base = above[c] + left[r] - tl;
+            const int pl = abs(base - left[r]), pt = abs(base - above[c]), ptl = abs(base - tl);
+            v            = (pl <= pt && pl <= ptl) ? left[r] : (pt <= ptl ? above[c] : tl);
+        }
+        out |= (uint32_t)(v & 0xff) << (8 * j);
+    }
+    return out;
 }
 
 template <int S>
-__device__ __forceinline__ void tpl_block(ConstTplParams &p, int b64, int bi, int x, int y, int32_t *lds) {
+__device__ __forceinline__ void tpl_block(ConstTplParams &p, int b64, int bi, int x, int y, int32_t *lds, uint8_t *edges) {
     constexpr int DW = S / 4, N = S * S / 256; // dwords per row, dwords per lane
     const int     lane = threadIdx.x & 63;
     const DevPlane cur = load_plane(p.cur);
@@ -248,10 +386,42 @@ __device__ __forceinline__ void tpl_block(ConstTplParams &p, int b64, int bi, in
         const int idx = lane + 64 * k, r = idx / DW, d = idx % DW;
         src[k]        = *reinterpret_cast<const uint32_t *>(cur.pix + (ptrdiff_t)(y + r) * cur.stride + x + 4 * d);
     }
-    long long best_intra = INT64_MAX, best_inter = INT64_MAX, best_err = 0;
-    int       best_rf = -1, best_mvx = 0, best_mvy = 0;
+    long long best_intra = INT64_MAX, best_inter = INT64_MAX, best_err = 0, best_rate = 0;
+    int       best_rf = -1, best_mvx = 0, best_mvy = 0, best_mode = 0;
 
-    if (!p.disable_intra_pred) {
+    if (S == 16 && !p.disable_intra_pred && p.mode_end > 0) {
+        // every mode from DC_PRED to mode_end in the transform domain, the first of the cheapest stays (:735-820)
+        if constexpr (S == 16) {
+            uint8_t *a0 = edges, *l0 = edges + kEdge, *a1 = edges + 2 * kEdge, *l1 = edges + 3 * kEdge;
+            wave_sync();
+            tpl_collect_edges(p, cur, x, y, a0, l0);
+            wave_sync();
+            for (int mode = 0; mode <= p.mode_end; ++mode) {
+                uint32_t prd[1];
+                if (mode == 0) { // dc_pred[x > 0][y > 0] (:2705-2707)
+                    uint32_t sum = 0;
+                    if (lane < 16) sum = (y > 0 ? a0[4 + lane] : 0u) + (x > 0 ? l0[4 + lane] : 0u);
+                    sum              = wave_sum(sum);
+                    const uint32_t n = (y > 0 ? 16 : 0) + (x > 0 ? 16 : 0);
+                    prd[0]           = (n ? (sum + (n >> 1)) / n : 128u) * 0x01010101u;
+                } else if (mode >= 3 && mode <= 8) { // the directional modes read filtered copies of the edges (:743-760)
+                    const int angle = mode == 3 ? 45 : (mode == 4 ? 135 : (mode == 5 ? 113 : (mode == 6 ? 157 : (mode == 7 ? 203 : 67))));
+                    wave_sync();
+                    tpl_filter_edges(angle, x, y, a0, l0, a1, l1);
+                    wave_sync();
+                    prd[0] = tpl_intra_dword(mode, a1 + 4, l1 + 4);
+                } else {
+                    prd[0] = tpl_intra_dword(mode, a0 + 4, l0 + 4);
+                }
+                long long cost, err;
+                tpl_transform<16, 16, 1>(p, src, prd, lds, false, cost, err);
+                if (cost < best_intra) {
+                    best_intra = cost;
+                    best_mode  = mode;
+                }
+            }
+        }
+    } else if (!p.disable_intra_pred) {
         // the row above and the column left of the block; entries past the picture's right / bottom edge keep the fill
         // values 127 / 129 (update_neighbor_samples_array_open_loop_mb, EbEncIntraPrediction.c:1150-1235); which sides
         // count: dc_pred[x > 0][y > 0] (EbIntraPrediction.c:985-1035, :2705-2707)
@@ -311,7 +481,9 @@ __device__ __forceinline__ void tpl_block(ConstTplParams &p, int b64, int bi, in
             if (!p.sad_inter) { // :894-917
                 uint32_t f[1];
                 __builtin_memcpy(&f[0], org + (ptrdiff_t)(lane >> 2) * rp.stride + 4 * (lane & 3), 4);
-                tpl_transform<16, 16, 1>(p, src, f, lds, p.src_dist != 0, sad, err);
+                long long rate = 0;
+                tpl_transform<16, 16, 1>(p, src, f, lds, p.src_dist != 0, sad, err, p.rate != 0, &rate);
+                if (sad < best_inter) best_rate = rate;
             }
         }
         if (sad < best_inter) { // strictly smaller: the first of equal candidates stays
@@ -351,9 +523,10 @@ __device__ __forceinline__ void tpl_block(ConstTplParams &p, int b64, int bi, in
         o.mv_y            = (int16_t)best_mvy;
         o.best_rf_idx     = (int8_t)best_rf;
         o.best_is_inter   = is_inter;
-        o.best_intra_mode = 0; // DC_PRED
+        o.best_intra_mode = (uint8_t)best_mode; // DC_PRED (0) unless every mode was tried
         o.valid           = 1;
         o.src_recon_error = p.src_dist && is_inter ? best_err : 0;
+        o.src_rate        = p.rate && is_inter ? best_rate : 0;
         p.out[(size_t)b64 * SVTME_TPL_BLOCKS + bi] = o;
     }
 }
@@ -362,6 +535,7 @@ __device__ __forceinline__ void tpl_block(ConstTplParams &p, int b64, int bi, in
 // (level 1, s < 4) or the block itself (level 2, s == 0); blocks that are not complete run at level 0 (:2086-2088)
 __global__ void __launch_bounds__(64) tpl_search_kernel(const TplParams *pp) {
     __shared__ int32_t lds[kTplLdsInts];
+    __shared__ __align__(4) uint8_t edges[4 * kEdge];
     ConstTplParams    &p = *(ConstTplParams *)pp;
     const int b64 = blockIdx.y, slot = blockIdx.x;
     const int sb_x = (b64 % p.b64_w) * 64, sb_y = (b64 / p.b64_w) * 64;
@@ -370,13 +544,13 @@ __global__ void __launch_bounds__(64) tpl_search_kernel(const TplParams *pp) {
         const int q = slot >> 2, s = slot & 3; // z-order: 32x32 quadrant, 16x16 inside it
         const int x = sb_x + (q & 1) * 32 + (s & 1) * 16, y = sb_y + (q >> 1) * 32 + (s >> 1) * 16;
         if (x + 8 > p.width || y + 8 > p.height) return; // at least half of the block inside (:604-607)
-        tpl_block<16>(p, b64, 5 + slot, x, y, lds);
+        tpl_block<16>(p, b64, 5 + slot, x, y, lds, edges);
     } else if (level == 1) {
         if (slot >= 4) return;
-        tpl_block<32>(p, b64, 1 + slot, sb_x + (slot & 1) * 32, sb_y + (slot >> 1) * 32, lds);
+        tpl_block<32>(p, b64, 1 + slot, sb_x + (slot & 1) * 32, sb_y + (slot >> 1) * 32, lds, edges);
     } else {
         if (slot >= 1) return;
-        tpl_block<64>(p, b64, 0, sb_x, sb_y, lds);
+        tpl_block<64>(p, b64, 0, sb_x, sb_y, lds, edges);
     }
 }
 

@@ -129,7 +129,7 @@ GM_MAX_CORNERS = 4096
 TPL_BLOCKS = 21
 TPL_BLOCK = np.dtype([("best_intra_cost", "<i8"), ("best_inter_cost", "<i8"), ("mv_x", "<i2"), ("mv_y", "<i2"),
                       ("best_rf_idx", "i1"), ("best_is_inter", "u1"), ("best_intra_mode", "u1"), ("valid", "u1"),
-                      ("src_recon_error", "<i8")])
+                      ("src_recon_error", "<i8"), ("src_rate", "<i8")])
 
 
 class TplPicture(C.Structure):
@@ -141,7 +141,8 @@ class TplPicture(C.Structure):
                 ("use_pred_sad_in_inter_search", C.c_uint8), ("enable_me_16x16", C.c_uint8), ("n_pu", C.c_uint8),
                 ("max_cand", C.c_uint8), ("max_refs", C.c_uint8), ("max_l0", C.c_uint8),
                 ("n_ref", C.c_uint8 * MAX_LISTS), ("subsample_tx", C.c_uint8), ("pf_shape", C.c_uint8), ("src_dist", C.c_uint8),
-                ("y_round_fp", C.c_int16 * 2), ("y_quant_fp", C.c_int16 * 2), ("y_dequant", C.c_int16 * 2), ("reserved", C.c_uint8 * 4),
+                ("y_round_fp", C.c_int16 * 2), ("y_quant_fp", C.c_int16 * 2), ("y_dequant", C.c_int16 * 2), ("intra_mode_end", C.c_uint8),
+                ("reserved", C.c_uint8 * 3),
                 ("total_me_candidate_index", C.POINTER(C.c_uint8)), ("me_candidate_array", C.POINTER(C.c_uint8)),
                 ("me_mv_array", C.POINTER(C.c_uint32))]
 

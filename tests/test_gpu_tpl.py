@@ -90,6 +90,11 @@ def test_random_me_results_match_the_restatement(seed):
         if level == 1:
             ctrl.update(subsample_tx=2)
         quant = some_quant
+    elif seed % 3 == 0 and seed % 2 == 0:  # no tpl_opt_flag: every intra mode up to a random last one, the rate of the choice
+        ctrl.update(dispenser_search_level=0, subsample_tx=0, tpl_opt_flag=0, intra_mode_end=int(rng.choice([12, 11, 8])),
+                    use_pred_sad_in_intra_search=int(rng.integers(0, 2)), use_pred_sad_in_inter_search=int(rng.integers(0, 2)))
+        if rng.integers(0, 4):
+            quant = some_quant
     from svtme import gop
     pic = gop.Picture(poc=0, temporal_layer=0, is_ref=1, refs=[list(range(1, 1 + n_ref[0])), list(range(1 + n_ref[0], n_frames))])
     skip = rng.integers(0, 4, (2, 4)) == 0
@@ -111,8 +116,8 @@ def test_unsupported_controls_and_bad_arguments():
     ctrl, me, tb, quant = per[pics.index(pic)]
     eng = _engine(frames)
     try:
-        # every intra mode (tpl_opt_flag 0); transform-domain costs or the source distortion on anything but whole 16x16 transforms
-        for change, q in ((dict(tpl_opt_flag=0), None), (dict(use_pred_sad_in_inter_search=0, dispenser_search_level=1), None),
+        # every intra mode (tpl_opt_flag 0), transform-domain costs or the source distortion on anything but whole 16x16 transforms
+        for change, q in ((dict(tpl_opt_flag=0, dispenser_search_level=1), None), (dict(use_pred_sad_in_inter_search=0, dispenser_search_level=1), None),
                           (dict(use_pred_sad_in_intra_search=0, subsample_tx=1), None), (dict(dispenser_search_level=1, subsample_tx=1), quant),
                           (dict(dispenser_search_level=2, subsample_tx=2), quant), (dict(pf_shape=3), None)):
             p, keep, refs = picture_of(frames, pic, dict(ctrl, **change), me, quant=q)

@@ -35,7 +35,7 @@ def load_case(name, c):
 def test_oracle_refuses_what_it_does_not_restate():
     frames, pics, per = load_case("tpl4_m8_200x136", CASES["tpl4_m8_200x136"])
     ctrl, me, tb, quant = per[0]
-    for change, q in ((dict(tpl_opt_flag=0), None), (dict(use_pred_sad_in_inter_search=0, dispenser_search_level=1), None),
+    for change, q in ((dict(tpl_opt_flag=0, dispenser_search_level=1), None), (dict(use_pred_sad_in_inter_search=0, dispenser_search_level=1), None),
                       (dict(use_pred_sad_in_intra_search=0, subsample_tx=1), None), (dict(dispenser_search_level=1, subsample_tx=1), quant),
                       (dict(dispenser_search_level=2, subsample_tx=2), quant), (dict(pf_shape=3), None)):
         p, keep, refs = picture_of(frames, pics[0], dict(ctrl, **change), me, quant=q)
@@ -71,8 +71,31 @@ def test_oracle_reproduces_reference_tpl_search(name):
         n_src += int((exp["src_recon_error"] > 0).sum())
         n_blocks += int(exp["valid"].sum())
         n_intra += int((exp["valid"] & (exp["best_is_inter"] == 0)).sum())
-    assert n_blocks > 0 and 0 < n_intra < n_blocks  # both outcomes occur in every case
-    assert (n_src > 0) == tplio.src_dist_available(per[0][0])
+    # both outcomes occur in every case but the flat one without tpl_opt_flag, where every cost is 0 and intra stays
+    assert n_blocks > 0 and 0 < n_intra and (n_intra < n_blocks or name == "tpl1_m2_flat_128x64")
+    assert (n_src > 0) == (tplio.src_dist_available(per[0][0]) and n_intra < n_blocks)
+
+
+@pytest.mark.parametrize("name", sorted(n for n in CASES if n.startswith("tpl1_")))
+def test_oracle_reproduces_every_intra_mode_cost_the_reference_recorded(name):
+    """tpl_opt_flag = 0: the reference's record holds the cost of each of the thirteen intra modes of every block, in mode
+    order, in front of the inter costs; the restatement's predictors (neighbour arrays with their paddings, filtered edges,
+    the three directional zones, smooth and Paeth) must give every one of them."""
+    frames, pics, per = load_case(name, CASES[name])
+    h, w = frames.shape[1:]
+    n = 0
+    for pic, (ctrl, me, tb, quant) in zip(pics, per):
+        assert not ctrl["tpl_opt_flag"] and not ctrl["disable_intra_pred"]
+        for b64 in range(tb.shape[0]):
+            sx, sy = (b64 % ((w + 63) // 64)) * 64, (b64 // ((w + 63) // 64)) * 64
+            for bi in range(5, 21):
+                if not tb[b64, bi]["valid"]:
+                    continue
+                bx, by, _ = tplio.BLOCK_GEOMETRY[bi]
+                got = tplio.oracle_intra_costs(frames[pic.poc], sx + bx, sy + by)
+                assert got.tolist() == tb[b64, bi]["costs"][:13].tolist(), (name, pic.poc, b64, bi)
+                n += 1
+    assert n > 0
 
 
 @pytest.mark.parametrize("name", sorted(UNSUPPORTED_CASES))

@@ -18,18 +18,22 @@ CASES = {
     "tpl3_m6_192x128": dict(width=192, height=128, n_frames=5, enc_mode=6, seed=88, structure="ra", level=3, qp=32),
     "tpl2_m6_200x136": dict(width=200, height=136, n_frames=9, enc_mode=6, seed=91, structure="ra", level=2, qp=20),
     "tpl3_m6_noise_128x128": dict(width=128, height=128, n_frames=5, enc_mode=6, seed=92, structure="ra", level=3, qp=55, kind="noise"),
-}
-# level 1 (M5 and slower) tries twelve more intra modes and estimates a rate: the reference's record is kept so that the
-# restatement's and the engine's refusal is a statement about known behaviour, not about missing data
-UNSUPPORTED_CASES = {
+    # level 1 (M5 and slower, tpl_opt_flag 0): thirteen intra modes with filtered edges, transform-domain costs throughout and
+    # a rate estimate of the chosen candidate; ragged sizes put blocks on the right and bottom edges, where the neighbour
+    # arrays are padded; noise makes the directional and smooth modes win often, flat makes every cost tie
     "tpl1_m3_128x128": dict(width=128, height=128, n_frames=5, enc_mode=3, seed=89, structure="ra", level=1, qp=32),
+    "tpl1_m5_200x136": dict(width=200, height=136, n_frames=9, enc_mode=5, seed=93, structure="ra", level=1, qp=24, motion=(6, -4)),
+    "tpl1_m4_noise_136x200": dict(width=136, height=200, n_frames=5, enc_mode=4, seed=94, structure="ra", level=1, qp=45, kind="noise"),
+    "tpl1_m2_flat_128x64": dict(width=128, height=64, n_frames=3, enc_mode=2, seed=95, structure="ra", level=1, qp=32, kind="flat"),
 }
+# (levels the restatement and the engine refuse would be listed here with the reference's record of them)
+UNSUPPORTED_CASES = {}
 # the benchmark's 1080p preset-8 shape: a digest of the reference's results only
 DIGEST_CASES = {
     "tpl4_m8_1920x1080": dict(width=1920, height=1080, n_frames=5, enc_mode=8, seed=90, structure="ra", level=4, qp=32, motion=(5, -3)),
 }
 SEARCH_FIELDS = ("valid", "best_intra_cost", "best_inter_cost", "mv_x", "mv_y", "best_rf_idx", "best_is_inter", "best_intra_mode",
-                 "src_recon_error")
+                 "src_recon_error", "src_rate")
 
 
 def job_args(c):
