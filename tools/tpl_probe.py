@@ -25,12 +25,14 @@ def main():
     want = json.load(open(os.path.join(ROOT, "tests", "golden", "tpl_digests.json")))[name]
     shape = want["me_shape"]
     if not calls_only:
-        for lib in (None, svtme.LIB_PATH):
-            hdr, recs = refio.run_reference_tpl(frames, pics, c["enc_mode"], c["level"], c["qp"], library=lib, ref_counts=rc)
-            t = json.loads(hdr["stdout"].strip().splitlines()[-1])
-            print("reference dispenser, search %s: %.2f ms per picture (+ %.2f ms binding: engine call, transform and quantisation of the choices)"
-                  % ("on the engine" if lib else "on the host  ", 1e3 * t["dispenser_seconds"] / t["pictures"],
-                     1e3 * t["binding_seconds"] / t["pictures"]))
+        # tpl level 4 is the preset's own; level 1 (every intra mode, transform-domain costs, rate) on the same pictures
+        for level in (c["level"], 1):
+            for lib in (None, svtme.LIB_PATH):
+                hdr, recs = refio.run_reference_tpl(frames, pics, c["enc_mode"], level, c["qp"], library=lib, ref_counts=rc)
+                t = json.loads(hdr["stdout"].strip().splitlines()[-1])
+                print("reference dispenser at tpl level %d, search %s: %.2f ms per picture (+ %.2f ms binding: engine call, filling the records)"
+                      % (level, "on the engine" if lib else "on the host  ", 1e3 * t["dispenser_seconds"] / t["pictures"],
+                         1e3 * t["binding_seconds"] / t["pictures"]))
     n, h, w = frames.shape
     eng = svtme.Engine(w, h, store_slots=n + 2, max_in_flight=2)
     try:
@@ -40,7 +42,7 @@ def main():
                           max_refs=shape["max_refs"], max_cand=shape["max_cand"], max_l0=shape["max_l0"],
                           input_resolution=shape["input_resolution"], gm_enabled=1, gm_use_distance_based_active_th=1)
         ctrl_me = svtme.derive_controls(c["enc_mode"], w, h, 0, 30 << 16)
-        jobs, jobs_satd = [], []
+        jobs, jobs_satd, jobs_all = [], [], []
         for pic, ctrl in zip(pics, want["controls"]):
             out = eng.run_picture(eng.make_picture(w, h, pic.poc, pic.temporal_layer, pic.is_ref, pic.refs, ctrl_me, tail=tail,
                                                    key_of=lambda poc: poc + 1))
@@ -51,8 +53,11 @@ def main():
             jobs.append(picture_of(frames, pic, ctrl, me, quant=want["quant"]))  # with the chosen candidate's quantisation error
             satd = dict(ctrl, use_pred_sad_in_intra_search=0, use_pred_sad_in_inter_search=0, pf_shape=0)
             jobs_satd.append(picture_of(frames, pic, satd, me, quant=want["quant"]))  # tpl level 3's costs on the same pictures
+            every = dict(satd, tpl_opt_flag=0, disable_intra_pred=0)
+            jobs_all.append(picture_of(frames, pic, every, me, quant=want["quant"]))  # tpl level 1: thirteen intra modes, rate
         for what, js in (("SAD costs (tpl level 4) + quantisation error of the choice", jobs),
-                         ("transform-domain costs (tpl level 3) + quantisation error", jobs_satd)):
+                         ("transform-domain costs (tpl level 3) + quantisation error", jobs_satd),
+                         ("thirteen intra modes, transform-domain costs, quantisation error and rate (tpl level 1)", jobs_all)):
             for p, keep, refs in js:
                 eng.tpl_search(p)
             reps = 50
@@ -62,7 +67,7 @@ def main():
                     eng.tpl_search(p)
             dt = (time.perf_counter() - t0) / (reps * len(js))
             print("svtme_tpl_search, 1080p, %d blocks, %s: %.3f ms per call (ME results in: %.2f MB, block records out: %.2f MB)"
-                  % (8160, what, 1e3 * dt, 510 * 85 * (1 + shape["max_cand"] + 4 * shape["max_refs"]) / 1e6, 510 * 21 * 32 / 1e6))
+                  % (8160, what, 1e3 * dt, 510 * 85 * (1 + shape["max_cand"] + 4 * shape["max_refs"]) / 1e6, 510 * 21 * 40 / 1e6))
     finally:
         eng.close()
 
