@@ -187,6 +187,36 @@ static uint64_t run_size(uint32_t w, uint32_t h, uint32_t max_w, uint32_t max_h,
         CHECK(svtme_picture_done(eng, t[0]));
     }
     EXPECT(svtme_derive_tf_controls(3, &tf.ctrl), SVTME_ERR_BAD_ARG);
+    /* the sequence's tiles for restricted temporal-filter searches: 64x64 tiles, bad shapes and bounds, clearing */
+    {
+        const uint32_t   bw = (w + 63) / 64, bh = (h + 63) / 64, n = bw * bh;
+        svtme_tile_rect *tiles = (svtme_tile_rect *)calloc(n, sizeof(*tiles));
+        for (uint32_t i = 0; i < n; ++i) {
+            tiles[i].start_x = (i % bw) * 64, tiles[i].start_y = (i / bw) * 64;
+            tiles[i].end_x = tiles[i].start_x + 64 < w ? tiles[i].start_x + 64 : w;
+            tiles[i].end_y = tiles[i].start_y + 64 < h ? tiles[i].start_y + 64 : h;
+        }
+        EXPECT(svtme_set_tile_rects(eng, w, h, tiles, n - 1), SVTME_ERR_BAD_ARG);
+        tiles[0].end_x = w + 8;
+        EXPECT(svtme_set_tile_rects(eng, w, h, tiles, n), SVTME_ERR_BAD_ARG);
+        tiles[0].end_x = 64;
+        CHECK(svtme_set_tile_rects(eng, w, h, tiles, n));
+        CHECK(svtme_derive_tf_controls(0, &tf.ctrl));
+        for (uint8_t restricted = 0; restricted < 2; ++restricted) {
+            tf.restricted_motion_vector = restricted;
+            CHECK(svtme_picture_submit(eng, &tf, &t[0]));
+            CHECK(svtme_picture_wait(eng, t[0], &res));
+            hsh = hash_results(&res, &tf, hsh);
+            CHECK(svtme_picture_done(eng, t[0]));
+        }
+        CHECK(svtme_set_tile_rects(eng, w, h, NULL, 0));
+        CHECK(svtme_picture_submit(eng, &tf, &t[0])); /* restricted, the picture as the one tile */
+        CHECK(svtme_picture_wait(eng, t[0], &res));
+        hsh = hash_results(&res, &tf, hsh);
+        CHECK(svtme_picture_done(eng, t[0]));
+        tf.restricted_motion_vector = 0;
+        free(tiles);
+    }
     svtme_picture fp;
     base_picture(&fp, w, h, 15, 5);
     fp.me_type = SVTME_ME_FIRST_PASS;
@@ -402,9 +432,22 @@ static uint64_t run_extras(uint32_t w, uint32_t h, uint32_t seed, uint64_t hsh) 
             }
         tp.dispenser_search_level = 1; /* 32x32 blocks have no 16x16 transform */
         EXPECT(svtme_tpl_search(eng, &tp, blk), SVTME_ERR_UNSUPPORTED);
-        tp.dispenser_search_level = 0;
-        tp.tpl_opt_flag = 0; /* every intra mode */
+        tp.tpl_opt_flag = 0; /* every intra mode: 16x16 blocks only */
+        tp.intra_mode_end = 12;
         EXPECT(svtme_tpl_search(eng, &tp, blk), SVTME_ERR_UNSUPPORTED);
+        tp.dispenser_search_level = 0;
+        tp.intra_mode_end = 5; /* not one of the loop's three ends */
+        EXPECT(svtme_tpl_search(eng, &tp, blk), SVTME_ERR_BAD_ARG);
+        for (int end = 0; end < 3; ++end) { /* PAETH_PRED, SMOOTH_H_PRED, D67_PRED */
+            tp.intra_mode_end = (uint8_t)(end == 0 ? 12 : (end == 1 ? 11 : 8));
+            CHECK(svtme_tpl_search(eng, &tp, blk));
+            for (uint32_t i = 0; i < n_b64 * SVTME_TPL_BLOCKS; ++i) {
+                if (!blk[i].valid) continue;
+                if (blk[i].best_intra_mode > tp.intra_mode_end) EXPECT(-124, SVTME_OK);
+                if ((blk[i].src_rate > 0) != (blk[i].best_is_inter != 0)) EXPECT(-125, SVTME_OK);
+            }
+            hsh = fnv(hsh, blk, sizeof(*blk) * (size_t)n_b64 * SVTME_TPL_BLOCKS);
+        }
         tp.tpl_opt_flag = 1;
         tp.n_ref[1] = 0; /* the list-1 candidates now name a reference that was not handed over */
         EXPECT(svtme_tpl_search(eng, &tp, blk), SVTME_ERR_BAD_ARG);
