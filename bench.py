@@ -56,6 +56,11 @@ WORKLOADS = {
     # first-pass ME of a two-pass encode (ME_FIRST_PASS): every frame searches the previous and the first frame;
     # fp = (ipp_pass_ctrls.bypass_zz_check, ipp_pass_ctrls.reduce_me_search)
     "1080p_first_pass": dict(width=1920, height=1080, enc_mode=8, structure="fp", n_frames=17, bit_depth=8, fp=(0, 0), batch=16),
+    # the fastest first pass of a 1080p two-pass encode (set_ipp_pass_ctrls level 2, EbEncHandle.c:3061-3069): pictures
+    # down-sampled to 960x544, no zero-vector check, reduced search, every second 64x64 block of every second block row
+    # (MeContext::bypass_blk_step, firstpass.c:1282-1285, :1313-1317)
+    "1080p_first_pass_fast": dict(width=960, height=544, enc_mode=8, structure="fp", n_frames=17, bit_depth=8, fp=(1, 1), b64_step=2,
+                                  batch=16),
 }
 STAGES = ["zz_centre", "prehme", "hme_l0", "hme_l1", "hme_l2", "integer_search"]
 # Packed-SAD peak of gfx950: 256 CUs x 4 SIMDs x 16 lanes/clk (v_sad_u8 / v_qsad_pk_u16_u8 issue at a quarter of the
@@ -95,7 +100,7 @@ def cpu_baseline(wl, frames, pics, budget_s=20.0):
 
         def run(reps):
             refio.write_job(job, frames, sample, wl["enc_mode"], mode=refio.MODE_BENCH, threads=threads, use_avx2=avx2,
-                            reps=reps, ref_counts=rc, tf=wl.get("tf"), first_pass=wl.get("fp"))
+                            reps=reps, ref_counts=rc, tf=wl.get("tf"), first_pass=wl.get("fp"), b64_step=wl.get("b64_step", 0))
             r = subprocess.run([binary, job, out], capture_output=True, text=True, timeout=600)
             if r.returncode != 0:
                 raise RuntimeError(r.stderr[-500:])
@@ -205,7 +210,7 @@ def main():
             e.store_put(i, i, frames[i])  # inputs resident in HBM before the timed region
         return e, [e.make_picture(w, h, p.poc, p.temporal_layer, p.is_ref, p.refs, ctrl, tail=tail,
                                   tf_me_exit_th=tf[1] if tf else None,
-                                  first_pass_bypass_zz=fp[0] if fp else None) for p in pics]
+                                  first_pass_bypass_zz=fp[0] if fp else None, b64_step=wl.get("b64_step", 0)) for p in pics]
 
     # per-kernel events only where they are needed: with one search stream they are the roofline timings
     streams = args.search_streams or (1 if args.batch > 1 else 3)  # what the engine makes of 0
@@ -222,6 +227,7 @@ def main():
         # the same pictures under a second set of store keys for every other step
         descs_alt = [[eng.make_picture(w, h, p.poc, p.temporal_layer, p.is_ref, p.refs, ctrl, tail=tail,
                                        tf_me_exit_th=tf[1] if tf else None, first_pass_bypass_zz=fp[0] if fp else None,
+                                       b64_step=wl.get("b64_step", 0),
                                        key_of=lambda poc, ks=ks: 1000 * ks + poc) for p in pics] for ks in range(KEY_SETS)]
 
     puts_made = [0]

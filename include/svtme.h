@@ -242,8 +242,8 @@ typedef struct svtme_tail {
  * previous and the golden frame, :1177-1186), temporal layer 0, used as reference, ctrl from
  * svtme_derive_first_pass_controls(). Differences: check_00_center is skipped when bypass_zz_check
  * (scs->ipp_pass_ctrls.bypass_zz_check, EbMotionEstimation.c:1363-1364) and the host tail has no compute_distortion
- * (:2990; a device tail leaves those statistics zero). Skipped frames and blocks (MeContext::skip_frame,
- * bypass_blk_step) are the caller's business: it does not submit / does not read them. */
+ * (:2990; a device tail leaves those statistics zero). Skipped frames (MeContext::skip_frame) are the caller's business: it
+ * does not submit them; skipped blocks (bypass_blk_step): b64_step. */
 typedef struct svtme_picture {
     uint64_t cur_key; /* store key of the current picture */
     uint64_t picture_number; /* pcs->picture_number */
@@ -265,6 +265,11 @@ typedef struct svtme_picture {
     svtme_controls ctrl;
     svtme_tail     tail;
     uint32_t       tf_me_exit_th; /* MeContext::tf_me_exit_th = pcs->tf_ctrls.me_exit_th; SVTME_ME_MCTF only */
+    uint8_t        b64_step; /* MeContext::bypass_blk_step (firstpass.c:1282-1285, :1313-1317): 0 or 1 = every 64x64 block; n > 1
+                                (the first pass uses 2 from 360p on when ipp_pass_ctrls.bypass_blk_step is set) = only the blocks
+                                whose column and row index are multiples of n are searched, nothing is computed for the others
+                                and their results are undefined (first_pass_me does not call motion_estimation_b64 for them) */
+    uint8_t        reserved[3];
 } svtme_picture;
 
 /* The tile of one 64x64 block: SbParams::tile_start_x, tile_start_y, tile_end_x, tile_end_y in the reference's order

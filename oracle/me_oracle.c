@@ -1177,6 +1177,7 @@ static void *orc_worker(void *arg) {
     for (uint32_t by = j->row0; by < j->row1; ++by)
         for (uint32_t bx = 0; bx < j->b64_w; ++bx) {
             uint32_t b = by * j->b64_w + bx;
+            if (j->pic->b64_step > 1 && (bx % j->pic->b64_step != 0 || by % j->pic->b64_step != 0)) continue;
             orc_me_b64(c, j->pic, b, j->out ? &j->out[b] : NULL, j->run_tail);
         }
     orc_ctx_ops(c, j->ops);

@@ -62,6 +62,8 @@ typedef struct orc_pic {
     /* scs->sb_params_array's tile fields per 64x64 block, read by ME_MCTF and ME_FIRST_PASS searches (:1408-1410); NULL, or
      * an open-loop search (pcs->sb_params_array, EbPictureControlSet.c:1684-1688): the picture is the tile */
     const svtme_tile_rect *tile_rects;
+    uint32_t b64_step; /* orc_me_picture: > 1 searches only the blocks whose column and row index are multiples of it
+                          (MeContext::bypass_blk_step, firstpass.c:1282-1285); the other records are left alone */
 } orc_pic;
 
 typedef struct orc_ctx orc_ctx; /* per-"thread" MeContext equivalent; state persists between b64s */

@@ -99,6 +99,7 @@ static void fill_pic(orc_pic *p, const ref_job_header *h, const ref_job_pic *jp,
     p->gm_enabled = jp->gm_enabled;
     p->gm_use_distance_based_active_th = jp->gm_dist_th;
     p->restricted_motion_vector = jp->restricted_motion_vector;
+    p->b64_step = h->b64_step;
     if (jp->tile_b64) p->tile_rects = make_tile_rects(h, jp->tile_b64); /* lives as long as the process */
     if (jp->me_type == 4) { /* firstpass.c:1273-1276 and set_gm_controls(pcs, 0), :702-703 */
         p->max_cand = 3;

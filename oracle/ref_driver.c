@@ -422,6 +422,8 @@ static void *worker_main(void *arg) {
         for (uint32_t bx = 0; bx < st->b64_w; ++bx) {
             uint32_t b64 = bx + by * st->b64_w;
             uint32_t ox = bx * 64, oy = by * 64;
+            /* MeContext::bypass_blk_step, firstpass.c:1282-1285 */
+            if (job->hdr.b64_step > 1 && (bx % job->hdr.b64_step != 0 || by % job->hdr.b64_step != 0)) continue;
             m->b64_src_ptr    = &cur->full.buffer_y[(cur->full.origin_y + oy) * cur->full.stride_y + cur->full.origin_x + ox];
             m->b64_src_stride = cur->full.stride_y;
             if (m->enable_hme_level1_flag) {
@@ -575,6 +577,7 @@ static void run_pic_shim(Shim *s, const Job *job, uint32_t pi, PicState *st) {
     d.bypass_zz_check          = m->me_type == ME_FIRST_PASS ? scs->ipp_pass_ctrls.bypass_zz_check : 0;
     d.restricted_motion_vector = scs->static_config.restricted_motion_vector;
     d.tf_me_exit_th            = m->me_type == ME_MCTF ? jp->tf_me_exit_th : 0;
+    d.b64_step                 = (uint8_t)job->hdr.b64_step; /* MeContext::bypass_blk_step */
     for (int l = 0; l < jp->n_list; ++l)
         for (int r = 0; r < jp->n_ref[l]; ++r) {
             d.ref_key[l][r]            = (uint64_t)(uintptr_t)&job->planes[jp->ref_frame[l][r]];
@@ -613,6 +616,7 @@ static void run_pic_shim(Shim *s, const Job *job, uint32_t pi, PicState *st) {
     Planes *cur = &job->planes[jp->cur_frame];
     for (uint32_t b64 = 0; b64 < st->n_b64; ++b64) {
         const uint32_t ox = (b64 % st->b64_w) * 64, oy = (b64 / st->b64_w) * 64;
+        if (d.b64_step > 1 && ((b64 % st->b64_w) % d.b64_step != 0 || (b64 / st->b64_w) % d.b64_step != 0)) continue; /* firstpass.c:1282-1285 */
         m->me_type = (EbMeType)d.me_type;
         m->tf_me_exit_th             = jp->tf_me_exit_th;
         m->tf_use_pred_64x64_only_th = 0;

@@ -41,6 +41,9 @@ typedef struct ref_job_header {
     uint32_t reps;
     uint32_t ref_count_used_list0; /* MRP maxima used to size me_results, EbPictureDecisionProcess.c:5075-5092 */
     uint32_t ref_count_used_list1;
+    uint32_t b64_step; /* > 1: only the 64x64 blocks whose column and row index are multiples of it are searched, as
+                          first_pass_me does with MeContext::bypass_blk_step (firstpass.c:1282-1285); the other blocks'
+                          records stay zero */
 } ref_job_header;
 
 typedef struct ref_job_pic {

@@ -69,14 +69,14 @@ TPL_BLK_DUMP = np.dtype([
     ("stats_mv_row", "<i2"), ("stats_mv_col", "<i2"), ("stats_ref_frame_poc", "<u8"),
 ])
 
-_HDR = "<8sIIIIIIIIII"
+_HDR = "<8sIIIIIIIIIII"
 _PIC = "<IIQiBBBBBBBB8I8QBBHBBBB"
 _OUT = "<8sIIIIIIdQ"
 
 
 def write_job(path, frames, pics, enc_mode, *, mode=MODE_DUMP, threads=1, use_avx2=0, reps=1,
               frame_rate=30 << 16, sc_class1=0, gm_enabled=0, gm_dist_th=0, ref_counts=(4, 3), tf=None, first_pass=None,
-              restricted_motion_vector=0, number_scale=1, tpl=(0, 0), tiles=(0, 0)):
+              restricted_motion_vector=0, number_scale=1, tpl=(0, 0), tiles=(0, 0), b64_step=0):
     """frames: uint8 [n, h, w]; pics: list of svtme.gop.Picture (refs are POCs = frame indices).
     tf = (hme_me_level, me_exit_th) runs every picture as a temporal-filter search (ME_MCTF) of its first list-0
     reference: the controls then come from tf_signal_derivation_me_kernel_oq and enc_mode is not used.
@@ -85,12 +85,14 @@ def write_job(path, frames, pics, enc_mode, *, mode=MODE_DUMP, threads=1, use_av
     number_scale: picture numbers are poc * number_scale (frames stay indexed by poc): stretches the picture distances.
     tpl = (tpl_level, qp): MODE_TPL runs the TPL dispenser with these after every picture's ME.
     tiles = (w, h): uniform tiles of w x h 64x64 blocks (0 = one tile in that direction), at most 15 each; they bound the
-    windows of temporal-filter and first-pass searches when restricted_motion_vector is set."""
+    windows of temporal-filter and first-pass searches when restricted_motion_vector is set.
+    b64_step: n > 1 searches only the 64x64 blocks whose column and row index are multiples of n (the first pass's
+    bypass_blk_step); the records of the others stay zero."""
     variant = (1, tf[0], tf[1]) if tf else ((4, (first_pass[0] & 1) | ((first_pass[1] & 1) << 1), 0) if first_pass else (0, 0, 0))
     n, h, w = frames.shape
     with open(path, "wb") as f:
         f.write(struct.pack(_HDR, b"SVTMEJ01", w, h, n, len(pics), mode, threads, use_avx2, reps,
-                            ref_counts[0], ref_counts[1]))
+                            ref_counts[0], ref_counts[1], b64_step))
         f.write(np.ascontiguousarray(frames, dtype=np.uint8).tobytes())
         for p in pics:
             rf = [[0] * 4, [0] * 4]

@@ -594,7 +594,7 @@ static int check_picture(const svtme_picture *pic) {
     if (k.me_search_method != 0) return SVTME_ERR_UNSUPPORTED;
     if (pic->tail.enable > 2 ||
         (pic->me_type != 0 && pic->me_type != SVTME_ME_OPEN_LOOP && pic->me_type != SVTME_ME_MCTF && pic->me_type != SVTME_ME_FIRST_PASS) ||
-        pic->bypass_zz_check > 1 || pic->restricted_motion_vector > 1)
+        pic->bypass_zz_check > 1 || pic->restricted_motion_vector > 1 || pic->b64_step > 8)
         return SVTME_ERR_BAD_ARG;
     // the temporal filter searches one neighbour frame at a time and has no host tail (EbTemporalFiltering.c:4844-4847,
     // EbMotionEstimation.c:2977)
@@ -646,6 +646,7 @@ static int fill_params(svtme_engine *e, const svtme_picture *pic, PicParams &p, 
     p.is_ref = pic->is_used_as_reference_flag;
     p.me_type       = pic->me_type ? pic->me_type : SVTME_ME_OPEN_LOOP;
     p.bypass_zz_check = pic->me_type == SVTME_ME_FIRST_PASS && pic->bypass_zz_check;
+    p.b64_step        = pic->b64_step;
     p.restricted      = pic->restricted_motion_vector;
     // the open-loop search reads the picture's own block parameters, whose one tile is the picture; the temporal filter
     // and the first pass read the sequence's (EbMotionEstimation.c:1408-1410)
@@ -706,7 +707,7 @@ extern "C" int svtme_pictures_submit(svtme_engine *e, const svtme_picture *pics,
         const svtme_picture &a = pics[0], &b = pics[i];
         if (a.width != b.width || a.height != b.height || memcmp(&a.ctrl, &b.ctrl, sizeof(a.ctrl)) || memcmp(&a.tail, &b.tail, sizeof(a.tail)) ||
             (a.me_type ? a.me_type : SVTME_ME_OPEN_LOOP) != (b.me_type ? b.me_type : SVTME_ME_OPEN_LOOP) ||
-            a.bypass_zz_check != b.bypass_zz_check || a.restricted_motion_vector != b.restricted_motion_vector ||
+            a.bypass_zz_check != b.bypass_zz_check || a.restricted_motion_vector != b.restricted_motion_vector || a.b64_step != b.b64_step ||
             a.tf_me_exit_th != b.tf_me_exit_th)
             return SVTME_ERR_BAD_ARG;
     }

@@ -301,6 +301,7 @@ template <class PICS>
 __global__ void __launch_bounds__(HI_THREADS) hme_zz_kernel(PICS pp, int n_b64) {
     const auto &p   = pp[blockIdx.x / n_b64];
     const int   b64 = blockIdx.x % n_b64;
+    if (b64_left_out(p, b64)) return;
     const int b64x = (b64 % p.b64_w) * 64, b64y = (b64 / p.b64_w) * 64;
     const int block_w = min(p.width - b64x, 64), block_h = min(p.height - b64y, 64);
     int       l = 0, r = (int)blockIdx.y;
@@ -441,6 +442,7 @@ __global__ void __launch_bounds__(HI_THREADS, 3) hme_l0_kernel(PICS pp, int n_b6
     const auto &p   = pp[blockIdx.x / n_b64];
     const auto &k   = p.ctrl;
     const int   b64 = blockIdx.x % n_b64;
+    if (b64_left_out(p, b64)) return;
     const int             b64x = (b64 % p.b64_w) * 64, b64y = (b64 / p.b64_w) * 64;
     const int             block_w = min(p.width - b64x, 64), block_h = min(p.height - b64y, 64);
     // references in reverse order: the closest references (smallest areas, cheapest items) are dispatched last and keep
@@ -991,7 +993,7 @@ __global__ void __launch_bounds__(FS ? HI_THREADS_FS : HI_THREADS) hme_l12_kerne
     const int             nw = k.num_hme_sa_w, nh = k.num_hme_sa_h;
     const int             n_refs = p.n_ref[0] + (p.n_list == 2 ? p.n_ref[1] : 0);
     int                   b64, item;
-    if (!b64_band_item(blockIdx.x, p.b64_w * p.b64_h, n_refs * nw * nh, b64, item)) return;
+    if (!b64_band_item(blockIdx.x, p.b64_w * p.b64_h, n_refs * nw * nh, b64, item) || b64_left_out(p, b64)) return;
     const int             b64x = (b64 % p.b64_w) * 64, b64y = (b64 / p.b64_w) * 64;
     const int             block_w = min(p.width - b64x, 64), block_h = min(p.height - b64y, 64);
     int                   l = 0, r = item / (nw * nh);
@@ -1184,7 +1186,7 @@ __global__ void __launch_bounds__(HI_THREADS) hme_l12_regions_kernel(PICS pp) {
     const auto &k = p.ctrl;
     const int   n_refs = p.n_ref[0] + (p.n_list == 2 ? p.n_ref[1] : 0);
     int         b64, item;
-    if (!b64_band_item(blockIdx.x, p.b64_w * p.b64_h, n_refs, b64, item)) return;
+    if (!b64_band_item(blockIdx.x, p.b64_w * p.b64_h, n_refs, b64, item) || b64_left_out(p, b64)) return;
     const int b64x = (b64 % p.b64_w) * 64, b64y = (b64 / p.b64_w) * 64;
     const int block_w = min(p.width - b64x, 64), block_h = min(p.height - b64y, 64);
     int       l = 0, r = item;

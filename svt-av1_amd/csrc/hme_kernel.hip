@@ -462,6 +462,7 @@ __global__ void __launch_bounds__(HME_THREADS) hme_kernel(PICS pp, int n_b64) {
     extern __shared__ __align__(16) uint8_t win[];
     const PicParams                      &p   = pp[blockIdx.x / n_b64];
     const int                             b64 = blockIdx.x % n_b64;
+    if (b64_left_out(p, b64)) return;
     if (threadIdx.x == 0) {
         S.l0c00_x = S.l0c00_y = 0;
         for (int r = 0; r < SVTME_MAX_REFS; ++r)

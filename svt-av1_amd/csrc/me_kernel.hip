@@ -207,7 +207,7 @@ __global__ void __launch_bounds__(ME_THREADS) me_plan_kernel(PICS pp, int n_b64,
     const int my = my_l * 4 + my_r;
     MeJob    *job = &p.me_jobs[b64 * 8 + my];
     for (int pu = tid; pu < SVTME_PU_COUNT; pu += ME_THREADS) p.me_keys[(size_t)(b64 * 8 + my) * SVTME_PU_COUNT + pu] = ~0ull;
-    if (!S.do_ref[my] || (p.me_type == SVTME_ME_MCTF && S.hsad[0] < p.tf_me_exit_th)) {
+    if (!S.do_ref[my] || (p.me_type == SVTME_ME_MCTF && S.hsad[0] < p.tf_me_exit_th) || b64_left_out(p, b64)) {
         if (tid == 0) *job = MeJob{0, 0, 0, 0};
         return;
     }

@@ -30,6 +30,14 @@ __device__ __forceinline__ bool ref_searched(const P &p, int l) { return p.tempo
 // :1638-1682): a window starting below `lo` is shifted, not shrunk (the size correction is computed from the
 // already corrected origin and is therefore zero); at the far side the origin is clamped to dim-1 and the size cut
 // so that the window ends at dim, but never below 1. int16_t arithmetic as in the reference.
+// svtme_picture::b64_step: the first pass's bypass_blk_step (firstpass.c:1282-1285) leaves out every block whose column or row
+// index is not a multiple of the step; nothing is computed for those.
+template <class P>
+__device__ __forceinline__ bool b64_left_out(const P &p, int b64) {
+    const int s = p.b64_step;
+    return s > 1 && ((b64 % p.b64_w) % s != 0 || (b64 / p.b64_w) % s != 0);
+}
+
 __device__ __forceinline__ void clip_axis(int o, int16_t &org, int16_t &size, int lo, int dim) {
     if (o + org < lo) {
         org  = (int16_t)(lo - o);

@@ -64,7 +64,8 @@ struct PicParams {
     int32_t        dep_pre; // list-1 pre-HME searches read the list-0 results (check_prehme_early_exit :1759-1768)
     int32_t        dep_l0; // the level-0 area of every reference but the first depends on the first one's vector (:1838-1850)
     int32_t        me_type; // SVTME_ME_OPEN_LOOP / SVTME_ME_MCTF / SVTME_ME_FIRST_PASS
-    int32_t        bypass_zz_check; // first pass only
+    int16_t        bypass_zz_check; // first pass only
+    int16_t        b64_step; // > 1: only the 64x64 blocks whose column and row index are multiples of it are searched
     int32_t        restricted; // integer search windows stay inside the block's tile (restricted_motion_vector)
     uint32_t       tf_me_exit_th;
     int32_t        me_max_items; // upper bound of search work items per (b64, ref) for this picture's controls

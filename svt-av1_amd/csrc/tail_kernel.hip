@@ -49,6 +49,7 @@ __global__ void __launch_bounds__(TAIL_THREADS) me_tail_kernel(PICS pp, int n_b6
     const auto &t    = p.tail;
     const int             lane = threadIdx.x;
     const int             b64  = blockIdx.x % n_b64;
+    if (b64_left_out(p, b64)) return;
     const int             b64x = (b64 % p.b64_w) * 64, b64y = (b64 / p.b64_w) * 64;
     const uint32_t        block_w = (uint32_t)min(p.width - b64x, 64), block_h = (uint32_t)min(p.height - b64y, 64);
     // best SAD / MV of reference (l, r), partition n: one plane per reference of the picture, list 0 first

@@ -79,7 +79,7 @@ class Picture(C.Structure):
         ("num_of_list_to_search", C.c_uint8), ("num_of_ref_pic_to_search", C.c_uint8 * 2), ("me_type", C.c_uint8),
         ("bypass_zz_check", C.c_uint8), ("restricted_motion_vector", C.c_uint8),
         ("ref_key", (C.c_uint64 * MAX_REFS) * MAX_LISTS), ("ref_picture_number", (C.c_uint64 * MAX_REFS) * MAX_LISTS),
-        ("ctrl", Controls), ("tail", Tail), ("tf_me_exit_th", C.c_uint32),
+        ("ctrl", Controls), ("tail", Tail), ("tf_me_exit_th", C.c_uint32), ("b64_step", C.c_uint8), ("reserved", C.c_uint8 * 3),
     ]
 
 
@@ -484,12 +484,14 @@ class Engine:
         return buf[:rows * st.value].reshape(rows, st.value).copy()
 
     def make_picture(self, width, height, poc, temporal_layer, is_ref, refs, ctrl, key_of=lambda poc: poc, tail=None,
-                     tf_me_exit_th=None, first_pass_bypass_zz=None, restricted_motion_vector=0, number_of=lambda poc: poc):
+                     tf_me_exit_th=None, first_pass_bypass_zz=None, restricted_motion_vector=0, number_of=lambda poc: poc, b64_step=0):
         """refs: [[pocs of list 0], [pocs of list 1]]; number_of: poc -> picture_number (the search areas grow with the
         picture-number distance); tail: a Tail to run the host tail on the device too;
         tf_me_exit_th: not None makes it a temporal-filter search (ME_MCTF) of refs[0][0] with that exit threshold;
-        first_pass_bypass_zz: not None makes it a first-pass search (ME_FIRST_PASS) with that bypass_zz_check."""
+        first_pass_bypass_zz: not None makes it a first-pass search (ME_FIRST_PASS) with that bypass_zz_check;
+        b64_step: n > 1 searches only the 64x64 blocks whose column and row index are multiples of n."""
         p = Picture()
+        p.b64_step = b64_step
         p.cur_key = key_of(poc)
         p.picture_number = number_of(poc)
         p.width, p.height = width, height

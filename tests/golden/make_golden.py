@@ -92,6 +92,9 @@ FP_CASES = {
                              motion=(8, 5)),
     "fp_tiles_fast_264x136": dict(width=264, height=136, n_frames=4, bypass_zz=1, reduce_me=1, seed=66, restricted=1,
                                   tiles=(3, 1), motion=(-9, -6)),
+    # the fastest first pass (ipp_pass_ctrls level 2): only every second block of every second block row is searched
+    # (MeContext::bypass_blk_step, firstpass.c:1282-1285); the other blocks' records stay zero
+    "fp_step2_328x264": dict(width=328, height=264, n_frames=4, bypass_zz=1, reduce_me=1, seed=67, b64_step=2, motion=(7, -4)),
 }
 
 
@@ -100,7 +103,7 @@ def fp_job(c):
                                                c.get("motion", (3, -2)))
     return frames, pics, dict(first_pass=(c["bypass_zz"], c["reduce_me"]), frame_rate=c.get("frame_rate", 30 << 16),
                               ref_counts=(2, 0), gm_enabled=1, gm_dist_th=1, restricted_motion_vector=c.get("restricted", 0),
-                              tiles=c.get("tiles", (0, 0)))
+                              tiles=c.get("tiles", (0, 0)), b64_step=c.get("b64_step", 0))
 
 
 def tf_job(c):

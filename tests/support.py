@@ -151,7 +151,8 @@ def run_engine_tf_job(frames, pics, level, exit_th, engine=None, serial_hme=0, r
             eng.close()
 
 
-def run_engine_first_pass_job(frames, pics, bypass_zz, reduce_me, frame_rate=30 << 16, tail=None, restricted=0, tiles=None):
+def run_engine_first_pass_job(frames, pics, bypass_zz, reduce_me, frame_rate=30 << 16, tail=None, restricted=0, tiles=None,
+                              b64_step=0):
     """First-pass searches (ME_FIRST_PASS) of a make_first_pass_job sequence through the engine's C ABI."""
     import svtme
     n, h, w = frames.shape
@@ -162,7 +163,8 @@ def run_engine_first_pass_job(frames, pics, bypass_zz, reduce_me, frame_rate=30 
         set_uniform_tiles(eng, w, h, tiles)
         ctrl = svtme.derive_first_pass_controls(w, h, frame_rate, reduce_me)
         return [eng.run_picture(eng.make_picture(w, h, p.poc, p.temporal_layer, p.is_ref, p.refs, ctrl, tail=tail,
-                                                 first_pass_bypass_zz=bypass_zz, restricted_motion_vector=restricted))
+                                                 first_pass_bypass_zz=bypass_zz, restricted_motion_vector=restricted,
+                                                 b64_step=b64_step))
                 for p in pics]
     finally:
         eng.close()

@@ -32,7 +32,7 @@ def test_struct_sizes_match_the_header():
     assert C.sizeof(svtme.SearchResult) == 24
     assert C.sizeof(svtme.Tail) == 16
     # keys/poc/geometry, ref keys, ref pocs, controls, device-tail parameters, tf_me_exit_th
-    assert C.sizeof(svtme.Picture) == 32 + 64 + 64 + 84 + 16 + 4  # tf_me_exit_th closes the struct
+    assert C.sizeof(svtme.Picture) == 32 + 64 + 64 + 84 + 16 + 4 + 1 + 3 + 4  # .. tf_me_exit_th, b64_step, reserved, padding to 8
 
 
 def test_bad_arguments_are_rejected_without_touching_a_device():

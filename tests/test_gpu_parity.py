@@ -362,6 +362,66 @@ def test_temporal_filter_search_argument_checks():
         eng.close()
 
 
+@pytest.mark.parametrize("kind,mode,step", [("fp", 0, 2), ("fp", 0, 3), ("open", 8, 2), ("open", 3, 2), ("open", 12, 2), ("tf", 0, 2)])
+def test_block_step_searches_only_the_lattice_blocks(kind, mode, step):
+    """svtme_picture::b64_step (the first pass's bypass_blk_step): the blocks whose column and row index are multiples of the
+    step get exactly the results they get when every block is searched - search results, minima, vectors and the device
+    tail's outputs -, singly and in a batch; the operation counters say that the other blocks cost nothing."""
+    w, h = 328, 264
+    if kind == "fp":
+        frames, pics = support.make_first_pass_job(w, h, 4, seed=77, motion=(5, -3))
+        ctrl = svtme.derive_first_pass_controls(w, h, 30 << 16, 0)
+        extra = dict(first_pass_bypass_zz=0)
+        tail = svtme.Tail(enable=1, enable_me_8x8=1, enable_me_16x16=1, max_refs=2, max_cand=3, max_l0=1,
+                          input_resolution=svtme.input_resolution(w, h), gm_enabled=0)
+    elif kind == "tf":
+        frames, pics = support.make_tf_job(w, h, 4, seed=78, motion=(5, -3))
+        ctrl, extra, tail = svtme.derive_tf_controls(1), dict(tf_me_exit_th=0), None
+    else:
+        frames, pics, rc = support.make_job(w, h, 9, mode, 79, "ra", "synth", (5, -3))
+        ctrl, extra = svtme.derive_controls(mode, w, h, 0, 30 << 16), {}
+        tail = svtme.Tail(enable=1, enable_me_8x8=1, enable_me_16x16=1, max_refs=rc[0] + rc[1],
+                          max_cand=rc[0] + rc[1] + rc[0] * rc[1] + (rc[0] - 1) + (1 if rc[1] == 3 else 0), max_l0=rc[0],
+                          input_resolution=svtme.input_resolution(w, h), gm_enabled=1, gm_use_distance_based_active_th=1)
+    bw, bh = (w + 63) // 64, (h + 63) // 64
+    on = np.array([(i % bw) % step == 0 and (i // bw) % step == 0 for i in range(bw * bh)])
+    assert 0 < on.sum() < on.size
+    eng = svtme.Engine(w, h, store_slots=len(frames) + 1, max_in_flight=8, kernel_timing=1)
+    try:
+        for i in range(len(frames)):
+            eng.store_put(i, i, frames[i])
+        mk = lambda p, s: eng.make_picture(w, h, p.poc, p.temporal_layer, p.is_ref, p.refs, ctrl, tail=tail, b64_step=s, **extra)  # noqa: E731
+        for p in pics:
+            t = eng.submit(mk(p, 0))
+            full = eng.wait(t)
+            full_ops = sum(eng.ops(t))
+            eng.done(t)
+            t = eng.submit(mk(p, step))
+            part = eng.wait(t)
+            part_ops = sum(eng.ops(t))
+            eng.done(t)
+            assert 0 < part_ops < 0.6 * full_ops  # 9 of 30 blocks at step 2 (the ragged, cheaper column is not among them)
+            for f in part:
+                a, b = np.asarray(part[f]), np.asarray(full[f])
+                if a.ndim == 0 or a.shape[0] != on.size:
+                    continue
+                if a.dtype.names:
+                    for g in a.dtype.names:
+                        assert np.array_equal(a[g][on], b[g][on]), (kind, mode, p.poc, f, g)
+                else:
+                    assert np.array_equal(a[on], b[on]), (kind, mode, p.poc, f)
+        batch = [mk(p, step) for p in pics[:4]]
+        singles = [eng.run_picture(d) for d in batch]
+        tickets = eng.submit_batch(batch)
+        for t, one in zip(tickets, singles):
+            got = eng.wait(t)
+            eng.done(t)
+            assert np.array_equal(np.asarray(got["best_mv"])[on], np.asarray(one["best_mv"])[on])
+            assert np.array_equal(np.asarray(got["best_sad"])[on], np.asarray(one["best_sad"])[on])
+    finally:
+        eng.close()
+
+
 def test_tile_rects_argument_checks_and_clearing():
     """svtme_set_tile_rects: shapes and bounds are checked, a restricted temporal-filter picture of another size than the
     table's is refused, clearing the table gives the one-tile results again, and an unrestricted picture never reads it."""
@@ -420,21 +480,24 @@ def test_first_pass_search_matches_reference_goldens(name):
                       input_resolution=int(pd0["input_resolution"]), gm_enabled=0)
     assert (tail.max_refs, tail.max_cand, tail.max_l0) == (2, 3, 1)
     outs = support.run_engine_first_pass_job(frames, pics, c["bypass_zz"], c["reduce_me"], c.get("frame_rate", 30 << 16), tail=tail,
-                                             restricted=c.get("restricted", 0), tiles=c.get("tiles"))
+                                             restricted=c.get("restricted", 0), tiles=c.get("tiles"), b64_step=c.get("b64_step", 0))
     stat_names = ["rc_me_distortion", "me_64x64_distortion", "me_32x32_distortion", "me_16x16_distortion",
                   "me_8x8_distortion", "me_8x8_cost_variance", "stationary_block_present_sb", "rc_me_allow_gm"]
+    # with a block step only the blocks on the lattice are searched; the others' results are undefined
+    step, bw = c.get("b64_step", 0), (c["width"] + 63) // 64
+    on = np.array([step <= 1 or ((i % bw) % step == 0 and (i // bw) % step == 0) for i in range(g["b64"].shape[1])])
     for i, (p, out) in enumerate(zip(pics, outs)):
         bd = g["b64"][i]
         sr = out["search_results"]
         for f in ("hme_sc_x", "hme_sc_y", "hme_sad", "do_ref"):
-            assert np.array_equal(sr[f], bd[f]), (name, p.poc, f)
+            assert np.array_equal(sr[f][on], bd[f][on]), (name, p.poc, f)
         nr = len(p.refs[0])
-        assert np.array_equal(out["best_sad"][:, 0, :nr], bd["best_sad"][:, 0, :nr]), (name, p.poc, "best_sad")
-        assert np.array_equal(out["best_mv"][:, 0, :nr], bd["best_mv"][:, 0, :nr]), (name, p.poc, "best_mv")
+        assert np.array_equal(out["best_sad"][on][:, 0, :nr], bd["best_sad"][on][:, 0, :nr]), (name, p.poc, "best_sad")
+        assert np.array_equal(out["best_mv"][on][:, 0, :nr], bd["best_mv"][on][:, 0, :nr]), (name, p.poc, "best_mv")
         for f in ("total_me_candidate_index", "me_mv_array", "me_candidate_array", "me_distortion"):
-            assert np.array_equal(out[f], bd[f]), (name, p.poc, f)
+            assert np.array_equal(out[f][on], bd[f][on]), (name, p.poc, f)
         for j, f in enumerate(stat_names):
-            assert np.array_equal(out["b64_stats"][:, j], bd[f].astype(np.uint32)), (name, p.poc, f)
+            assert np.array_equal(out["b64_stats"][on, j], bd[f][on].astype(np.uint32)), (name, p.poc, f)
             assert not bd[f].any()
 
 

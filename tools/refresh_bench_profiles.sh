@@ -19,6 +19,7 @@ run 4k_ra_m8 --workload 4k_ra_m8
 run 1080p_tf_l0 --workload 1080p_tf_l0
 run 1080p_tf_l2 --workload 1080p_tf_l2
 run 1080p_first_pass --workload 1080p_first_pass
+run 1080p_first_pass_fast --workload 1080p_first_pass_fast
 run 8k_ra_m2 --workload 8k_ra_m2 --steps 10 --warmup 2 --kernel-steps 2
 # the same with every source picture put into the device store inside the timed region (zero-copy puts from page-locked
 # buffers with the encoder's stride); these lines carry no CPU baseline
