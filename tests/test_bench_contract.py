@@ -20,7 +20,7 @@ def check_line(d, expect_cpu_baseline):
         assert k in d and isinstance(d[k], t), k
     assert "vs_baseline" in d and d["vs_baseline"] is None  # no published number exists for this metric
     assert d["metric"] == "open-loop ME pictures/s" and d["unit"] == "pictures/s"
-    # round 1's lines were replicas per rank ("weak"); since then N ranks split one sequence ("strong")
+    # N ranks split one sequence ("strong"); replicas per rank would be "weak"
     assert d["higher_is_better"] is True and d["scaling"] in ("weak", "strong") and d["dtype"] == "u8" and d["data"] == "synthetic"
     assert isinstance(d["config"].get("workload"), str) and "model" not in d["config"]
     assert d["value"] > 0 and d["ms_per_step"] > 0
