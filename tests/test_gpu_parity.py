@@ -964,6 +964,31 @@ def test_two_ranks_share_a_sequence_without_any_exchange():
     assert not msgs, "\n".join(msgs[:10])
 
 
+def test_engine_group_hands_the_tiles_to_every_engine():
+    """svtme_group_set_tile_rects: restricted temporal-filter pairs through a group of two engines (round robin, so both
+    run some) give the reference's tiled results."""
+    c = MOD.TF_CASES["tf0_tiles_320x192"]
+    g = np.load(os.path.join(GOLDEN, "tf0_tiles_320x192.npz"))
+    frames, pics, _ = MOD.tf_job(c)
+    n, h, w = frames.shape
+    ctrl = svtme.derive_tf_controls(c["level"])
+    grp = svtme.Group([0, 0], w, h, store_slots=n + 1, max_in_flight=2)
+    try:
+        for i in range(n):
+            grp.store_put(i, i, frames[i])
+        grp.set_tile_rects(w, h, svtme.uniform_tile_rects(w, h, *c["tiles"]))
+        for i, p in enumerate(pics):
+            t = grp.submit(grp.make_picture(w, h, p.poc, p.temporal_layer, p.is_ref, p.refs, ctrl, tf_me_exit_th=c["exit_th"],
+                                            restricted_motion_vector=1))
+            out = grp.wait(t)
+            grp.done(t)
+            want = MOD.tf_canonical(g["b64"][i])
+            for f, v in support.tf_fields(out).items():
+                assert np.array_equal(v, want[f]), ("engine %d" % (t >> 56), p.refs[0][0], f)
+    finally:
+        grp.close()
+
+
 def test_engine_group_shards_one_sequence_and_moves_sources_only_where_they_are_read():
     """svtme_group (the in-process multi-GPU path of the C ABI) with two engines on the one GPU of this box: pictures go
     round robin, every source is uploaded once per engine that reads it, results equal the oracle's; a key announced
