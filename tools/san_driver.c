@@ -231,6 +231,19 @@ static uint64_t run_size(uint32_t w, uint32_t h, uint32_t max_w, uint32_t max_h,
     CHECK(svtme_picture_wait(eng, t[0], &res));
     hsh = hash_results(&res, &fp, hsh);
     CHECK(svtme_picture_done(eng, t[0]));
+    /* the first pass's block step: only every second block of every second block row; the others are not looked at */
+    fp.b64_step = 2;
+    CHECK(svtme_picture_submit(eng, &fp, &t[0]));
+    CHECK(svtme_picture_wait(eng, t[0], &res));
+    {
+        const uint32_t bw = (w + 63) / 64;
+        for (uint32_t b = 0; b < res.n_b64; ++b)
+            if ((b % bw) % 2 == 0 && (b / bw) % 2 == 0) hsh = fnv(hsh, &res.search_results[b * 8], 8 * sizeof(svtme_search_result));
+    }
+    CHECK(svtme_picture_done(eng, t[0]));
+    fp.b64_step = 9;
+    EXPECT(svtme_picture_submit(eng, &fp, &t[0]), SVTME_ERR_BAD_ARG);
+    fp.b64_step = 0;
 
     /* read back a plane, then leave with a picture still in flight */
     {
