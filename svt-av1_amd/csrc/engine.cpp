@@ -181,6 +181,10 @@ struct svtme_engine {
     int                 copy_on_search_stream = -1; // -1: with three search streams only; 0 / 1: diagnostic override
     std::vector<Slot>   slots;
     std::vector<Flight> flights;
+    // the flights' result blocks, device and pinned host: flight i's at i * res_stride of one allocation each, so that the
+    // results of a batch on neighbouring flights can go to the host in one strided copy
+    uint8_t            *d_res_arena = nullptr, *h_res_arena = nullptr;
+    size_t              res_stride = 0;
     std::vector<BatchRec> batches;
     // the pictures' parameter records: a ring in device memory and its pinned host mirror; a batch takes a run of
     // neighbouring records; the record behind the ring belongs to svtme_picture_search_static
@@ -254,9 +258,7 @@ void free_flight(Flight &f) {
     if (f.d_hme) (void)hipFree(f.d_hme);
     if (f.d_jobs) (void)hipFree(f.d_jobs);
     if (f.d_keys) (void)hipFree(f.d_keys);
-    if (f.d_res) (void)hipFree(f.d_res);
-    if (f.h_res) (void)hipHostFree(f.h_res);
-    f = Flight();
+    f = Flight(); // (the result blocks are parts of the engine's arenas)
 }
 
 } // namespace
@@ -311,13 +313,23 @@ extern "C" int svtme_create(const svtme_config *cfg, svtme_engine **out) {
             return fail(SVTME_ERR_NO_RESOURCES);
     }
     e->flights.resize(cfg->max_in_flight);
-    for (auto &f : e->flights) {
+    {
+        Flight probe;
+        probe.layout(e->max_b64, SVTME_MAX_LISTS * SVTME_MAX_REFS, true); // the largest a picture can ask for
+        e->res_stride = align_up(probe.res_bytes, 256);
+        if (hipMalloc((void **)&e->d_res_arena, e->res_stride * cfg->max_in_flight) != hipSuccess ||
+            hipHostMalloc((void **)&e->h_res_arena, e->res_stride * cfg->max_in_flight, hipHostMallocDefault) != hipSuccess)
+            return fail(SVTME_ERR_NO_RESOURCES);
+    }
+    for (size_t fi = 0; fi < e->flights.size(); ++fi) {
+        Flight      &f = e->flights[fi];
         const size_t n = e->max_b64 * SVTME_MAX_LISTS * SVTME_MAX_REFS;
-        f.layout(e->max_b64, SVTME_MAX_LISTS * SVTME_MAX_REFS, true); // the largest a picture can ask for
-        if (hipMalloc((void **)&f.d_hme, n * sizeof(HmeRefOut) + SVTME_OPS_BYTES) != hipSuccess || hipMalloc((void **)&f.d_res, f.res_bytes) != hipSuccess ||
+        f.layout(e->max_b64, SVTME_MAX_LISTS * SVTME_MAX_REFS, true);
+        f.d_res = e->d_res_arena + fi * e->res_stride;
+        f.h_res = e->h_res_arena + fi * e->res_stride;
+        if (hipMalloc((void **)&f.d_hme, n * sizeof(HmeRefOut) + SVTME_OPS_BYTES) != hipSuccess ||
             hipMalloc((void **)&f.d_jobs, n * sizeof(MeJob)) != hipSuccess ||
-            hipMalloc((void **)&f.d_keys, n * SVTME_PU_COUNT * sizeof(unsigned long long)) != hipSuccess ||
-            hipHostMalloc((void **)&f.h_res, f.res_bytes, hipHostMallocDefault) != hipSuccess)
+            hipMalloc((void **)&f.d_keys, n * SVTME_PU_COUNT * sizeof(unsigned long long)) != hipSuccess)
             return fail(SVTME_ERR_NO_RESOURCES);
         if (hipMemset(f.d_hme, 0, n * sizeof(HmeRefOut) + SVTME_OPS_BYTES) != hipSuccess) return fail(SVTME_ERR_DEVICE);
     }
@@ -352,6 +364,8 @@ extern "C" void svtme_destroy(svtme_engine *e) {
     for (auto d : e->d_upload)
         if (d) (void)hipFree(d);
     for (auto &f : e->flights) free_flight(f);
+    if (e->d_res_arena) (void)hipFree(e->d_res_arena);
+    if (e->h_res_arena) (void)hipHostFree(e->h_res_arena);
     for (auto &b : e->batches)
         for (auto &ev : b.ev)
             if (ev) (void)hipEventDestroy(ev);
@@ -716,9 +730,19 @@ extern "C" int svtme_pictures_submit(svtme_engine *e, const svtme_picture *pics,
     // ---- resources: a flight per picture, a batch record, a run of parameter records
     Flight *fl[SVTME_MAX_BATCH];
     {
+        // neighbouring flights when there are n free ones in a row (their result blocks then lie one stride apart), else
+        // any n free ones
         uint32_t got = 0;
-        for (auto &c : e->flights)
-            if (!c.busy && got < n) fl[got++] = &c;
+        for (size_t i = 0, run = 0; i < e->flights.size() && got < n; ++i) {
+            run = e->flights[i].busy ? 0 : run + 1;
+            if (run == n)
+                for (uint32_t j = 0; j < n; ++j) fl[got++] = &e->flights[i + 1 - n + j];
+        }
+        if (got < n) {
+            got = 0;
+            for (auto &c : e->flights)
+                if (!c.busy && got < n) fl[got++] = &c;
+        }
         if (got < n) return SVTME_ERR_NO_RESOURCES;
     }
     int bi = -1;
@@ -802,11 +826,22 @@ extern "C" int svtme_pictures_submit(svtme_engine *e, const svtme_picture *pics,
         // (kernels that write their results straight into the pinned host block were measured against these copies: slower
         // at 1080p and 4K - the finishing kernel then runs at the link's pace -, faster only at 720p)
         if (sc != sm && (err = hipStreamWaitEvent(sc, B.ev[5], 0)) != hipSuccess) return err;
-        for (uint32_t i = 0; i < n; ++i) {
-            // tail.enable == 2: the host wants finished results only, the best SAD / MV planes (the end of the block)
-            // stay on the device
-            const size_t c1 = skip_arrays ? fl[i]->tail_end : fl[i]->res_bytes;
-            if ((err = hipMemcpyAsync(fl[i]->h_res, fl[i]->d_res, c1, hipMemcpyDeviceToHost, sc)) != hipSuccess) return err;
+        // tail.enable == 2: the host wants finished results only, the best SAD / MV planes (the end of the block) stay on
+        // the device
+        auto bytes_of = [&](uint32_t i) { return skip_arrays ? fl[i]->tail_end : fl[i]->res_bytes; };
+        // Pictures on neighbouring flights that bring back equally much (the same number of references: low-delay P
+        // pictures, temporal-filter pairs, the first pass) go to the host in one strided copy, a row per picture: a copy
+        // call costs the submitting thread several microseconds, which is what bounds the smallest pictures.
+        static const bool no_strided = getenv("SVTME_NO_STRIDED_COPY") != nullptr; // diagnostic
+        for (uint32_t i = 0; i < n;) {
+            uint32_t j = i + 1;
+            while (!no_strided && j < n && fl[j] == fl[j - 1] + 1 && bytes_of(j) == bytes_of(i)) ++j;
+            if (j - i > 1)
+                err = hipMemcpy2DAsync(fl[i]->h_res, e->res_stride, fl[i]->d_res, e->res_stride, bytes_of(i), j - i, hipMemcpyDeviceToHost, sc);
+            else
+                err = hipMemcpyAsync(fl[i]->h_res, fl[i]->d_res, bytes_of(i), hipMemcpyDeviceToHost, sc);
+            if (err != hipSuccess) return err;
+            i = j;
         }
         return hipEventRecord(B.ev[6], sc);
     };
