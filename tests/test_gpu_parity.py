@@ -422,6 +422,39 @@ def test_block_step_searches_only_the_lattice_blocks(kind, mode, step):
         eng.close()
 
 
+@pytest.mark.parametrize("w,h", [(1280, 720), (7680, 4320)])
+def test_strided_result_copy_of_a_uniform_batch_equals_single_submissions(w, h):
+    """Pictures of a batch that bring back equally much leave the device in one strided copy (a row per picture, rows one
+    result-block stride apart: ~60 MB at 8K); every byte of every picture's results must be what a single submission
+    gives, also for the picture in the middle of a run and when the run does not start at the first flight."""
+    from svtme import synth
+    frames = synth.synth_sequence(w, h, 3, seed=5, bit_depth=8)
+    ctrl = svtme.derive_tf_controls(2)
+    eng = svtme.Engine(w, h, store_slots=4, max_in_flight=5)
+    try:
+        for i in range(3):
+            eng.store_put(i, i, frames[i])
+        descs = [eng.make_picture(w, h, 1, 0, 1, [[r], []], ctrl, tf_me_exit_th=0) for r in (0, 2, 0)]
+        singles = [eng.run_picture(d) for d in descs]
+        hold = eng.submit(descs[0])  # occupies the first flight: the batch's run starts behind it
+        tickets = eng.submit_batch(descs)
+        outs = [eng.wait(t) for t in tickets]
+        for t in tickets:
+            eng.done(t)
+        eng.wait(hold)
+        eng.done(hold)
+        for one, got in zip(singles, outs):
+            for f in got:
+                a, b = np.asarray(one[f]), np.asarray(got[f])
+                if a.dtype.names:
+                    for g in a.dtype.names:
+                        assert np.array_equal(a[g], b[g]), (f, g)
+                else:
+                    assert np.array_equal(a, b), f
+    finally:
+        eng.close()
+
+
 def test_tile_rects_argument_checks_and_clearing():
     """svtme_set_tile_rects: shapes and bounds are checked, a restricted temporal-filter picture of another size than the
     table's is refused, clearing the table gives the one-tile results again, and an unrestricted picture never reads it."""
