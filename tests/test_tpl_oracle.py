@@ -12,7 +12,7 @@ import refio
 import support
 import tpl_cases
 import tplio
-from tpl_cases import CASES, SEARCH_FIELDS, UNSUPPORTED_CASES
+from tpl_cases import CASES, SEARCH_FIELDS
 
 GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 
@@ -96,16 +96,6 @@ def test_oracle_reproduces_every_intra_mode_cost_the_reference_recorded(name):
                 assert got.tolist() == tb[b64, bi]["costs"][:13].tolist(), (name, pic.poc, b64, bi)
                 n += 1
     assert n > 0
-
-
-@pytest.mark.parametrize("name", sorted(UNSUPPORTED_CASES))
-def test_oracle_refuses_the_levels_it_does_not_restate(name):
-    frames, pics, per = load_case(name, UNSUPPORTED_CASES[name])
-    ctrl, me, tb, quant = per[0]
-    assert not ctrl["tpl_opt_flag"]
-    p, keep, refs = picture_of(frames, pics[0], ctrl, me)
-    with pytest.raises(RuntimeError, match="-5"):
-        tplio.oracle_search(frames[pics[0].poc], refs, p)
 
 
 def test_block_geometry_follows_the_dispensers_tables():
