@@ -1,3 +1,6 @@
+"""Host time of the driving loop on the launch-bound workloads (inputs resident, a mini-GOP per submit): microseconds per
+picture in svtme_pictures_submit and in wait + done against the wall time. Diagnostic.
+    python tools/host_split_probe.py"""
 import sys, time
 sys.path.insert(0, "svt-av1_amd"); sys.path.insert(0, ".")
 import bench, svtme
