@@ -66,7 +66,9 @@ STAGES = ["zz_centre", "prehme", "hme_l0", "hme_l1", "hme_l2", "integer_search"]
 # Packed-SAD peak of gfx950: 256 CUs x 4 SIMDs x 16 lanes/clk (v_sad_u8 / v_qsad_pk_u16_u8 issue at a quarter of the
 # lane rate, measured in profiles/r01_probe_sad_rates.txt: 146 T/s sustained) x 4 byte differences x 2.4 GHz.
 PEAK_SAD_TOPS = 256 * 4 * 16 * 4 * 2.4e9 / 1e12
+MEASURED_SAD_TOPS = 146.6  # sustained v_qsad_pk_u16_u8 rate of a probe kernel that does nothing else (profiles/r01_probe_sad_rates.txt)
 PEAK_HBM_GBS = 8000.0
+SEED = 1000  # of the synthetic sequence; tests/golden/bench_digests.json holds the reference's digests for it
 
 
 def make_pictures(wl, seed):
@@ -98,7 +100,7 @@ def cpu_baseline(wl, frames, pics, budget_s=20.0):
     with tempfile.TemporaryDirectory(prefix="svtme_bench_") as td:
         job, out = os.path.join(td, "job.bin"), os.path.join(td, "out.bin")
 
-        def run(reps):
+        def run(reps, sample=sample, threads=threads):
             refio.write_job(job, frames, sample, wl["enc_mode"], mode=refio.MODE_BENCH, threads=threads, use_avx2=avx2,
                             reps=reps, ref_counts=rc, tf=wl.get("tf"), first_pass=wl.get("fp"), b64_step=wl.get("b64_step", 0))
             r = subprocess.run([binary, job, out], capture_output=True, text=True, timeout=600)
@@ -111,9 +113,14 @@ def cpu_baseline(wl, frames, pics, budget_s=20.0):
         reps = int(min(20, max(1, (budget_s / threads) / per_pass)))
         if reps > 1:
             hdr = run(reps)
+        # the same path on one host thread, over as many of the sample's pictures as a quarter of the budget allows
+        n1 = int(min(len(sample), max(1, (budget_s / 4) / max(per_pass * threads / len(sample), 1e-3))))
+        hdr1 = run(1, sample[:n1], 1)
     used_avx2 = bool(hdr.get("used_avx2", 0))
     return {
         "value": hdr["bench_pictures"] / hdr["bench_seconds"], "unit": "pictures/s", "cores": threads, "kind": kind,
+        "single_thread": {"value": hdr1["bench_pictures"] / max(hdr1["bench_seconds"], 1e-9), "cores": 1,
+                          "sample": "the first %d pictures of the same sample, one pass" % n1},
         "sample": "%d pictures x %d passes of the same %s workload, %s, %d threads over b64 rows" %
                   (len(sample), hdr["bench_pictures"] // max(1, len(sample)), wl["name"],
                    "reference C control code + its AVX2 SAD kernels" if (kind == "reference" and used_avx2)
@@ -134,6 +141,8 @@ def main():
                     help="0 = the engine's default: one stream for batches, three for pictures submitted singly")
     ap.add_argument("--kernel-steps", type=int, default=8, help="steps of the one-stream pass that times the kernels")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-verify", action="store_true",
+                    help="skip the check (outside the timed region) of one more step's results against the reference's digest")
     ap.add_argument("--with-upload", action="store_true",
                     help="every step also puts each of its source pictures into the device store once, inside the timed "
                          "region (host -> device included; reported as a second line of evidence, never as `value` of the default run)")
@@ -176,7 +185,7 @@ def main():
     if args.in_flight <= 0:
         args.in_flight = max(6, 3 * args.batch)
     args.in_flight = max(args.in_flight, args.batch)
-    frames, pics = make_pictures(wl, seed=1000)  # every rank sees the same sequence
+    frames, pics = make_pictures(wl, seed=SEED)  # every rank sees the same sequence
     n, h, w = frames.shape
     tf, fp = wl.get("tf"), wl.get("fp")
     ctrl = (svtme.derive_tf_controls(tf[0]) if tf else
@@ -240,17 +249,39 @@ def main():
             e.store_put(1000 * ks + k_, k_, view)
         puts_made[0] += 1
 
-    def run_steps(k, collect, e=None, ds=None, upload=False, owners=None):
+    def run_steps(k, collect, e=None, ds=None, upload=False, owners=None, sample=None, keep=None):
         """k steps back to back: at most --in-flight pictures outstanding, also across step boundaries (mini-GOPs follow
         each other without a pause, as they do in the encoder); everything has been waited for on return. owners: the
-        rank of every picture of the k steps (this rank runs its own ones only)."""
+        rank of every picture of the k steps (this rank runs its own ones only). sample = (stats, stride): the kernel
+        durations of every stride-th submission are added to stats (one svtme_picture_timing call for the submission: its
+        pictures share their launches and report equal shares). keep: a list that receives every picture's results."""
         e, ds = e or eng, ds or descs
         tickets, group = [], []
+        sampled, n_flush = set(), [0]
+
+        def finish(e, t, collect):
+            if keep is not None:
+                keep.append(e.wait(t))
+            else:
+                e.wait_raw(t)  # the picture's results have landed in pinned host memory (no conversion to numpy in the timed loop)
+            if t in sampled:
+                sampled.discard(t)
+                sample[0]["ms"] += np.array(e.timing(t), np.float64)
+                sample[0]["launches"] += 1
+            if collect is not None:
+                collect["ms"] += np.array(e.timing(t), np.float64)
+                collect["launches"] += 1
+                collect["ops"] += np.array(e.ops(t), np.float64)
+            e.done(t)
 
         def flush():
             while len(tickets) + len(group) > args.in_flight:
                 finish(e, tickets.pop(0), collect)
-            tickets.extend(e.submit_batch(group) if len(group) > 1 else [e.submit(group[0])])
+            new = e.submit_batch(group) if len(group) > 1 else [e.submit(group[0])]
+            if sample is not None and n_flush[0] % sample[1] == 0:
+                sampled.add(new[0])
+            n_flush[0] += 1
+            tickets.extend(new)
             group.clear()
 
         for step in range(k):
@@ -271,14 +302,6 @@ def main():
             flush()
         while tickets:
             finish(e, tickets.pop(0), collect)
-
-    def finish(e, t, collect):
-        e.wait_raw(t)  # the picture's results have landed in pinned host memory (no conversion to numpy in the timed loop)
-        if collect is not None:
-            collect["ms"] += np.array(e.timing(t), np.float64)
-            collect["launches"] += 1
-            collect["ops"] += np.array(e.ops(t), np.float64)
-        e.done(t)
 
     def barrier():
         if use_dist:
@@ -307,8 +330,12 @@ def main():
     barrier()
     puts_made[0] = 0
     t0 = time.perf_counter()
-    # nothing but (put,) submit / wait / done per picture inside the timed region
-    run_steps(args.steps, None, upload=args.with_upload, owners=owners_timed)
+    # nothing but (put,) submit / wait / done per picture inside the timed region - and, with one search stream, one
+    # svtme_picture_timing call for every few submissions (at most ~64 over the region): the kernels' HIP events
+    timed = new_stats()
+    n_submits = max(1, args.steps * ((per_rank[rank] // args.steps + args.batch - 1) // args.batch))
+    run_steps(args.steps, None, upload=args.with_upload, owners=owners_timed,
+              sample=(timed, max(1, n_submits // 64)) if streams == 1 else None)
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
     barrier()
@@ -332,8 +359,36 @@ def main():
         fh, fw = frames[0].shape
         eng.store_read(n - 1, 0, (fh // 4, fw // 4))  # waits for the store stream (reads back the smallest plane of the last put)
         upload_pps = 4 * n / max(1e-9, time.perf_counter() - t1)
+    # the last word on parity: one more step, its results against the digest of the real reference's output for the same
+    # seeded pictures (tests/golden/bench_digests.json, written by tests/golden/make_golden.py --bench)
+    verified, verify_note = None, "skipped"
+    if rank == 0 and not args.no_verify:
+        from svtme import verify
+        try:
+            with open(os.path.join(ROOT, "tests", "golden", "bench_digests.json")) as f:
+                want = json.load(f)["digests"].get(args.workload)
+        except (OSError, ValueError, KeyError):
+            want = None
+        import hashlib
+        if args.device_tail_only:
+            verify_note = "--device-tail-only leaves the search arrays on the device"
+        elif want is None:
+            verify_note = "tests/golden/bench_digests.json holds no digest of this workload"
+        elif hashlib.sha256(frames.tobytes()).hexdigest() != want["frames_sha256"]:
+            verified, verify_note = False, "the synthetic pictures differ from the ones the reference digested"
+        else:
+            outs = []
+            run_steps(1, None, keep=outs)
+            got = verify.engine_digest(outs, pics, verify.kind_of(wl), (w + 63) // 64, wl.get("b64_step", 0))
+            verified = got == want["sha256"]
+            verify_note = ("%d pictures of one more step (submitted %d at a time, as in the timed region): sha256 over their search "
+                           "centres, zero-MV SADs, divisors and best SAD / MV arrays %s the reference's (ref_me, AVX2 kernels)"
+                           % (len(outs), args.batch, "equals" if verified else "DIFFERS FROM"))
     # kernels alone on the GPU: same pictures, one search stream (rank 0 reports them)
     solo = stats
+    if streams == 1 and timed["launches"]:
+        # the timed region's own events; the operation counts (the same for every step: same pictures) from the pass after it
+        solo = {"ms": timed["ms"], "launches": timed["launches"], "ops": stats["ops"] * (timed["launches"] / max(1, stats["launches"]))}
     if rank == 0 and streams != 1 and args.kernel_steps > 0:
         eng.close()
         eng, descs = make_engine(1, 1)
@@ -406,10 +461,14 @@ def main():
                 # a launch covers the `pictures_per_submit` pictures of a batch: operations, duration and traffic are the
                 # launch's divided by that number, i.e. per picture
                 "ops_per_launch": dom_ops, "avg_launch_ms": dom_ms,
-                "measured": "HIP events on the kernels' stream, %d-step pass with one search stream after the timed region"
-                            % args.kernel_steps if solo is not stats else "HIP events on the kernels' stream, timed region",
+                "frac_vs_measured_rate": achieved / MEASURED_SAD_TOPS,
+                "measured_rate": MEASURED_SAD_TOPS,
+                "measured": ("HIP events on the kernels' stream inside the timed region, %d of its submissions sampled" % timed["launches"]
+                             if streams == 1 and timed["launches"] else
+                             "HIP events on the kernels' stream, %d-step pass with one search stream after the timed region" % args.kernel_steps),
                 "all_kernels": {"ops_per_picture": float(ops.sum()), "ms_per_picture": kernel_ms,
-                                "achieved": float(ops.sum()) / (kernel_ms * 1e-3) / 1e12 if kernel_ms > 0 else 0.0},
+                                "achieved": float(ops.sum()) / (kernel_ms * 1e-3) / 1e12 if kernel_ms > 0 else 0.0,
+                                "frac": (float(ops.sum()) / (kernel_ms * 1e-3) / 1e12 if kernel_ms > 0 else 0.0) / PEAK_SAD_TOPS},
                 "hbm_view": {"algorithmic_bytes_per_picture": alg_bytes,
                              "achieved_GBps": alg_bytes / (kernel_ms * 1e-3) / 1e9 if kernel_ms > 0 else 0.0,
                              "peak_GBps": PEAK_HBM_GBS},
@@ -422,6 +481,7 @@ def main():
             "with_upload": ({"mode": args.upload_mode, "sources_put_per_step": n,
                              "note": "every source picture of a step is put into the device store once inside the timed region"}
                             if args.with_upload else None),
+            "verified": verified, "verify": verify_note,
             "ops_by_stage": dict(zip(STAGES, [float(v) for v in ops])),
             "picture_ms_incl_d2h": float(ms[6]),
         }

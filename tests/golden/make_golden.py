@@ -168,11 +168,47 @@ def main_big():
         json.dump(doc, f, indent=1)
 
 
+def main_bench():
+    """`make_golden.py --bench [workload ...]`: one digest per bench.py workload (its seed-1000 pictures through the real
+    reference with its AVX2 SAD kernels, which the digest cases above assert equal to its C kernels) into
+    bench_digests.json: what `bench.py` checks its last step's results against."""
+    sys.path.insert(0, ROOT)
+    import bench
+    from svtme import gop, verify
+    path = os.path.join(HERE, "bench_digests.json")
+    doc = {"seed": bench.SEED, "digests": {}}
+    if os.path.exists(path):
+        with open(path) as f:
+            doc = json.load(f)
+    names = [a for a in sys.argv[sys.argv.index("--bench") + 1:] if not a.startswith("-")] or sorted(bench.WORKLOADS)
+    for name in names:
+        wl = dict(bench.WORKLOADS[name], name=name)
+        frames, pics = bench.make_pictures(wl, seed=bench.SEED)
+        kind = verify.kind_of(wl)
+        if kind == "tf":
+            kw = dict(tf=wl["tf"])
+        elif kind == "fp":
+            kw = dict(first_pass=wl["fp"], ref_counts=(2, 0), b64_step=wl.get("b64_step", 0))
+        else:
+            b0, b1, n0, n1 = gop.mrp_counts(wl["enc_mode"])
+            kw = dict(ref_counts=(max(b0, n0), max(b1, n1)))
+        hdr, recs = refio.run_reference(frames, pics, wl["enc_mode"], threads=8, use_avx2=1, **kw)
+        assert hdr["used_avx2"]
+        doc["digests"][name] = {
+            "frames_sha256": hashlib.sha256(frames.tobytes()).hexdigest(), "pictures": len(pics),
+            "sha256": verify.reference_digest(recs, pics, kind, (wl["width"] + 63) // 64, wl.get("b64_step", 0))}
+        print(name, doc["digests"][name]["sha256"][:16], len(pics), "pictures", flush=True)
+        with open(path, "w") as f:
+            json.dump(doc, f, indent=1)
+
+
 def main():
     if not refio.have_reference():
         sys.exit("oracle/_ref/ref_me missing: run `make -C oracle ref` where /root/reference exists")
     if "--big" in sys.argv:
         return main_big()
+    if "--bench" in sys.argv:
+        return main_bench()
     # `make_golden.py --only name ...`: just these full-dump fixtures, digests.json untouched
     only = sys.argv[sys.argv.index("--only") + 1:] if "--only" in sys.argv else None
     want = lambda name: only is None or name in only  # noqa: E731

@@ -99,22 +99,30 @@ def compare_picture(out, bd, pic, where=""):
 
 
 def run_engine_job(frames, pics, enc_mode, sc_class1=0, frame_rate=30 << 16, engine=None, tail=None, serial_hme=0,
-                   restricted=0, number_scale=1, tiles=None):
+                   restricted=0, number_scale=1, tiles=None, batch=1):
     """Runs every picture of the job through the engine's C ABI; returns the list of output dicts. tail: an
-    svtme.Tail to run the host tail on the device as well."""
+    svtme.Tail to run the host tail on the device as well. batch > 1: the pictures go through svtme_pictures_submit,
+    `batch` at a time (one set of launches for all of them, one search stream), as the benchmark submits them."""
     import svtme
     n, h, w = frames.shape
     own = engine is None
-    eng = engine or svtme.Engine(w, h, store_slots=n + 1, max_in_flight=2, serial_hme=serial_hme)
+    eng = engine or svtme.Engine(w, h, store_slots=n + 1, max_in_flight=max(2, batch), serial_hme=serial_hme)
     try:
         for i in range(n):
             eng.store_put(i, i, frames[i])
         set_uniform_tiles(eng, w, h, tiles)
         ctrl = svtme.derive_controls(enc_mode, w, h, sc_class1, frame_rate)
         outs = []
-        for p in pics:
-            pic = eng.make_picture(w, h, p.poc, p.temporal_layer, p.is_ref, p.refs, ctrl, tail=tail,
-                                   restricted_motion_vector=restricted, number_of=lambda poc: poc * number_scale)
+        descs = [eng.make_picture(w, h, p.poc, p.temporal_layer, p.is_ref, p.refs, ctrl, tail=tail,
+                                  restricted_motion_vector=restricted, number_of=lambda poc: poc * number_scale) for p in pics]
+        if batch > 1:
+            for i in range(0, len(descs), batch):
+                tickets = eng.submit_batch(descs[i:i + batch]) if len(descs[i:i + batch]) > 1 else [eng.submit(descs[i])]
+                for t in tickets:
+                    outs.append(eng.wait(t))
+                    eng.done(t)
+            return outs
+        for pic in descs:
             outs.append(eng.run_picture(pic))
         return outs
     finally:

@@ -271,18 +271,26 @@ def test_scheduler_runs_a_sequence_on_the_engine_with_store_reuse():
     assert not msgs, "\n".join(msgs[:10])
 
 
+# the batch sizes the benchmark submits these shapes with (bench.py WORKLOADS): their launch shapes - pictures as a grid
+# dimension, parameter records read from device memory, 16-row work items at the fast presets - differ from a single picture's
+BENCH_BATCH = {"m3_ra_1920x1080": 8, "m8_ra_3840x2160": 8, "m2_ra_7680x4320": 2, "m12_ldp_1280x720": 16, "m8_ra_1920x1080": 16,
+               "m3_ra_640x360": 8}
+
+
+@pytest.mark.parametrize("batch", [1, 0])
 @pytest.mark.parametrize("name", sorted(MOD.DIGEST_CASES) + sorted(MOD.BIG_DIGEST_CASES))
-def test_engine_matches_reference_digests_at_full_size(name):
+def test_engine_matches_reference_digests_at_full_size(name, batch):
     """1080p preset 8 and preset 3 (the benchmark's headline shape) / 720p preset 12 / 360p preset 3 / 4K preset 8 from
     10-bit input / 8K preset 2: sha256 of the engine's masked best
-    SAD / MV arrays and search centres against digests of the real reference's output (tests/golden/digests.json)."""
+    SAD / MV arrays and search centres against digests of the real reference's output (tests/golden/digests.json).
+    batch 1: pictures submitted singly; batch 0: in the benchmark's batches (BENCH_BATCH) through svtme_pictures_submit."""
     with open(os.path.join(GOLDEN, "digests.json")) as f:
         dig = json.load(f)["digests"][name]
     c = MOD.DIGEST_CASES.get(name) or MOD.BIG_DIGEST_CASES[name]
     frames, pics, _ = support.make_job(c["width"], c["height"], c["n_frames"], c["enc_mode"], c["seed"], c["structure"],
                                        motion=c.get("motion", (3, -2)), bit_depth=c.get("bit_depth", 8))
     assert hashlib.sha256(frames.tobytes()).hexdigest() == dig["frames_sha256"]
-    outs = support.run_engine_job(frames, pics, c["enc_mode"])
+    outs = support.run_engine_job(frames, pics, c["enc_mode"], batch=batch or BENCH_BATCH[name])
     for i, (p, out) in enumerate(zip(pics, outs)):
         sr = out["search_results"]
         n_ref = [len(p.refs[0]), len(p.refs[1])]
