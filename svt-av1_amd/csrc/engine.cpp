@@ -656,6 +656,7 @@ static int fill_params(svtme_engine *e, const svtme_picture *pic, PicParams &p, 
     p.height = (int32_t)pic->height;
     p.b64_w  = (int32_t)((pic->width + 63) / 64);
     p.b64_h  = (int32_t)((pic->height + 63) / 64);
+    p.b64_w_magic = (uint32_t)((0x100000000ull + (uint32_t)p.b64_w - 1) / (uint32_t)p.b64_w);
     p.temporal_layer = pic->temporal_layer_index;
     p.is_ref = pic->is_used_as_reference_flag;
     p.me_type       = pic->me_type ? pic->me_type : SVTME_ME_OPEN_LOOP;

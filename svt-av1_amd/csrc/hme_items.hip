@@ -18,7 +18,7 @@
 //                  then searches level 1 around the level-0 vector and level 2 around the level-1 vector. Few positions
 //                  (8x3) of a large block (32x32, 64x64): the block's rows are split over 8 lanes per position quad.
 //
-// The argmin is exact under the reference's rule (strict '<' in raster order): 64-bit keys (SAD << 32 | raster index).
+// The argmin is exact under the reference's rule (strict '<' in raster order): 64-bit keys (SAD << 32 | y << 16 | x).
 //
 // Both kernels exist in two forms: SUB_SAD_SEARCH (every other block row, SAD x2: every preset of the pre-analysis ME)
 // and FULL_SAD_SEARCH (all block rows: the temporal filter's searches, EbTemporalFiltering.c:331). The template
@@ -31,7 +31,7 @@ namespace svtme {
 
 constexpr int HI_THREADS   = 64;
 constexpr int HI_WIN_BYTES = 12288; // LDS budget of one staged reference window
-constexpr int HI_XCHUNK    = 96; // search positions per staged column chunk (level 0 / pre-HME)
+constexpr int HI_XCHUNK    = 96; // search positions per staged column chunk (level 0 / pre-HME); 128 for windows wider than that
 constexpr int HI_WIN2_BYTES = 6144; // levels 1 and 2
 constexpr int HI_WIN2_BYTES_FS = 8192; // the same with FULL_SAD_SEARCH: 16 + 63 rows of the 64x64 block's 16x16 window
 constexpr int HI_THREADS_FS = 64; // threads of a level-1/2 work item with FULL_SAD_SEARCH
@@ -82,23 +82,28 @@ __device__ void l0_area(const P &p, const HmeRefOut &first, int l, int r, int16_
         }
         int x_off = is_hor ? 1 : 2, y_off = is_ver ? 1 : 2;
         if (k.enable_me_sr_adjustment == 2 && is_still) x_off = y_off = 4;
-        sa.sa_min.width  = (uint16_t)(sa.sa_min.width / (x_off + r));
-        sa.sa_min.height = (uint16_t)(sa.sa_min.height / (y_off + r));
-        sa.sa_max.width  = (uint16_t)(sa.sa_max.width / (x_off + r));
-        sa.sa_max.height = (uint16_t)(sa.sa_max.height / (y_off + r));
+        // (divisors 1..7: through the table of magic numbers; operands below 2^16)
+        const uint32_t dx = (uint32_t)(x_off + r), dy = (uint32_t)(y_off + r), mx = div_magic(dx), my = div_magic(dy);
+        sa.sa_min.width  = (uint16_t)magic_div(sa.sa_min.width, dx, mx);
+        sa.sa_min.height = (uint16_t)magic_div(sa.sa_min.height, dy, my);
+        sa.sa_max.width  = (uint16_t)magic_div(sa.sa_max.width, dx, mx);
+        sa.sa_max.height = (uint16_t)magic_div(sa.sa_max.height, dy, my);
     }
     const int factor = scaled_dist(p.dist[l][r]);
-    int16_t   w      = (int16_t)(sa.sa_min.width / k.num_hme_sa_w);
-    w = (int16_t)min(((w * factor) + 15) & ~0x0F, ((sa.sa_max.width / k.num_hme_sa_w) + 15) & ~0x0F);
-    int16_t h = (int16_t)(sa.sa_min.height / k.num_hme_sa_h);
-    h         = (int16_t)min(h * factor, sa.sa_max.height / k.num_hme_sa_h);
+    // the number of regions per direction is 1 or 2: the divisions are shifts
+    const int shw = k.num_hme_sa_w - 1, shh = k.num_hme_sa_h - 1;
+    int16_t   w   = (int16_t)(sa.sa_min.width >> shw);
+    w = (int16_t)min(((w * factor) + 15) & ~0x0F, ((sa.sa_max.width >> shw) + 15) & ~0x0F);
+    int16_t h = (int16_t)(sa.sa_min.height >> shh);
+    h         = (int16_t)min(h * factor, sa.sa_max.height >> shh);
     sa_w      = w;
     sa_h      = h;
 }
 
 // What the callers of svt_sad_loop_kernel make of its outputs: SAD x2 (rows were subsampled), position + window
 // origin, times the level's scale (:938-944, :1040-1046, :1133-1137, :1710-1716).
-__device__ __forceinline__ void decode_key(u64 key, int sa_w, int org_x, int org_y, int scale, int16_t &mx, int16_t &my, uint32_t &sad,
+// The low half of a key is y << 16 | x, the position inside the window: keys order like the reference's raster scan.
+__device__ __forceinline__ void decode_key(u64 key, int org_x, int org_y, int scale, int16_t &mx, int16_t &my, uint32_t &sad,
                                            bool sub_sad = true) {
     if (key == ~0ull) { // no position evaluated: svt_sad_loop_kernel leaves 0xffffff and does not touch x / y
         sad = sub_sad ? 0xffffffu * 2 : 0xffffffu;
@@ -106,8 +111,7 @@ __device__ __forceinline__ void decode_key(u64 key, int sa_w, int org_x, int org
         my  = (int16_t)(org_y * scale);
         return;
     }
-    const int idx = (int)(uint32_t)key;
-    const int y = idx / sa_w, x = idx - y * sa_w;
+    const int y = (int)((uint32_t)key >> 16), x = (int)((uint32_t)key & 0xFFFFu);
     sad = (uint32_t)(key >> 32) * (sub_sad ? 2 : 1);
     mx  = (int16_t)((int16_t)(x + org_x) * scale);
     my  = (int16_t)((int16_t)(y + org_y) * scale);
@@ -209,13 +213,13 @@ __device__ __forceinline__ void strip_units(const uint32_t *win, int pd, int n_x
         // raster order: row first, then column
         u64        ubest  = ~0ull;
         const bool second = PAIR && x_abs0 + xg * 4 >= w_reg;
-        const int  pitch = PAIR ? w_reg : sa_w, xo = second ? w_reg : 0;
+        const int  xo = second ? w_reg : 0;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const int x = x_abs0 + xg * 4 + i;
             if (col[i] != ~0u && x < sa_w) {
                 const int y = y_abs0 + yfirst + STEP * (int)(col[i] & 15);
-                const u64 k = ((u64)(col[i] >> 4) << 32) | (uint32_t)(y * pitch + x - xo);
+                const u64 k = ((u64)(col[i] >> 4) << 32) | ((uint32_t)y << 16) | (uint32_t)(x - xo);
                 ubest       = k < ubest ? k : ubest;
             }
         }
@@ -225,10 +229,10 @@ __device__ __forceinline__ void strip_units(const uint32_t *win, int pd, int n_x
 }
 
 // Exhaustive search of the (bw x rows sampled rows, STEP = FS ? 1 : 2 plane rows apart) block of `cur` at (ox, oy) over
-// the sa_w x sa_h window of `ref` whose first position is plane pixel (wx, wy). Returns min (SAD << 32 | y * sa_w + x),
+// the sa_w x sa_h window of `ref` whose first position is plane pixel (wx, wy). Returns min (SAD << 32 | y << 16 | x),
 // ~0 when no position was evaluated (skip_even with a single row). Whole wave. skip_even needs FS == false.
 // PAIR (bw == 16 only): the window is two regions of w_reg = sa_w / 2 columns side by side; returns the left region's
-// minimum and leaves the right one's in key1, both with positions counted inside the region (y * w_reg + x).
+// minimum and leaves the right one's in key1, both with positions counted inside the region.
 template <bool FS, bool PAIR = false>
 __device__ __forceinline__ u64 l0_search(uint32_t *win, int zero, const DevPlane &cur, const DevPlane &ref, int ox, int oy, int bw,
                                          int rows, int wx, int wy, int sa_w, int sa_h, bool skip_even, int w_reg, u64 &key1) {
@@ -241,7 +245,7 @@ __device__ __forceinline__ u64 l0_search(uint32_t *win, int zero, const DevPlane
         for (int i = lane; i < sa_w * sa_h; i += HI_THREADS) {
             const int y = i / sa_w, x = i - y * sa_w;
             if (skip_even && (y & 1) == 0) continue;
-            const u64 k = ((u64)slow_sad(cur, ref, ox, oy, wx + x, wy + y, bw, rows, STEP) << 32) | (uint32_t)i;
+            const u64 k = ((u64)slow_sad(cur, ref, ox, oy, wx + x, wy + y, bw, rows, STEP) << 32) | ((uint32_t)y << 16) | (uint32_t)x;
             best        = k < best ? k : best;
         }
     } else {
@@ -257,8 +261,11 @@ __device__ __forceinline__ u64 l0_search(uint32_t *win, int zero, const DevPlane
                 for (int j = 0; j < 4; ++j) src[m][j] = row[j];
             }
         }
-        for (int x0 = 0; x0 < sa_w; x0 += HI_XCHUNK) {
-            const int n_xg = (min(HI_XCHUNK, sa_w - x0) + 3) >> 2;
+        // column chunks: a window of up to 96 positions in one piece; wider ones in chunks of 128 positions, whose 32
+        // position quads x 2 row parities give each of the 64 lanes a unit per group of rows, whatever the rows per unit
+        const int xchunk = sa_w > HI_XCHUNK ? 128 : HI_XCHUNK;
+        for (int x0 = 0; x0 < sa_w; x0 += xchunk) {
+            const int n_xg = (min(xchunk, sa_w - x0) + 3) >> 2;
             const int pd   = (n_xg + 4 + 3) & ~3; // dwords per staged row: the positions + 15 more pixels, in 16-byte pieces
             // rows the LDS budget holds: a band's search rows + the (NR - 1) STEP rows under the last one + the staggered
             // walk's overrun (rows that are addressed but never used)
@@ -270,9 +277,23 @@ __device__ __forceinline__ u64 l0_search(uint32_t *win, int zero, const DevPlane
             band           = band >= 16 ? band & ~15 : max(band, 1);
             for (int y0 = 0; y0 < sa_h; y0 += band) {
                 const int brows = min(band, sa_h - y0);
-                // rows per unit: as many as still give every lane a unit
-                const int cells = n_xg * ((brows + STEP - 1) / STEP); // position quads x rows of one walk direction
-                const int t = brows > 8 && cells >= 8 * HI_THREADS ? 8 : (brows > 4 && cells >= 4 * HI_THREADS ? 4 : 2);
+                // rows per unit (8, 4 or 2): the choice that costs the wave the fewest cycles - trips of 64 units, each
+                // 16 QSADs per source row and search row (16 cycles apiece) and some 230 + 36 T cycles of bookkeeping
+                int t = 2;
+                {
+                    const int npar = (skip_even || STEP == 1) ? 1 : 2;
+                    int       best_cost = 0x7FFFFFFF;
+#pragma unroll
+                    for (int tt = 8; tt >= 2; tt >>= 1) {
+                        const int n_yg = (brows + STEP * tt - 1) / (STEP * tt); // (a shift: STEP * tt is a constant power of two)
+                        const int trips = (n_xg * n_yg * npar + HI_THREADS - 1) / HI_THREADS;
+                        const int cost = trips * (NR * 64 * tt + 230 + 36 * tt);
+                        if (cost < best_cost) {
+                            best_cost = cost;
+                            t         = tt;
+                        }
+                    }
+                }
                 wave_sync();
                 stage_window<5>(win, ref.pix + (ptrdiff_t)(wy + y0) * ref.stride + wx + x0, ref.stride, pd, brows + under,
                                 (STEP == 2 ? 1 : 0) + (t == 8 ? 3 : (t == 4 ? 2 : 1)));
@@ -298,11 +319,12 @@ __device__ __forceinline__ u64 l0_search(uint32_t *win, int zero, const DevPlane
 // :1720-1742: the 64x64 block on every other row, x2), once instead of in each of the six level-0 / pre-HME items that
 // test it; also the per-reference header fields. One wave per (b64, reference).
 template <class PICS>
-__global__ void __launch_bounds__(HI_THREADS) hme_zz_kernel(PICS pp, int n_b64) {
-    const auto &p   = pp[blockIdx.x / n_b64];
-    const int   b64 = blockIdx.x % n_b64;
+__global__ void __launch_bounds__(HI_THREADS) hme_zz_kernel(PICS pp) {
+    const auto &p   = pp[blockIdx.z];
+    const int   b64 = blockIdx.x;
     if (b64_left_out(p, b64)) return;
-    const int b64x = (b64 % p.b64_w) * 64, b64y = (b64 / p.b64_w) * 64;
+    int b64x, b64y;
+    b64_origin(p, b64, b64x, b64y);
     const int block_w = min(p.width - b64x, 64), block_h = min(p.height - b64y, 64);
     int       l = 0, r = (int)blockIdx.y;
     if (r >= p.n_ref[0] + (p.n_list == 2 ? p.n_ref[1] : 0)) return; // the grid covers the batch's longest reference list
@@ -409,8 +431,8 @@ __device__ __forceinline__ void l0_item(const P &p, uint32_t *win, int b64x, int
                     const u64 k0 = l0_search<FS, true>(win, p.zero, cur, ref, ox, oy, bw, rows, ox + rx[0], oy + ry[2 * sh], 2 * rw[0], rh[0], false,
                                                        rw[0], k1);
                     if (lane == 0) {
-                        decode_key(k0, rw[0], rx[0], ry[2 * sh], 4, rec->raw_x[sh], rec->raw_y[sh], rec->raw_sad[sh], !FS);
-                        decode_key(k1, rw[0], rx[1], ry[2 * sh], 4, rec->raw_x[2 + sh], rec->raw_y[2 + sh], rec->raw_sad[2 + sh], !FS);
+                        decode_key(k0, rx[0], ry[2 * sh], 4, rec->raw_x[sh], rec->raw_y[sh], rec->raw_sad[sh], !FS);
+                        decode_key(k1, rx[1], ry[2 * sh], 4, rec->raw_x[2 + sh], rec->raw_y[2 + sh], rec->raw_sad[2 + sh], !FS);
                     }
                 }
             } else {
@@ -418,7 +440,7 @@ __device__ __forceinline__ void l0_item(const P &p, uint32_t *win, int b64x, int
                     u64       none;
                     const int i   = (q_ % nw) * 2 + q_ / nw;
                     const u64 key = l0_search<FS>(win, p.zero, cur, ref, ox, oy, bw, rows, ox + rx[q_], oy + ry[q_], rw[q_], rh[q_], false, 0, none);
-                    if (lane == 0) decode_key(key, rw[q_], rx[q_], ry[q_], 4, rec->raw_x[i], rec->raw_y[i], rec->raw_sad[i], !FS);
+                    if (lane == 0) decode_key(key, rx[q_], ry[q_], 4, rec->raw_x[i], rec->raw_y[i], rec->raw_sad[i], !FS);
                 }
             }
             return;
@@ -433,21 +455,25 @@ __device__ __forceinline__ void l0_item(const P &p, uint32_t *win, int b64x, int
     if (lane == 0) count_ops(p, ops_k, (unsigned long long)max(skip ? h >> 1 : (int)h, 0) * max((int)w, 0) * rows * bw);
     u64       none;
     const u64 key = l0_search<FS>(win, p.zero, cur, ref, ox, oy, bw, rows, ox + org_x, oy + org_y, w, h, skip, 0, none);
-    if (lane == 0) decode_key(key, w, org_x, org_y, 4, *res_x, *res_y, *res_sad, !FS);
+    if (lane == 0) decode_key(key, org_x, org_y, 4, *res_x, *res_y, *res_sad, !FS);
 }
 
 template <bool FS, class PICS>
-__global__ void __launch_bounds__(HI_THREADS, 3) hme_l0_kernel(PICS pp, int n_b64, int hme_phase, int all_regions) {
+__global__ void __launch_bounds__(HI_THREADS, 3) hme_l0_kernel(PICS pp, int grid_refs, uint32_t grid_refs_magic, int hme_phase, int all_regions) {
     __shared__ __align__(16) uint32_t win[HI_WIN_BYTES / 4 + 64];
-    const auto &p   = pp[blockIdx.x / n_b64];
+    // grid: x = 64x64 block, y = search of the reference, z = (picture, reference): the work items of one picture are
+    // dispatched together; the picture's index by a multiplication (grid_refs_magic = ceil(2^32 / grid_refs))
+    const int   pic_i = grid_refs == 1 ? (int)blockIdx.z : (int)__umulhi(blockIdx.z, grid_refs_magic);
+    const auto &p   = pp[pic_i];
     const auto &k   = p.ctrl;
-    const int   b64 = blockIdx.x % n_b64;
+    const int   b64 = blockIdx.x;
     if (b64_left_out(p, b64)) return;
-    const int             b64x = (b64 % p.b64_w) * 64, b64y = (b64 / p.b64_w) * 64;
+    int                   b64x, b64y;
+    b64_origin(p, b64, b64x, b64y);
     const int             block_w = min(p.width - b64x, 64), block_h = min(p.height - b64y, 64);
     // references in reverse order: the closest references (smallest areas, cheapest items) are dispatched last and keep
     // the kernel's tail short (the grid covers the batch's longest reference list)
-    int                   l = 0, r = p.n_ref[0] + (p.n_list == 2 ? p.n_ref[1] : 0) - 1 - (int)blockIdx.z;
+    int                   l = 0, r = p.n_ref[0] + (p.n_list == 2 ? p.n_ref[1] : 0) - 1 - ((int)blockIdx.z - pic_i * grid_refs);
     if (r < 0) return;
     if (r >= p.n_ref[0]) {
         r -= p.n_ref[0];
@@ -596,7 +622,7 @@ __device__ u64 small_search(const uint32_t *src, uint32_t *win, const DevPlane &
                     for (int i = 0; i < 4; ++i) {
                         const int x = x0 + xg * 4 + i;
                         if (x < sa_w) {
-                            const u64 kk = ((u64)a32[i] << 32) | (uint32_t)((y0 + yl) * sa_w + x);
+                            const u64 kk = ((u64)a32[i] << 32) | ((uint32_t)(y0 + yl) << 16) | (uint32_t)x;
                             best         = kk < best ? kk : best;
                         }
                     }
@@ -688,7 +714,7 @@ __device__ u64 strip_search_fs(const uint32_t *src, uint32_t *win, int zero, con
             if constexpr (NSTRIP == 4) v += quad_xor2(v);
             const int x = xg * 4 + i, y = yfirst + t;
             if (valid && strip == 0 && x < sa_w && y < sa_h) {
-                const u64 kk = ((u64)v << 32) | (uint32_t)(y * sa_w + x);
+                const u64 kk = ((u64)v << 32) | ((uint32_t)y << 16) | (uint32_t)x;
                 best         = kk < best ? kk : best;
             }
         }
@@ -788,7 +814,7 @@ __device__ __forceinline__ u64 quick_scan(const uint32_t *src, const uint32_t *w
         if (active && chunk == 0) {
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
-                const u64 kk = ((u64)a32[i] << 32) | (uint32_t)(yl * 8 + xg * 4 + i);
+                const u64 kk = ((u64)a32[i] << 32) | ((uint32_t)yl << 16) | (uint32_t)(xg * 4 + i);
                 best         = kk < best ? kk : best;
             }
         }
@@ -866,7 +892,7 @@ __device__ u64 quick_search(const uint32_t *src, uint32_t *win, const DevPlane &
         if (active && chunk == 0) {
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
-                const u64 kk = ((u64)a32[i] << 32) | (uint32_t)(yl * 8 + xg * 4 + i);
+                const u64 kk = ((u64)a32[i] << 32) | ((uint32_t)yl << 16) | (uint32_t)(xg * 4 + i);
                 best         = kk < best ? kk : best;
             }
         }
@@ -960,7 +986,7 @@ __device__ __forceinline__ void l12_region(const P &p, const uint32_t *src1, con
                 key = small_search<FS>(src, win, ref, bw, rows, ox + org_x, oy + org_y, w, h);
         }
         uint32_t  sad;
-        decode_key(key, w, org_x, org_y, level == 1 ? 2 : 1, cx, cy, sad, !FS);
+        decode_key(key, org_x, org_y, level == 1 ? 2 : 1, cx, cy, sad, !FS);
         if (lane == 0) {
             rec->lx[level][i]   = cx;
             rec->ly[level][i]   = cy;
@@ -994,7 +1020,8 @@ __global__ void __launch_bounds__(FS ? HI_THREADS_FS : HI_THREADS) hme_l12_kerne
     const int             n_refs = p.n_ref[0] + (p.n_list == 2 ? p.n_ref[1] : 0);
     int                   b64, item;
     if (!b64_band_item(blockIdx.x, p.b64_w * p.b64_h, n_refs * nw * nh, b64, item) || b64_left_out(p, b64)) return;
-    const int             b64x = (b64 % p.b64_w) * 64, b64y = (b64 / p.b64_w) * 64;
+    int                   b64x, b64y;
+    b64_origin(p, b64, b64x, b64y);
     const int             block_w = min(p.width - b64x, 64), block_h = min(p.height - b64y, 64);
     int                   l = 0, r = item / (nw * nh);
     const int             q = item - r * (nw * nh);
@@ -1019,15 +1046,16 @@ static void launch_hme_items_as(const Batch &b, PICS pics, hipStream_t s, hipEve
     // of a reference, the two of a row as one window; large ones keep a work item per region (shorter items, shorter tail).
     static const int all_env = getenv("SVTME_L0_ALL_REGIONS") ? atoi(getenv("SVTME_L0_ALL_REGIONS")) : -1; // diagnostic override
     const bool all_regions = !fs && n_reg == 4 && (all_env >= 0 ? all_env != 0 : p0.ctrl.hme_l0_sa.sa_min.width <= 16);
-    const dim3 g0(n_b64 * b.n, all_regions ? 3 : 2 + max(n_reg, 1), n_refs), g12((n_b64 + 7) / 8 * 8 * n_refs * n_reg, b.n);
+    const dim3 g0(n_b64, all_regions ? 3 : 2 + max(n_reg, 1), n_refs * b.n), g12((n_b64 + 7) / 8 * 8 * n_refs * n_reg, b.n);
+    const uint32_t refs_magic = (uint32_t)((0x100000000ull + (uint32_t)n_refs - 1) / (uint32_t)n_refs);
     bool       deps = false;
     for (int i = 0; i < b.n; ++i) deps = deps || b.host[i].dep_pre || b.host[i].dep_l0;
     const int n_phase = deps ? 2 : 1;
-    if (p0.ctrl.me_early_exit_th) hipLaunchKernelGGL(hme_zz_kernel<PICS>, dim3(n_b64 * b.n, n_refs), dim3(HI_THREADS), 0, s, pics, n_b64);
+    if (p0.ctrl.me_early_exit_th) hipLaunchKernelGGL(hme_zz_kernel<PICS>, dim3(n_b64, n_refs, b.n), dim3(HI_THREADS), 0, s, pics);
     for (int phase = 1; phase <= n_phase; ++phase) {
         const int hme_phase = n_phase == 1 ? 0 : phase;
-        if (fs) hipLaunchKernelGGL((hme_l0_kernel<true, PICS>), g0, dim3(HI_THREADS), 0, s, pics, n_b64, hme_phase, 0);
-        else hipLaunchKernelGGL((hme_l0_kernel<false, PICS>), g0, dim3(HI_THREADS), 0, s, pics, n_b64, hme_phase, all_regions ? 1 : 0);
+        if (fs) hipLaunchKernelGGL((hme_l0_kernel<true, PICS>), g0, dim3(HI_THREADS), 0, s, pics, n_refs, refs_magic, hme_phase, 0);
+        else hipLaunchKernelGGL((hme_l0_kernel<false, PICS>), g0, dim3(HI_THREADS), 0, s, pics, n_refs, refs_magic, hme_phase, all_regions ? 1 : 0);
     }
     if (marks[0]) (void)hipEventRecord(marks[0], s);
     if (p0.ctrl.enable_hme_flag) {
@@ -1164,7 +1192,7 @@ __device__ __forceinline__ void l12_regions(const P &p, const uint32_t *src1, co
         for (int q = 0; q < 4; ++q) {
             const int i = (q & 1) * 2 + (q >> 1);
             uint32_t  sad;
-            decode_key(key[q], ww[q], orgx[q], orgy[q], level == 1 ? 2 : 1, cx[q], cy[q], sad, true);
+            decode_key(key[q], orgx[q], orgy[q], level == 1 ? 2 : 1, cx[q], cy[q], sad, true);
             if (lane == 0) {
                 rec->lx[level][i]   = cx[q];
                 rec->ly[level][i]   = cy[q];
@@ -1187,7 +1215,8 @@ __global__ void __launch_bounds__(HI_THREADS) hme_l12_regions_kernel(PICS pp) {
     const int   n_refs = p.n_ref[0] + (p.n_list == 2 ? p.n_ref[1] : 0);
     int         b64, item;
     if (!b64_band_item(blockIdx.x, p.b64_w * p.b64_h, n_refs, b64, item) || b64_left_out(p, b64)) return;
-    const int b64x = (b64 % p.b64_w) * 64, b64y = (b64 / p.b64_w) * 64;
+    int       b64x, b64y;
+    b64_origin(p, b64, b64x, b64y);
     const int block_w = min(p.width - b64x, 64), block_h = min(p.height - b64y, 64);
     int       l = 0, r = item;
     if (r >= p.n_ref[0]) {

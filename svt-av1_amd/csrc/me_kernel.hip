@@ -82,13 +82,14 @@ __device__ __forceinline__ uint32_t row_quads_min(uint32_t v) {
 __device__ __forceinline__ int me_item_count(int w, int h, int item_rows) { return ((w + ME_TILE - 1) / ME_TILE) * ((h + item_rows - 1) / item_rows); }
 
 template <class PICS>
-__global__ void __launch_bounds__(ME_THREADS) me_plan_kernel(PICS pp, int n_b64, int me_ref0) {
+__global__ void __launch_bounds__(ME_THREADS) me_plan_kernel(PICS pp, int me_ref0) {
     __shared__ MeShared S;
-    const auto &p   = pp[blockIdx.x / n_b64];
+    const auto &p   = pp[blockIdx.z]; // grid: x = 64x64 block, y = reference, z = picture
     const auto &k   = p.ctrl;
     const int             tid = threadIdx.x;
-    const int             b64 = blockIdx.x % n_b64;
-    const int             b64x = (b64 % p.b64_w) * 64, b64y = (b64 / p.b64_w) * 64;
+    const int             b64 = blockIdx.x;
+    int                   b64x, b64y;
+    b64_origin(p, b64, b64x, b64y);
     const int             block_w = min(p.width - b64x, 64), block_h = min(p.height - b64y, 64);
 
     // me_ref0: first reference (list-0 references first, then list 1) this launch covers; the grid covers the batch's
@@ -307,20 +308,23 @@ __global__ void __launch_bounds__(ME_THREADS) me_plan_kernel(PICS pp, int n_b64,
 }
 
 template <class PICS, bool TALL>
-__global__ void __launch_bounds__(ME_THREADS, 2) me_search_kernel(PICS pp, int grid_refs, int ref_first, int ref_last) {
+__global__ void __launch_bounds__(ME_THREADS, 2) me_search_kernel(PICS pp, int grid_refs, uint32_t grid_refs_magic, int ref_first, int ref_last) {
     constexpr int ITEM_ROWS = TALL ? 16 : 8, ROW_BITS = TALL ? 4 : 3; // keys carry the row within the item
     __shared__ MeShared               S;
     __shared__ __align__(16) uint32_t win[ME_WIN_BYTES / 4];
     // the grid's slowest dimension is (picture, reference): the work items of one picture are dispatched together, so that
     // the workgroups in flight read a picture or two's planes rather than the whole batch's (what L2 holds)
-    const auto &p = pp[blockIdx.z / grid_refs];
+    // (the picture's index by a multiplication: grid_refs_magic = ceil(2^32 / grid_refs))
+    const int   pic_i = grid_refs == 1 ? (int)blockIdx.z : (int)__umulhi(blockIdx.z, grid_refs_magic);
+    const auto &p = pp[pic_i];
     const int tid = threadIdx.x;
     const int b64 = blockIdx.x;
-    const int b64x = (b64 % p.b64_w) * 64, b64y = (b64 / p.b64_w) * 64;
+    int       b64x, b64y;
+    b64_origin(p, b64, b64x, b64y);
     // references in reverse order: the closest references (smallest windows, cheapest items) are dispatched last and
     // keep the kernel's tail short. The grid covers the batch's longest reference list; the launch covers references
     // ref_first .. ref_last (list-0 references first, then list 1).
-    int       my_l = 0, my_r = p.n_ref[0] + (p.n_list == 2 ? p.n_ref[1] : 0) - 1 - (int)(blockIdx.z % grid_refs);
+    int       my_l = 0, my_r = p.n_ref[0] + (p.n_list == 2 ? p.n_ref[1] : 0) - 1 - ((int)blockIdx.z - pic_i * grid_refs);
     if (my_r < ref_first || my_r > ref_last) return;
     if (my_r >= p.n_ref[0]) {
         my_r -= p.n_ref[0];
@@ -668,16 +672,17 @@ static void launch_me_as(const Batch &b, PICS pics, hipStream_t s, hipEvent_t ma
     int        me_ref0 = 0;
     auto       search = [&](int ref_first, int ref_last) {
         const dim3 grid(n_b64, p.me_max_items, n_refs * b.n);
-        if (p.me_tall) hipLaunchKernelGGL((me_search_kernel<PICS, true>), grid, dim3(ME_THREADS), 0, s, pics, n_refs, ref_first, ref_last);
-        else hipLaunchKernelGGL((me_search_kernel<PICS, false>), grid, dim3(ME_THREADS), 0, s, pics, n_refs, ref_first, ref_last);
+        const uint32_t refs_magic = (uint32_t)((0x100000000ull + (uint32_t)n_refs - 1) / (uint32_t)n_refs);
+        if (p.me_tall) hipLaunchKernelGGL((me_search_kernel<PICS, true>), grid, dim3(ME_THREADS), 0, s, pics, n_refs, refs_magic, ref_first, ref_last);
+        else hipLaunchKernelGGL((me_search_kernel<PICS, false>), grid, dim3(ME_THREADS), 0, s, pics, n_refs, refs_magic, ref_first, ref_last);
     };
     if (two_phase) {
-        hipLaunchKernelGGL(me_plan_kernel<PICS>, dim3(n_b64 * b.n, 1), dim3(ME_THREADS), 0, s, pics, n_b64, 0);
+        hipLaunchKernelGGL(me_plan_kernel<PICS>, dim3(n_b64, 1, b.n), dim3(ME_THREADS), 0, s, pics, 0);
         search(0, 0);
         me_ref0 = 1;
     }
     const int n_now = n_refs - me_ref0;
-    hipLaunchKernelGGL(me_plan_kernel<PICS>, dim3(n_b64 * b.n, n_now), dim3(ME_THREADS), 0, s, pics, n_b64, me_ref0);
+    hipLaunchKernelGGL(me_plan_kernel<PICS>, dim3(n_b64, n_now, b.n), dim3(ME_THREADS), 0, s, pics, me_ref0);
     if (marks[0]) (void)hipEventRecord(marks[0], s);
     search(me_ref0, 1 << 30);
     if (marks[1]) (void)hipEventRecord(marks[1], s);

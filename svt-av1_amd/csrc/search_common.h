@@ -26,6 +26,15 @@ __device__ __forceinline__ int scaled_dist(int dist) { return (uint16_t)(((dist 
 template <class P>
 __device__ __forceinline__ bool ref_searched(const P &p, int l) { return p.temporal_layer > 0 || l == 0; }
 
+// Pixel origin of 64x64 block `b64` of the picture: the block row through the picture's magic number (one scalar multiply
+// instead of a division by a number only known at run time).
+template <class P>
+__device__ __forceinline__ void b64_origin(const P &p, int b64, int &b64x, int &b64y) {
+    const int by = p.b64_w == 1 ? b64 : (int)__umulhi((uint32_t)b64, p.b64_w_magic);
+    b64x = (b64 - by * p.b64_w) * 64;
+    b64y = by * 64;
+}
+
 // The per-axis window correction all stages share (:875-907, :976-1009, :1077-1105, :1441-1460, :1502-1520,
 // :1638-1682): a window starting below `lo` is shifted, not shrunk (the size correction is computed from the
 // already corrected origin and is therefore zero); at the far side the origin is clamped to dim-1 and the size cut
@@ -116,29 +125,34 @@ __device__ __forceinline__ uint32_t div_magic(uint32_t d) {
 __device__ __forceinline__ uint32_t magic_div(uint32_t i, uint32_t d, uint32_t magic) { return d == 1 ? i : __umulhi(i, magic); }
 
 // Copies an (n_row x pd dwords) window from a plane (any byte alignment) into LDS rows of pd dwords, whole 64-lane wave,
-// in 16-byte pieces (unaligned 16-byte loads); pd is a multiple of 4 and `win` 16-byte aligned. Piece i = lane + 64 k
-// goes to piece i of the window; indices past the end repeat the last piece (same value into the same slot), so
-// nothing branches. NB loads are in flight per lane before the first is stored: a window of up to 1 KiB x NB costs one
-// memory round trip. Reads pd * 4 bytes per row. NT > 64: the NT threads of the workgroup share the pieces.
+// in 16-byte pieces (unaligned 16-byte loads); pd is a multiple of 4 and `win` 16-byte aligned. A row's pieces go to
+// neighbouring lanes: 2^lg lanes per row (the power of two that holds the row's pd / 4 pieces; the lanes beyond them
+// idle), 64 >> lg rows per trip, so a lane keeps its piece column and walks down the rows: per piece a row number, its
+// clamp, and two 24-bit multiply-adds (no division, no 64-bit address arithmetic: a 32-bit offset from the uniform base).
+// Rows past the end repeat the last row (same value into the same slot), so nothing branches. NB loads are in flight per
+// lane before the first is stored. Reads pd * 4 bytes per row.
 // gap_shift: one empty 16-byte piece goes in front of every 2^gap_shift-th row (row r starts at dword
 // r * pd + 4 * (r >> gap_shift)), so that lanes which walk row groups 2^gap_shift rows apart do not all start in the same
 // bank when 2^gap_shift * pd is a multiple of 32 dwords; 31: none.
 template <int NB, int NT = 64>
 __device__ __forceinline__ void stage_window(uint32_t *win, const uint8_t *g, int stride, int pd, int n_row, int gap_shift = 31) {
-    const int      pr = pd >> 2, n = n_row * pr, lane = NT == 64 ? (threadIdx.x & 63) : (int)threadIdx.x;
-    const uint32_t magic = div_magic((uint32_t)pr);
+    static_assert(NT == 64, "one wave stages");
+    const int      pr = pd >> 2, lg = pr <= 2 ? 1 : (pr <= 4 ? 2 : (pr <= 8 ? 3 : (pr <= 16 ? 4 : 5)));
+    const int      lane = threadIdx.x & 63, c = lane & ((1 << lg) - 1), r0 = lane >> lg, per_trip = NT >> lg;
     uint4         *dst = reinterpret_cast<uint4 *>(win);
-    for (int base = lane; base < n; base += NT * NB) {
-        uint4    v[NB];
-        uint32_t at[NB];
+    if (c < pr) {
+        for (int base = r0; base < n_row; base += per_trip * NB) {
+            uint4    v[NB];
+            uint32_t at[NB];
 #pragma unroll
-        for (int k = 0; k < NB; ++k) {
-            const uint32_t i = (uint32_t)min(base + NT * k, n - 1), r = magic_div(i, (uint32_t)pr, magic), d = i - r * (uint32_t)pr;
-            __builtin_memcpy(&v[k], g + (ptrdiff_t)(int)r * stride + 16 * d, 16);
-            at[k] = i + (r >> gap_shift);
+            for (int k = 0; k < NB; ++k) {
+                const uint32_t r = (uint32_t)min(base + per_trip * k, n_row - 1);
+                __builtin_memcpy(&v[k], g + (uint32_t)(__umul24(r, (uint32_t)stride) + 16u * (uint32_t)c), 16);
+                at[k] = __umul24(r, (uint32_t)pr) + (uint32_t)c + (r >> gap_shift);
+            }
+#pragma unroll
+            for (int k = 0; k < NB; ++k) dst[at[k]] = v[k];
         }
-#pragma unroll
-        for (int k = 0; k < NB; ++k) dst[at[k]] = v[k];
     }
 }
 
@@ -148,13 +162,29 @@ __device__ __forceinline__ uint32_t wave_sum(uint32_t v) {
     return v;
 }
 
+// Minimum of a 64-bit key over the wave, the same value in every lane: DPP lane exchanges only (no LDS round trips). The
+// four exchanges inside a row of 16 lanes leave the row's minimum in each of its lanes; row_bcast:15 / row_bcast:31 carry
+// it on to the following rows, so that lane 63 holds the wave's, which every lane then reads.
 __device__ __forceinline__ u64 wave_min_u64(u64 v) {
-#pragma unroll
-    for (int m = 32; m >= 1; m >>= 1) {
-        const u64 o = __shfl_xor(v, m);
-        v = o < v ? o : v;
+    uint32_t lo = (uint32_t)v, hi = (uint32_t)(v >> 32);
+#define SVTME_MIN_STEP(CTRL, ROWS)                                                                          \
+    {                                                                                                       \
+        const uint32_t olo = (uint32_t)__builtin_amdgcn_update_dpp((int)lo, (int)lo, CTRL, ROWS, 0xF, false); \
+        const uint32_t ohi = (uint32_t)__builtin_amdgcn_update_dpp((int)hi, (int)hi, CTRL, ROWS, 0xF, false); \
+        const bool     lt  = ohi < hi || (ohi == hi && olo < lo);                                           \
+        lo = lt ? olo : lo;                                                                                 \
+        hi = lt ? ohi : hi;                                                                                 \
     }
-    return v;
+    SVTME_MIN_STEP(0xB1, 0xF) // quad_perm [1, 0, 3, 2]
+    SVTME_MIN_STEP(0x4E, 0xF) // quad_perm [2, 3, 0, 1]
+    SVTME_MIN_STEP(0x141, 0xF) // row_half_mirror
+    SVTME_MIN_STEP(0x140, 0xF) // row_mirror
+    SVTME_MIN_STEP(0x142, 0xA) // row_bcast:15 into rows 1 and 3
+    SVTME_MIN_STEP(0x143, 0xC) // row_bcast:31 into rows 2 and 3
+#undef SVTME_MIN_STEP
+    lo = (uint32_t)__builtin_amdgcn_readlane((int)lo, 63);
+    hi = (uint32_t)__builtin_amdgcn_readlane((int)hi, 63);
+    return ((u64)hi << 32) | lo;
 }
 
 // The same for a single wave and a block of at most 64 x 32 sampled rows, every other plane row (the zero-MV and

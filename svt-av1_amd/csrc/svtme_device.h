@@ -56,13 +56,14 @@ struct PicParams {
     svtme_controls ctrl;
     int32_t        width, height; // input_ptr->width/height == pcs->aligned_width/height
     int32_t        b64_w, b64_h;
+    uint32_t       b64_w_magic; // ceil(2^32 / b64_w): block row = (b64 * magic) >> 32 (b64_w > 1)
     int32_t        n_list;
     int32_t        n_ref[SVTME_MAX_LISTS];
     int32_t        temporal_layer;
     int32_t        is_ref;
     int32_t        serial_refs; // 1: one workgroup walks all references of a b64 in order (the serial HME kernel)
-    int32_t        dep_pre; // list-1 pre-HME searches read the list-0 results (check_prehme_early_exit :1759-1768)
-    int32_t        dep_l0; // the level-0 area of every reference but the first depends on the first one's vector (:1838-1850)
+    int16_t        dep_pre; // list-1 pre-HME searches read the list-0 results (check_prehme_early_exit :1759-1768)
+    int16_t        dep_l0; // the level-0 area of every reference but the first depends on the first one's vector (:1838-1850)
     int32_t        me_type; // SVTME_ME_OPEN_LOOP / SVTME_ME_MCTF / SVTME_ME_FIRST_PASS
     int16_t        bypass_zz_check; // first pass only
     int16_t        b64_step; // > 1: only the 64x64 blocks whose column and row index are multiples of it are searched
