@@ -382,7 +382,7 @@ def main():
             got = verify.engine_digest(outs, pics, verify.kind_of(wl), (w + 63) // 64, wl.get("b64_step", 0))
             verified = got == want["sha256"]
             verify_note = ("%d pictures of one more step (submitted %d at a time, as in the timed region): sha256 over their search "
-                           "centres, zero-MV SADs, divisors and best SAD / MV arrays %s the reference's (ref_me, AVX2 kernels)"
+                           "centres, zero-MV SADs, divisors and best SAD / MV arrays %s the reference's (oracle/_ref/ref_me)"
                            % (len(outs), args.batch, "equals" if verified else "DIFFERS FROM"))
     # kernels alone on the GPU: same pictures, one search stream (rank 0 reports them)
     solo = stats

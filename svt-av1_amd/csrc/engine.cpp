@@ -677,15 +677,13 @@ static int fill_params(svtme_engine *e, const svtme_picture *pic, PicParams &p, 
         k.reduce_hme_l0_sr_th_min && k.reduce_hme_l0_sr_th_max && p.n_ref[0] + p.n_ref[1] > 1;
     p.serial_refs = e->cfg.serial_hme != 0;
     {
-        // search work items per (b64, ref): 64-position column chunks x groups of 8 rows of the largest window the
-        // controls allow (integer_search_b64 :1319-1345 caps the window at sa_max, rounds the width up to 8 and keeps
-        // the height >= 3)
+        // search work items per (b64, ref): the most any window the controls allow can need (integer_search_b64
+        // :1319-1345 caps the window at sa_max, rounds the width up to 8 and keeps the height >= 3; clipping at the
+        // picture's edge may leave any multiple of 8 below that, or fewer than 8 columns)
         const int w_max = (std::max<int>(k.me_sa.sa_max.width, 1) + 7) & ~7, h_max = std::max<int>(k.me_sa.sa_max.height, 3);
-        // windows of at most 16 x 16 positions that are higher than 8 rows (preset 8's 16 x 9): one work item of 16 rows,
-        // whose spare lanes take rows 8.., instead of two of 8
-        p.me_tall       = w_max <= 16 && h_max > 8 && h_max <= 16 && getenv("SVTME_NO_TALL_ITEMS") == nullptr;
-        const int rows  = p.me_tall ? 16 : 8;
-        p.me_max_items  = ((w_max + 63) / 64) * ((h_max + rows - 1) / rows);
+        int       items = 1;
+        for (int w = 1; w <= w_max; w += (w < 8 ? 1 : 8)) items = std::max(items, me_item_count(w, h_max));
+        p.me_max_items = items;
     }
     return SVTME_OK;
 }

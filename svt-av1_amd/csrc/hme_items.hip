@@ -703,8 +703,9 @@ __device__ u64 strip_search_fs(const uint32_t *src, uint32_t *win, int zero, con
             }
         });
     });
-    // the strips of a position: adjacent lanes
-    u64 best = ~0ull;
+    // the strips of a position: adjacent lanes. A lane meets its positions in raster order (rows, then columns), so a
+    // strictly smaller sum is all that replaces its best one.
+    uint32_t bsad = ~0u, bpos = ~0u;
 #pragma unroll
     for (int t = 0; t < T; ++t) {
 #pragma unroll
@@ -713,12 +714,13 @@ __device__ u64 strip_search_fs(const uint32_t *src, uint32_t *win, int zero, con
             v += quad_xor1(v);
             if constexpr (NSTRIP == 4) v += quad_xor2(v);
             const int x = xg * 4 + i, y = yfirst + t;
-            if (valid && strip == 0 && x < sa_w && y < sa_h) {
-                const u64 kk = ((u64)v << 32) | ((uint32_t)y << 16) | (uint32_t)x;
-                best         = kk < best ? kk : best;
+            if (valid && strip == 0 && x < sa_w && y < sa_h && v < bsad) {
+                bsad = v;
+                bpos = ((uint32_t)y << 16) | (uint32_t)x;
             }
         }
     }
+    const u64 best = ((u64)bsad << 32) | bpos;
     wave_sync();
     return wave_min_u64(best);
 }

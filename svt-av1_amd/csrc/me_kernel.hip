@@ -31,7 +31,9 @@ namespace svtme {
 constexpr int ME_THREADS   = 64;
 constexpr int ME_PD        = 32; // dwords per staged window row: 64 positions + 63 more pixels, rounded up
 constexpr int ME_TILE      = 64; // search positions per tile side
-constexpr int ME_WIN_ROWS  = 8 + 70; // a work item's 8 search rows, 62 rows under the last one + the staggered walk's overrun
+constexpr int ME_ITEM_GROUPS = 2; // a work item's units lie in at most 2 consecutive groups of 8 search rows
+constexpr int ME_ROW_BITS    = 4; // keys carry the row within the item
+constexpr int ME_WIN_ROWS  = 8 * ME_ITEM_GROUPS + 62; // the item's search rows and the 62 rows under the last one
 constexpr int ME_WIN_BYTES = ME_WIN_ROWS * ME_PD * 4;
 
 struct MeShared {
@@ -76,10 +78,12 @@ __device__ __forceinline__ uint32_t row_quads_min(uint32_t v) {
     return v;
 }
 
-// Work items of a w x h window: one per (64-position column chunk, group of `item_rows` rows). item_rows is 8, or 16 for
-// pictures whose controls keep every window at most 16 positions wide and 16 rows high (PicParams::me_tall): such a window
-// fills a quarter of an item's lanes, and the other quads take the rows under the eighth instead of a second item.
-__device__ __forceinline__ int me_item_count(int w, int h, int item_rows) { return ((w + ME_TILE - 1) / ME_TILE) * ((h + item_rows - 1) / item_rows); }
+// x / d for the small divisors of the work-item geometry (below 256; x * d far below 2^32): a shift or a multiplication
+__device__ __forceinline__ int div_small(int x, int d) { return d == 16 ? x >> 4 : (int)magic_div((uint32_t)x, (uint32_t)d, div_magic((uint32_t)d)); }
+// The same for the units per group of rows (2, 4, 8, 10, 12, 14, 16) and x below 2^12, without the table: x * ceil(2^16 / d) >> 16
+__device__ __forceinline__ uint32_t units_inverse(int d) {
+    return (d & (d - 1)) == 0 ? 65536u >> (31 - __clz(d)) : (d == 10 ? 6554u : (d == 12 ? 5462u : 4682u));
+}
 
 template <class PICS>
 __global__ void __launch_bounds__(ME_THREADS) me_plan_kernel(PICS pp, int me_ref0) {
@@ -303,14 +307,14 @@ __global__ void __launch_bounds__(ME_THREADS) me_plan_kernel(PICS pp, int me_ref
     if (tid == 0) {
         *job = MeJob{org_x, org_y, w, h};
         count_ops(p, 5, (unsigned long long)w * h * 2048ull);
-        if (me_item_count(w, h, p.me_tall ? 16 : 8) > p.me_max_items) count_ops(p, 7, 1); // cannot happen: the host sized the grid from sa_max
+        if (me_item_count(w, h) > p.me_max_items) count_ops(p, 7, 1); // cannot happen: the host sized the grid from sa_max
     }
 }
 
-template <class PICS, bool TALL>
+template <class PICS>
 __global__ void __launch_bounds__(ME_THREADS, 2) me_search_kernel(PICS pp, int grid_refs, uint32_t grid_refs_magic, int ref_first, int ref_last) {
-    constexpr int ITEM_ROWS = TALL ? 16 : 8, ROW_BITS = TALL ? 4 : 3; // keys carry the row within the item
-    __shared__ MeShared               S;
+    constexpr int ROW_BITS = ME_ROW_BITS;
+    __shared__ __align__(16) uint32_t src_rows[32 * 16]; // rows 0,2,..,62 of the source block, 16 dwords each
     __shared__ __align__(16) uint32_t win[ME_WIN_BYTES / 4];
     // the grid's slowest dimension is (picture, reference): the work items of one picture are dispatched together, so that
     // the workgroups in flight read a picture or two's planes rather than the whole batch's (what L2 holds)
@@ -334,14 +338,27 @@ __global__ void __launch_bounds__(ME_THREADS, 2) me_search_kernel(PICS pp, int g
     const MeJob job = p.me_jobs[b64 * 8 + my];
     const int   w = job.w, h = job.h, org_x = job.org_x, org_y = job.org_y;
     if (w <= 0) return;
-    // ---- this item: one group of 8 search rows of one 64-position column chunk = up to 16 runs (4 positions x 8 rows);
-    // TALL: two such groups of a window of at most 4 runs
-    const int n_yg = (h + ITEM_ROWS - 1) / ITEM_ROWS;
-    if ((int)blockIdx.y >= me_item_count(w, h, ITEM_ROWS)) return;
-    const int chunk = blockIdx.y / n_yg, yg0 = blockIdx.y - chunk * n_yg;
-    const int tx0 = chunk * ME_TILE, n_xg = (min(ME_TILE, w - tx0) + 3) >> 2;
-    const int ty0 = yg0 * ITEM_ROWS, rows = min(h - ty0, ITEM_ROWS); // search rows staged for this item
-    const int r0 = 0, r1 = n_xg;
+    // ---- this item (me_item_units in svtme_device.h): a 64-position column chunk of the window is cut into units - the
+    // 4 positions x 8 rows of a position quad and a group of 8 rows, or one row parity of them where the chunk has few
+    // quads - numbered group by group; an item takes the next 16 of them, one per quad of lanes, from up to two groups of
+    // rows. A window of 48 x 48 positions fills its items' lanes that way, where an item per group would leave a quarter
+    // of them idle.
+    const int G = (h + 7) >> 3, full = (w - 1) / ME_TILE;
+    int       chunk = full, item_i = (int)blockIdx.y - full * G;
+    if (item_i < 0) { // one of the 64-position chunks before the last: an item per group of rows
+        chunk = div_small((int)blockIdx.y, G);
+        item_i = (int)blockIdx.y - chunk * G;
+    }
+    const int tx0 = chunk * ME_TILE;
+    int       n_xg, U, UPI;
+    me_item_units(min(ME_TILE, w - tx0), n_xg, U, UPI);
+    const bool split = n_xg <= ME_THREADS / 8; // few quads: each row parity of a (quad, group) is a unit of its own
+    const int  n_unit_all = G * U, u0 = item_i * UPI;
+    if (u0 >= n_unit_all) return;
+    const int u_end = min(u0 + UPI, n_unit_all);
+    const uint32_t u_inv = units_inverse(U);
+    const int      g0 = (int)(((uint32_t)u0 * u_inv) >> 16), g_last = (int)(((uint32_t)(u_end - 1) * u_inv) >> 16);
+    const int ty0 = 8 * g0, rows = min(h - ty0, 8 * (g_last - g0 + 1)); // search rows staged for this item
 
     const DevPlane cur = load_plane(p.cur.lvl[2]);
     const DevPlane ref = load_plane(p.ref[my_l][my_r].lvl[2]);
@@ -354,10 +371,10 @@ __global__ void __launch_bounds__(ME_THREADS, 2) me_search_kernel(PICS pp, int g
             __builtin_memcpy(&v[t], cur.pix + (ptrdiff_t)(b64y + 2 * (i >> 2)) * cur.stride + b64x + 16 * (i & 3), 16);
         }
 #pragma unroll
-        for (int t = 0; t < 2; ++t) reinterpret_cast<uint4 *>(S.src)[tid + ME_THREADS * t] = v[t];
+        for (int t = 0; t < 2; ++t) reinterpret_cast<uint4 *>(src_rows)[tid + ME_THREADS * t] = v[t];
     }
     const int       quad = tid >> 2, col = tid & 3;
-    const uint32_t *sbase = &S.src[col * 4];
+    const uint32_t *sbase = &src_rows[col * 4];
 
     {
         {
@@ -368,9 +385,10 @@ __global__ void __launch_bounds__(ME_THREADS, 2) me_search_kernel(PICS pp, int g
                 const uint8_t *g = ref.pix + (ptrdiff_t)(b64y + org_y + ty0 + (tid >> 3)) * ref.stride + (b64x + org_x + tx0 + 16 * d);
                 uint4         *dst = reinterpret_cast<uint4 *>(win) + (tid >> 3) * (ME_PD / 4) + d;
                 if (d < nq) {
-                    // nrow <= 70 (78): at most 9 (10) trips, all loads issued before the first store; trips past the last
-                    // row repeat it (same value into the same slot), so nothing is conditional
-                    constexpr int TRIPS = (ITEM_ROWS + 62 + 7) / 8;
+                    // nrow <= 78: at most 10 trips. The 9 trips that an item of one group of rows needs are all issued before
+                    // the first store; trips past the last row repeat it (same value into the same slot), so nothing is
+                    // conditional. Items whose units lie in two groups take one more.
+                    constexpr int TRIPS = (8 + 62 + 7) / 8, MORE = (ME_WIN_ROWS + 7) / 8 - TRIPS;
                     uint4         v[TRIPS];
 #pragma unroll
                     for (int t = 0; t < TRIPS; ++t) {
@@ -379,20 +397,28 @@ __global__ void __launch_bounds__(ME_THREADS, 2) me_search_kernel(PICS pp, int g
                     }
 #pragma unroll
                     for (int t = 0; t < TRIPS; ++t) dst[min(8 * t, nrow - 1 - (tid >> 3)) * (ME_PD / 4)] = v[t];
+                    if (nrow > 8 * TRIPS) {
+                        uint4 e[MORE];
+#pragma unroll
+                        for (int t = 0; t < MORE; ++t) {
+                            const int dr = min(8 * (TRIPS + t), nrow - 1 - (tid >> 3));
+                            __builtin_memcpy(&e[t], g + (ptrdiff_t)dr * ref.stride, 16);
+                        }
+#pragma unroll
+                        for (int t = 0; t < MORE; ++t) dst[min(8 * (TRIPS + t), nrow - 1 - (tid >> 3)) * (ME_PD / 4)] = e[t];
+                    }
                 }
             }
             __syncthreads();
-            // few runs: each parity of a run gets its own quad
-            const bool split  = TALL || r1 - r0 <= ME_THREADS / 8;
-            const int  n_unit = split ? 2 * (r1 - r0) : r1 - r0;
             const int  n_it   = split ? 1 : 2;
             {
-                // TALL (at most 4 runs, so at most 8 units): quads 8..15 repeat the units on search rows 8..15
-                const int  u     = TALL ? quad & 7 : quad, grp = TALL ? quad >> 3 : 0;
-                const bool valid = u < n_unit;
-                const int  run   = r0 + (valid ? (split ? u >> 1 : u) : 0);
-                const int  par0  = split ? (u & 1) : 0;
-                const int  xg    = run;
+                // this quad's unit: group of rows `grp` (counted from the item's first), position quad xg, row parity
+                const int  u     = u0 + quad;
+                const bool valid = quad < UPI && u < u_end;
+                const int  ug    = valid ? (int)(((uint32_t)u * u_inv) >> 16) : g0, uv = valid ? u - ug * U : 0;
+                const int  grp   = ug - g0;
+                const int  xg    = split ? uv >> 1 : uv;
+                const int  par0  = split ? (uv & 1) : 0;
                 const int  ya = 8 * grp, yb = min(rows, ya + 8);
                 // running minima of this lane. 8x8: packed 16-bit keys SAD * 8 + row-in-run, two positions per dword;
                 // 16x16: SAD << 16 | row << 6; larger: SAD << 9 | row << 6. A position that does not exist carries an
@@ -549,13 +575,13 @@ __global__ void __launch_bounds__(ME_THREADS, 2) me_search_kernel(PICS pp, int g
 #pragma unroll
                         for (int c = 0; c < 2; ++c) {
                             const uint32_t d0 = b8[by][c][0], d1 = b8[by][c][1];
-                            // a 16-bit key SAD << 3 | row of 8 -> SAD << (6 + ROW_BITS) | row of the item << 6
-                            auto wide = [&](uint32_t k16) {
-                                return TALL ? ((k16 & 0xFFF8u) << 7) | ((k16 & 7u) << 6) | ((uint32_t)grp << 9) : k16 << 6;
-                            };
-                            const uint32_t k0 = wide(d0 & 0xFFFFu) | xlab[0], k1 = wide(d0 >> 16) | xlab[1];
-                            const uint32_t k2 = wide(d1 & 0xFFFFu) | xlab[2], k3 = wide(d1 >> 16) | xlab[3];
-                            const uint32_t k  = row_quads_min(min(min(k0, k1), min(k2, k3)));
+                            // a 16-bit key SAD << 3 | row of 8, first with the column under it: the lane's minimum over
+                            // its four columns; then the group goes between SAD and row: SAD << (6 + ROW_BITS) | row of the
+                            // item << 6 | column (all ones stay above every key a position can produce)
+                            const uint32_t k0 = ((d0 & 0xFFFFu) << 6) | xlab[0], k1 = ((d0 >> 16) << 6) | xlab[1];
+                            const uint32_t k2 = ((d1 & 0xFFFFu) << 6) | xlab[2], k3 = ((d1 >> 16) << 6) | xlab[3];
+                            const uint32_t km = min(min(k0, k1), min(k2, k3));
+                            const uint32_t k  = row_quads_min(((km & 0xFFFFFE00u) << (ROW_BITS - 3)) | ((km & 0x1FFu) | ((uint32_t)grp << 9)));
                             const int      bx8 = col * 2 + c; // 8x8 block column
                             const int      pu  = 21 + z16(by >> 1, bx8 >> 1) * 4 + ((by & 1) << 1) + (bx8 & 1);
                             if (writer) part[pu] = k;
@@ -587,7 +613,7 @@ __global__ void __launch_bounds__(ME_THREADS, 2) me_search_kernel(PICS pp, int g
         const uint32_t sad = k >> sh;
         // a key that no position produced (cannot happen for an item the plan made): all-ones fields exceed the largest SAD
         if (sad > (pu >= 21 ? 8u * 4u : pu >= 5 ? 16u * 8u : pu >= 1 ? 32u * 16u : 64u * 32u) * 255u) continue;
-        const u64 key = ((u64)sad << 32) | ((uint32_t)(ty0 + (int)((k >> 6) & (ITEM_ROWS - 1))) << 16) | (uint32_t)(tx0 + (int)(k & 63));
+        const u64 key = ((u64)sad << 32) | ((uint32_t)(ty0 + (int)((k >> 6) & ((1 << ROW_BITS) - 1))) << 16) | (uint32_t)(tx0 + (int)(k & 63));
         u64      *g   = &p.me_keys[(size_t)(b64 * 8 + my) * SVTME_PU_COUNT + pu];
         if (key < *g) atomicMin(g, key);
     }
@@ -673,8 +699,7 @@ static void launch_me_as(const Batch &b, PICS pics, hipStream_t s, hipEvent_t ma
     auto       search = [&](int ref_first, int ref_last) {
         const dim3 grid(n_b64, p.me_max_items, n_refs * b.n);
         const uint32_t refs_magic = (uint32_t)((0x100000000ull + (uint32_t)n_refs - 1) / (uint32_t)n_refs);
-        if (p.me_tall) hipLaunchKernelGGL((me_search_kernel<PICS, true>), grid, dim3(ME_THREADS), 0, s, pics, n_refs, refs_magic, ref_first, ref_last);
-        else hipLaunchKernelGGL((me_search_kernel<PICS, false>), grid, dim3(ME_THREADS), 0, s, pics, n_refs, refs_magic, ref_first, ref_last);
+        hipLaunchKernelGGL((me_search_kernel<PICS>), grid, dim3(ME_THREADS), 0, s, pics, n_refs, refs_magic, ref_first, ref_last);
     };
     if (two_phase) {
         hipLaunchKernelGGL(me_plan_kernel<PICS>, dim3(n_b64, 1, b.n), dim3(ME_THREADS), 0, s, pics, 0);
@@ -698,7 +723,7 @@ void launch_me(const Batch &b, hipStream_t s, hipEvent_t marks[3]) {
 // resident workgroups per CU the runtime expects for the search kernel (diagnostic)
 int occupancy_me_search() {
     int n = 0;
-    (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, me_search_kernel<OnePicture, false>, ME_THREADS, 0);
+    (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, me_search_kernel<OnePicture>, ME_THREADS, 0);
     return n;
 }
 

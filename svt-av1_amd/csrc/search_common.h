@@ -141,6 +141,7 @@ __device__ __forceinline__ void stage_window(uint32_t *win, const uint8_t *g, in
     const int      lane = threadIdx.x & 63, c = lane & ((1 << lg) - 1), r0 = lane >> lg, per_trip = NT >> lg;
     uint4         *dst = reinterpret_cast<uint4 *>(win);
     if (c < pr) {
+#pragma unroll 1
         for (int base = r0; base < n_row; base += per_trip * NB) {
             uint4    v[NB];
             uint32_t at[NB];

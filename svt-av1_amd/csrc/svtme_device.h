@@ -45,6 +45,24 @@ struct MeJob {
     int16_t org_x, org_y, w, h;
 };
 
+// Work items of the integer search. A 64-position column chunk of a window (`wc` positions wide) has n_xg position quads;
+// per group of 8 search rows it is cut into U units - a quad's 4 positions x 8 rows, or with at most 8 quads one row
+// parity of them -, numbered group by group, and an item takes UPI consecutive units: 16, one per quad of lanes, where any
+// 16 consecutive units lie in at most two groups of rows (U = 8, 12, 14, 16); else the units of one group (U = 10) or of
+// two (chunks of one or two quads).
+__host__ __device__ inline void me_item_units(int wc, int &n_xg, int &U, int &UPI) {
+    n_xg = (wc + 3) >> 2;
+    U    = n_xg <= 8 ? 2 * n_xg : n_xg;
+    UPI  = (U >= 12 || U == 8) ? 16 : (U == 10 ? 10 : 2 * U);
+}
+// items of a w x h window: an item per group of rows for every 64-position chunk but the last, whose units are packed
+__host__ __device__ inline int me_item_count(int w, int h) {
+    const int G = (h + 7) >> 3, full = (w - 1) / 64;
+    int       n_xg, U, UPI;
+    me_item_units(w - full * 64, n_xg, U, UPI);
+    return full * G + (G * U + UPI - 1) / UPI;
+}
+
 // Everything a picture's kernels need. A launch covers the pictures of one batch: their records lie next to each other in
 // device memory and a workgroup picks its picture from its index (blockIdx.x / n_b64, or a grid dimension of its own).
 // The pictures of a batch have one size, one set of controls and one me_type; they differ in planes, reference lists,
@@ -70,7 +88,7 @@ struct PicParams {
     int32_t        restricted; // integer search windows stay inside the block's tile (restricted_motion_vector)
     uint32_t       tf_me_exit_th;
     int32_t        me_max_items; // upper bound of search work items per (b64, ref) for this picture's controls
-    int32_t        me_tall; // every window is at most 16 positions wide and 9..16 rows high: work items of 16 rows
+    int32_t        reserved_me; // (unused)
     int32_t        zero; // always 0, but the compiler cannot know: keeps it from merging loads that must stay apart
     const svtme_tile_rect *tiles; // [n_b64] the blocks' tiles for restricted windows; nullptr: the picture is the tile
     // intermediates

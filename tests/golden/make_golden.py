@@ -170,7 +170,7 @@ def main_big():
 
 def main_bench():
     """`make_golden.py --bench [workload ...]`: one digest per bench.py workload (its seed-1000 pictures through the real
-    reference with its AVX2 SAD kernels, which the digest cases above assert equal to its C kernels) into
+    reference with its AVX2 SAD kernels, which the digest cases above assert equal to its C kernels for open-loop ME) into
     bench_digests.json: what `bench.py` checks its last step's results against."""
     sys.path.insert(0, ROOT)
     import bench
@@ -192,8 +192,12 @@ def main_bench():
         else:
             b0, b1, n0, n1 = gop.mrp_counts(wl["enc_mode"])
             kw = dict(ref_counts=(max(b0, n0), max(b1, n1)))
-        hdr, recs = refio.run_reference(frames, pics, wl["enc_mode"], threads=8, use_avx2=1, **kw)
-        assert hdr["used_avx2"]
+        # temporal-filter searches through the reference's C kernels: its AVX2 kernel leaves the 8x8 vectors unwritten when
+        # the caller does not ask for them (EbComputeSAD_Intrinsic_AVX2.c:4634), which the temporal filter does not; the
+        # C kernel writes them regardless (EbMotionEstimation.c:367), and that is what the engine reproduces
+        avx2 = 0 if kind == "tf" else 1
+        hdr, recs = refio.run_reference(frames, pics, wl["enc_mode"], threads=8, use_avx2=avx2, **kw)
+        assert bool(hdr["used_avx2"]) == bool(avx2)
         doc["digests"][name] = {
             "frames_sha256": hashlib.sha256(frames.tobytes()).hexdigest(), "pictures": len(pics),
             "sha256": verify.reference_digest(recs, pics, kind, (wl["width"] + 63) // 64, wl.get("b64_step", 0))}
