@@ -424,7 +424,7 @@ __global__ void __launch_bounds__(ME_THREADS, 2) me_search_kernel(PICS pp, int g
                 // 16x16: SAD << 16 | row << 6; larger: SAD << 9 | row << 6. A position that does not exist carries an
                 // all-ones row mask, which makes its keys all ones.
                 uint32_t b8[8][2][2];
-                uint32_t b16[4][4], b32[2][4], b64k[4];
+                uint32_t b16[4][4], b32[2][2], b64k[2]; // (32x32 / 64x64: this lane's two of the quad's four positions)
 #pragma unroll
                 for (int a = 0; a < 8; ++a)
 #pragma unroll
@@ -433,8 +433,10 @@ __global__ void __launch_bounds__(ME_THREADS, 2) me_search_kernel(PICS pp, int g
                 for (int i = 0; i < 4; ++i) {
 #pragma unroll
                     for (int a = 0; a < 4; ++a) b16[a][i] = 0xFFFFFFFFu;
-                    b32[0][i] = b32[1][i] = b64k[i] = 0xFFFFFFFFu;
+                    b32[i >> 1][i & 1] = 0xFFFFFFFFu;
                 }
+                b64k[0] = b64k[1] = 0xFFFFFFFFu;
+                const bool odd = (col & 1) != 0;
                 // The 4 same-parity rows of a pass are walked together, staggered by one sampled source row: position t
                 // meets source row m at step s = t + m, while the lane holds reference row (first row of the pass + 2 s) in
                 // registers. Every reference row is read from LDS once for 4 positions and every source row once (kept
@@ -533,19 +535,22 @@ __global__ void __launch_bounds__(ME_THREADS, 2) me_search_kernel(PICS pp, int g
                                             topv[t][0] = half[t][0];
                                             topv[t][1] = half[t][1];
                                         }
-                                        if constexpr (a == 3) { // the whole block: 32x32 and 64x64 sums across the quad
+                                        if constexpr (a == 3) {
+                                            // The whole block: 32x32 and 64x64 sums across the quad. The two lanes of a pair
+                                            // (the two 16-pixel columns of a 32x32 partition) split the quad's four positions:
+                                            // each hands the packed sums of the other's two positions over and adds what it
+                                            // receives to its own, so a lane sums and ranks two positions, not four.
+                                            const uint32_t tk = odd ? topv[t][1] : topv[t][0], tr = quad_xor1(odd ? topv[t][0] : topv[t][1]);
+                                            const uint32_t bk = odd ? half[t][1] : half[t][0], br = quad_xor1(odd ? half[t][0] : half[t][1]);
 #pragma unroll
-                                            for (int i = 0; i < 4; ++i) {
-                                                const uint32_t tw_ = topv[t][i >> 1], bw_ = half[t][i >> 1];
-                                                uint32_t       tp = (i & 1) ? tw_ >> 16 : tw_ & 0xFFFFu;
-                                                uint32_t       bt = (i & 1) ? bw_ >> 16 : bw_ & 0xFFFFu;
-                                                tp += quad_xor1(tp);
-                                                bt += quad_xor1(bt);
-                                                uint32_t all = tp + bt;
+                                            for (int j = 0; j < 2; ++j) {
+                                                const uint32_t tp = j ? (tk >> 16) + (tr >> 16) : (tk & 0xFFFFu) + (tr & 0xFFFFu);
+                                                const uint32_t bt = j ? (bk >> 16) + (br >> 16) : (bk & 0xFFFFu) + (br & 0xFFFFu);
+                                                uint32_t       all = tp + bt;
                                                 all += quad_xor2(all);
-                                                b32[0][i] = min(b32[0][i], (tp << (6 + ROW_BITS)) | yrk[t]);
-                                                b32[1][i] = min(b32[1][i], (bt << (6 + ROW_BITS)) | yrk[t]);
-                                                b64k[i]   = min(b64k[i], (all << (6 + ROW_BITS)) | yrk[t]);
+                                                b32[0][j] = min(b32[0][j], (tp << (6 + ROW_BITS)) | yrk[t]);
+                                                b32[1][j] = min(b32[1][j], (bt << (6 + ROW_BITS)) | yrk[t]);
+                                                b64k[j]   = min(b64k[j], (all << (6 + ROW_BITS)) | yrk[t]);
                                             }
                                         }
                                     }
@@ -591,13 +596,17 @@ __global__ void __launch_bounds__(ME_THREADS, 2) me_search_kernel(PICS pp, int g
                         const uint32_t k = row_quads_min(min(min(b16[a][0] | xlab[0], b16[a][1] | xlab[1]), min(b16[a][2] | xlab[2], b16[a][3] | xlab[3])));
                         if (writer) part[5 + z16(a, col)] = k;
                     }
+                    // (32x32 / 64x64: the lane holds positions 0, 1 or 2, 3 of the quad; its pair partner the other two)
+                    const uint32_t xl0 = odd ? xlab[2] : xlab[0], xl1 = odd ? xlab[3] : xlab[1];
 #pragma unroll
                     for (int a = 0; a < 2; ++a) {
-                        const uint32_t k = row_quads_min(min(min(b32[a][0] | xlab[0], b32[a][1] | xlab[1]), min(b32[a][2] | xlab[2], b32[a][3] | xlab[3])));
-                        if (writer && (col & 1) == 0) part[1 + a * 2 + (col >> 1)] = k;
+                        uint32_t k = min(b32[a][0] | xl0, b32[a][1] | xl1);
+                        k          = row_quads_min(min(k, quad_xor1(k)));
+                        if (writer && !odd) part[1 + a * 2 + (col >> 1)] = k;
                     }
                     {
-                        const uint32_t k = row_quads_min(min(min(b64k[0] | xlab[0], b64k[1] | xlab[1]), min(b64k[2] | xlab[2], b64k[3] | xlab[3])));
+                        uint32_t k = min(b64k[0] | xl0, b64k[1] | xl1);
+                        k          = row_quads_min(min(k, quad_xor1(k)));
                         if (writer && col == 0) part[0] = k;
                     }
                 }
