@@ -30,7 +30,7 @@
 namespace svtme {
 
 constexpr int HI_THREADS   = 64;
-constexpr int HI_WIN_BYTES = 12288; // LDS budget of one staged reference window
+constexpr int HI_WIN_BYTES = 6144; // LDS budget of one staged reference window (with it five work items per SIMD are resident)
 constexpr int HI_XCHUNK    = 96; // search positions per staged column chunk (level 0 / pre-HME); 128 for windows wider than that
 constexpr int HI_WIN2_BYTES = 6144; // levels 1 and 2
 constexpr int HI_WIN2_BYTES_FS = 8192; // the same with FULL_SAD_SEARCH: 16 + 63 rows of the 64x64 block's 16x16 window
@@ -138,30 +138,38 @@ __device__ uint32_t slow_sad(const DevPlane &cur, const DevPlane &ref, int ox, i
 
 // The T search rows (STEP apart: same parity for a block sampled every other row, consecutive for a block sampled on
 // every row) x 4 columns of every unit of a staged window band, for a 16-pixel-wide block of `rows` sampled rows held in
-// src (wave-uniform); FULL: rows == NR. Folds each lane's best (SAD, raster index) into `best`. The window was staged with one
-// empty 16-byte piece in front of every (STEP T)-th row (stage_window's gap_shift): units STEP T rows apart start 4 banks
-// apart instead of in the same one.
-// PAIR: the window is two regions of w_reg columns side by side (w_reg a multiple of 4, so a unit lies in one of them);
-// each keeps its own minimum, with positions counted inside the region: `best` the left one's, `best1` the right one's.
-template <int T, bool FULL, int NR = 8, int STEP = 2, bool PAIR = false>
+// src (wave-uniform); FULL: rows == NR. Folds each lane's best (SAD, y, x) into `best`.
+// MODE 0: one window, one minimum (best[0]). The window was staged with one empty 16-byte piece in front of every
+// (STEP T)-th row (stage_window's gap_shift): units STEP T rows apart start 4 banks apart instead of in the same one.
+// MODE 1: the window is two regions of w_reg columns side by side (w_reg a multiple of 4, so a unit lies in one of them);
+// each keeps its own minimum, with positions counted inside the region: best[0] the left one's, best[1] the right one's.
+// MODE 2: two such rows of regions, h_reg rows each, one under the other in a window staged in one piece without the empty
+// pieces (brows == 2 h_reg): the units are cut per row of regions, so none lies across the border; best[2], best[3] are
+// the lower row's.
+template <int T, bool FULL, int NR, int STEP, int MODE>
 __device__ __forceinline__ void strip_units(const uint32_t *win, int pd, int n_xg, int brows, bool skip_even, const uint32_t (&src)[NR][4],
-                                            int rows, int zero, int y_abs0, int x_abs0, int sa_w, u64 &best, int w_reg, u64 &best1) {
+                                            int rows, int zero, int y_abs0, int x_abs0, int sa_w, u64 (&best)[4], int w_reg, int h_reg) {
     const int lane   = threadIdx.x & 63;
-    const int n_yg   = (brows + STEP * T - 1) / (STEP * T);
-    const int n_unit = n_xg * n_yg * ((skip_even || STEP == 1) ? 1 : 2);
+    const int hrows  = MODE == 2 ? h_reg : brows; // rows the units are cut from
+    const int n_yg   = (hrows + STEP * T - 1) / (STEP * T);
+    const int n_half = n_xg * n_yg * ((skip_even || STEP == 1) ? 1 : 2);
+    const int n_unit = MODE == 2 ? 2 * n_half : n_half;
     const uint32_t xg_magic = div_magic((uint32_t)n_xg);
     for (int ub = 0; ub < n_unit; ub += HI_THREADS) {
         const int  u     = ub + lane;
         const bool valid = u < n_unit;
-        const int  rest  = valid ? (int)magic_div((uint32_t)u, (uint32_t)n_xg, xg_magic) : 0;
-        const int  xg    = valid ? u - rest * n_xg : 0;
+        const bool lower = MODE == 2 && u >= n_half;
+        const int  uu    = lower ? u - n_half : u;
+        const int  rest  = valid ? (int)magic_div((uint32_t)uu, (uint32_t)n_xg, xg_magic) : 0;
+        const int  xg    = valid ? uu - rest * n_xg : 0;
         const int  par   = STEP == 1 ? 0 : (skip_even ? 1 : (rest & 1));
         const int  yg    = (skip_even || STEP == 1) ? rest : rest >> 1;
-        const int  yfirst = yg * STEP * T + par;
-        const int  n_pos  = valid ? min(T, max(0, (brows - yfirst + STEP - 1) / STEP)) : 0;
+        const int  yrel  = yg * STEP * T + par; // first row, within the rows the units are cut from
+        const int  n_pos = valid ? min(T, max(0, (hrows - yrel + STEP - 1) / STEP)) : 0;
+        const int  yfirst = yrel + (lower ? h_reg : 0);
         // the four 8-byte operands of a step overlap by a dword; the odd pairs are read through a second pointer the
         // compiler cannot prove equal to the first, so every pair comes from LDS in its own aligned register pair
-        const uint32_t *rr = win + yfirst * pd + 4 * yg + xg; // (yfirst / (STEP T) == yg)
+        const uint32_t *rr = win + yfirst * pd + (MODE == 2 ? 0 : 4 * yg) + xg; // (MODE < 2: yfirst / (STEP T) == yg)
         const uint32_t *rq = rr + 1 + zero;
         u64             acc[T];
 #pragma unroll
@@ -170,7 +178,7 @@ __device__ __forceinline__ void strip_units(const uint32_t *win, int pd, int n_x
         uint32_t n01[2], n12[2], n23[2], n34[2];
         auto     fetch = [&](auto sn_c) { // the window row of step sn: STEP sn rows below the unit's first, past sn / T gaps
             constexpr int sn = decltype(sn_c)::value;
-            if constexpr (sn > 0 && sn % T == 0) {
+            if constexpr (MODE != 2 && sn > 0 && sn % T == 0) {
                 rr += 4;
                 rq += 4;
             }
@@ -210,43 +218,52 @@ __device__ __forceinline__ void strip_units(const uint32_t *win, int pd, int n_x
             col[2] = min(col[2], ((hi & 0xFFFFu) << 4) | tk);
             col[3] = min(col[3], ((hi >> 16) << 4) | tk);
         }
-        // raster order: row first, then column
+        // raster order: row first, then column (positions counted inside the unit's region)
         u64        ubest  = ~0ull;
-        const bool second = PAIR && x_abs0 + xg * 4 >= w_reg;
+        const bool second = MODE >= 1 && x_abs0 + xg * 4 >= w_reg;
         const int  xo = second ? w_reg : 0;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const int x = x_abs0 + xg * 4 + i;
             if (col[i] != ~0u && x < sa_w) {
-                const int y = y_abs0 + yfirst + STEP * (int)(col[i] & 15);
+                const int y = y_abs0 + yrel + STEP * (int)(col[i] & 15);
                 const u64 k = ((u64)(col[i] >> 4) << 32) | ((uint32_t)y << 16) | (uint32_t)(x - xo);
                 ubest       = k < ubest ? k : ubest;
             }
         }
-        if (second) best1 = ubest < best1 ? ubest : best1;
-        else best = ubest < best ? ubest : best;
+        const int q = (second ? 1 : 0) + (lower ? 2 : 0);
+#pragma unroll
+        for (int j = 0; j < (MODE == 2 ? 4 : MODE + 1); ++j) best[j] = (q == j && ubest < best[j]) ? ubest : best[j];
     }
 }
 
 // Exhaustive search of the (bw x rows sampled rows, STEP = FS ? 1 : 2 plane rows apart) block of `cur` at (ox, oy) over
-// the sa_w x sa_h window of `ref` whose first position is plane pixel (wx, wy). Returns min (SAD << 32 | y << 16 | x),
-// ~0 when no position was evaluated (skip_even with a single row). Whole wave. skip_even needs FS == false.
-// PAIR (bw == 16 only): the window is two regions of w_reg = sa_w / 2 columns side by side; returns the left region's
-// minimum and leaves the right one's in key1, both with positions counted inside the region.
-template <bool FS, bool PAIR = false>
-__device__ __forceinline__ u64 l0_search(uint32_t *win, int zero, const DevPlane &cur, const DevPlane &ref, int ox, int oy, int bw,
-                                         int rows, int wx, int wy, int sa_w, int sa_h, bool skip_even, int w_reg, u64 &key1) {
-    constexpr int NR = FS ? 16 : 8, STEP = FS ? 1 : 2;
+// the sa_w x sa_h window of `ref` whose first position is plane pixel (wx, wy). Leaves min (SAD << 32 | y << 16 | x) in
+// key[0] (in every lane), ~0 when no position was evaluated (skip_even with a single row). Whole wave. skip_even needs
+// FS == false.
+// MODE 1 (bw == 16 only): the window is two regions of w_reg = sa_w / 2 columns side by side: key[0] the left region's
+// minimum, key[1] the right one's, both with positions counted inside the region. MODE 2: two such rows of regions of
+// h_reg = sa_h / 2 rows each, key[2], key[3] the lower one's; the caller has checked with l0_quad_fits that the window
+// can be staged in one piece.
+constexpr int kL0Under = 14; // rows under a band's last search row that a sub-sampled 16-row block reaches: 7 x 2
+__device__ __forceinline__ bool l0_quad_fits(int sa_w, int sa_h) {
+    const int n_xg = (sa_w + 3) >> 2, pd = (n_xg + 4 + 3) & ~3;
+    return sa_w <= HI_XCHUNK && (sa_h + kL0Under + 16) * pd * 4 <= HI_WIN_BYTES;
+}
+template <bool FS, int MODE = 0>
+__device__ __forceinline__ void l0_search(uint32_t *win, u64 (&key)[4], int zero, const DevPlane &cur, const DevPlane &ref, int ox, int oy, int bw,
+                                          int rows, int wx, int wy, int sa_w, int sa_h, bool skip_even, int w_reg, int h_reg) {
+    constexpr int NR = FS ? 16 : 8, STEP = FS ? 1 : 2, NKEY = MODE == 2 ? 4 : MODE + 1;
     const int lane = threadIdx.x & 63;
-    u64       best = ~0ull, best1 = ~0ull;
-    key1           = ~0ull;
-    if (sa_w <= 0 || sa_h <= 0 || rows <= 0) return best;
+    u64       best[4] = {~0ull, ~0ull, ~0ull, ~0ull};
+    key[0] = key[1] = key[2] = key[3] = ~0ull;
+    if (sa_w <= 0 || sa_h <= 0 || rows <= 0) return;
     if (bw != 16) {
         for (int i = lane; i < sa_w * sa_h; i += HI_THREADS) {
             const int y = i / sa_w, x = i - y * sa_w;
             if (skip_even && (y & 1) == 0) continue;
             const u64 k = ((u64)slow_sad(cur, ref, ox, oy, wx + x, wy + y, bw, rows, STEP) << 32) | ((uint32_t)y << 16) | (uint32_t)x;
-            best        = k < best ? k : best;
+            best[0]     = k < best[0] ? k : best[0];
         }
     } else {
         // the block's sampled rows are the same for every lane: they come through the scalar (constant) path straight into
@@ -270,11 +287,13 @@ __device__ __forceinline__ u64 l0_search(uint32_t *win, int zero, const DevPlane
             // rows the LDS budget holds: a band's search rows + the (NR - 1) STEP rows under the last one + the staggered
             // walk's overrun (rows that are addressed but never used)
             constexpr int under = (NR - 1) * STEP;
+            static_assert(FS || under == kL0Under, "l0_quad_fits counts the rows under a band");
             // (a row costs up to 4 / (2 STEP) dwords more: the gap pieces, one per STEP T >= 2 STEP rows)
             const int     pdg   = pd + 2 / STEP;
             const int     cap   = (int)magic_div(HI_WIN_BYTES / 4, (uint32_t)pdg, div_magic((uint32_t)pdg));
             int           band  = cap - under - 16;
             band           = band >= 16 ? band & ~15 : max(band, 1);
+            if (MODE == 2) band = sa_h; // (fits: l0_quad_fits)
             for (int y0 = 0; y0 < sa_h; y0 += band) {
                 const int brows = min(band, sa_h - y0);
                 // rows per unit (8, 4 or 2): the choice that costs the wave the fewest cycles - trips of 64 units, each
@@ -282,11 +301,12 @@ __device__ __forceinline__ u64 l0_search(uint32_t *win, int zero, const DevPlane
                 int t = 2;
                 {
                     const int npar = (skip_even || STEP == 1) ? 1 : 2;
+                    const int cut = MODE == 2 ? h_reg : brows, sets = MODE == 2 ? 2 : 1;
                     int       best_cost = 0x7FFFFFFF;
 #pragma unroll
                     for (int tt = 8; tt >= 2; tt >>= 1) {
-                        const int n_yg = (brows + STEP * tt - 1) / (STEP * tt); // (a shift: STEP * tt is a constant power of two)
-                        const int trips = (n_xg * n_yg * npar + HI_THREADS - 1) / HI_THREADS;
+                        const int n_yg = (cut + STEP * tt - 1) / (STEP * tt); // (a shift: STEP * tt is a constant power of two)
+                        const int trips = (n_xg * n_yg * npar * sets + HI_THREADS - 1) / HI_THREADS;
                         const int cost = trips * (NR * 64 * tt + 230 + 36 * tt);
                         if (cost < best_cost) {
                             best_cost = cost;
@@ -296,23 +316,23 @@ __device__ __forceinline__ u64 l0_search(uint32_t *win, int zero, const DevPlane
                 }
                 wave_sync();
                 stage_window<5>(win, ref.pix + (ptrdiff_t)(wy + y0) * ref.stride + wx + x0, ref.stride, pd, brows + under,
-                                (STEP == 2 ? 1 : 0) + (t == 8 ? 3 : (t == 4 ? 2 : 1)));
+                                MODE == 2 ? 31 : (STEP == 2 ? 1 : 0) + (t == 8 ? 3 : (t == 4 ? 2 : 1)));
                 wave_sync();
                 if (rows == NR) {
-                    if (t == 8) strip_units<8, true, NR, STEP, PAIR>(win, pd, n_xg, brows, skip_even, src, rows, zero, y0, x0, sa_w, best, w_reg, best1);
-                    else if (t == 4) strip_units<4, true, NR, STEP, PAIR>(win, pd, n_xg, brows, skip_even, src, rows, zero, y0, x0, sa_w, best, w_reg, best1);
-                    else strip_units<2, true, NR, STEP, PAIR>(win, pd, n_xg, brows, skip_even, src, rows, zero, y0, x0, sa_w, best, w_reg, best1);
+                    if (t == 8) strip_units<8, true, NR, STEP, MODE>(win, pd, n_xg, brows, skip_even, src, rows, zero, y0, x0, sa_w, best, w_reg, h_reg);
+                    else if (t == 4) strip_units<4, true, NR, STEP, MODE>(win, pd, n_xg, brows, skip_even, src, rows, zero, y0, x0, sa_w, best, w_reg, h_reg);
+                    else strip_units<2, true, NR, STEP, MODE>(win, pd, n_xg, brows, skip_even, src, rows, zero, y0, x0, sa_w, best, w_reg, h_reg);
                 } else { // blocks of the picture's bottom edge
-                    if (t == 8) strip_units<8, false, NR, STEP, PAIR>(win, pd, n_xg, brows, skip_even, src, rows, zero, y0, x0, sa_w, best, w_reg, best1);
-                    else if (t == 4) strip_units<4, false, NR, STEP, PAIR>(win, pd, n_xg, brows, skip_even, src, rows, zero, y0, x0, sa_w, best, w_reg, best1);
-                    else strip_units<2, false, NR, STEP, PAIR>(win, pd, n_xg, brows, skip_even, src, rows, zero, y0, x0, sa_w, best, w_reg, best1);
+                    if (t == 8) strip_units<8, false, NR, STEP, MODE>(win, pd, n_xg, brows, skip_even, src, rows, zero, y0, x0, sa_w, best, w_reg, h_reg);
+                    else if (t == 4) strip_units<4, false, NR, STEP, MODE>(win, pd, n_xg, brows, skip_even, src, rows, zero, y0, x0, sa_w, best, w_reg, h_reg);
+                    else strip_units<2, false, NR, STEP, MODE>(win, pd, n_xg, brows, skip_even, src, rows, zero, y0, x0, sa_w, best, w_reg, h_reg);
                 }
             }
         }
     }
-    wave_sync(); // the window and the block rows may be rewritten by this wave's next search
-    if (PAIR) key1 = wave_min_u64(best1);
-    return wave_min_u64(best);
+    wave_sync(); // the window may be rewritten by this wave's next search
+#pragma unroll
+    for (int j = 0; j < NKEY; ++j) key[j] = wave_min_u64(best[j]);
 }
 
 // Zero-MV SAD of every (b64, reference) for the controls with me_early_exit_th (init_zz_sad :2318-2333, get_zz_sad
@@ -357,6 +377,7 @@ __device__ __forceinline__ void l0_item(const P &p, uint32_t *win, int b64x, int
     const int             ox = b64x >> 2, oy = b64y >> 2;
     const int             bw = block_w >> 2, bh = block_h >> 2;
     const int             rows = FS ? bh : bh >> 1;
+    u64                   lbest[4]; // the minima of a search (up to four regions)
     // the search this item runs: window (origin relative to the block, size), row skipping, where the result goes
     int16_t   w = 0, h = 0, org_x = 0, org_y = 0;
     bool      skip = false;
@@ -414,9 +435,10 @@ __device__ __forceinline__ void l0_item(const P &p, uint32_t *win, int b64x, int
         };
         if (all_regions) {
             // This wave runs every region of the reference. Where the 2 x 2 regions tile one rectangle (no region was
-            // clipped at the picture's edge) the two regions of a row are searched as one window, each keeping its own
-            // minimum: the item's fixed part (geometry, the block's rows, staging, reductions) is paid once per pair
-            // and the lanes are twice as well filled, which is what counts for the small windows of the fast presets.
+            // clipped at the picture's edge) they are searched as one window - all four where it can be staged in one
+            // piece, else the two of a row -, each region keeping its own minimum: the item's fixed part (geometry, the
+            // block's rows, staging) is paid once and the lanes are two or four times as well filled, which is what counts
+            // for the small windows of the fast presets.
             int16_t rw[4] = {0, 0, 0, 0}, rh[4] = {0, 0, 0, 0}, rx[4] = {0, 0, 0, 0}, ry[4] = {0, 0, 0, 0};
             for (int q_ = 0; q_ < nw * nh; ++q_) region(q_, rw[q_], rh[q_], rx[q_], ry[q_]);
             const bool tiled = nw == 2 && nh == 2 && bw == 16 && rw[0] >= 8 && rh[0] >= 1 && rw[1] == rw[0] && rw[2] == rw[0] && rw[3] == rw[0] &&
@@ -425,22 +447,26 @@ __device__ __forceinline__ void l0_item(const P &p, uint32_t *win, int b64x, int
             unsigned long long ops = 0;
             for (int q_ = 0; q_ < nw * nh; ++q_) ops += (unsigned long long)max((int)rh[q_], 0) * max((int)rw[q_], 0) * rows * bw;
             if (lane == 0) count_ops(p, 2, ops);
-            if (tiled) {
+            if (!FS && tiled && l0_quad_fits(2 * rw[0], 2 * rh[0])) {
+                l0_search<FS, 2>(win, lbest, p.zero, cur, ref, ox, oy, bw, rows, ox + rx[0], oy + ry[0], 2 * rw[0], 2 * rh[0], false, rw[0], rh[0]);
+                if (lane == 0)
+                    for (int sh = 0; sh < 2; ++sh) {
+                        decode_key(lbest[2 * sh], rx[0], ry[2 * sh], 4, rec->raw_x[sh], rec->raw_y[sh], rec->raw_sad[sh], !FS);
+                        decode_key(lbest[2 * sh + 1], rx[1], ry[2 * sh], 4, rec->raw_x[2 + sh], rec->raw_y[2 + sh], rec->raw_sad[2 + sh], !FS);
+                    }
+            } else if (tiled) {
                 for (int sh = 0; sh < 2; ++sh) {
-                    u64       k1;
-                    const u64 k0 = l0_search<FS, true>(win, p.zero, cur, ref, ox, oy, bw, rows, ox + rx[0], oy + ry[2 * sh], 2 * rw[0], rh[0], false,
-                                                       rw[0], k1);
+                    l0_search<FS, 1>(win, lbest, p.zero, cur, ref, ox, oy, bw, rows, ox + rx[0], oy + ry[2 * sh], 2 * rw[0], rh[0], false, rw[0], 0);
                     if (lane == 0) {
-                        decode_key(k0, rx[0], ry[2 * sh], 4, rec->raw_x[sh], rec->raw_y[sh], rec->raw_sad[sh], !FS);
-                        decode_key(k1, rx[1], ry[2 * sh], 4, rec->raw_x[2 + sh], rec->raw_y[2 + sh], rec->raw_sad[2 + sh], !FS);
+                        decode_key(lbest[0], rx[0], ry[2 * sh], 4, rec->raw_x[sh], rec->raw_y[sh], rec->raw_sad[sh], !FS);
+                        decode_key(lbest[1], rx[1], ry[2 * sh], 4, rec->raw_x[2 + sh], rec->raw_y[2 + sh], rec->raw_sad[2 + sh], !FS);
                     }
                 }
             } else {
                 for (int q_ = 0; q_ < nw * nh; ++q_) {
-                    u64       none;
                     const int i   = (q_ % nw) * 2 + q_ / nw;
-                    const u64 key = l0_search<FS>(win, p.zero, cur, ref, ox, oy, bw, rows, ox + rx[q_], oy + ry[q_], rw[q_], rh[q_], false, 0, none);
-                    if (lane == 0) decode_key(key, rx[q_], ry[q_], 4, rec->raw_x[i], rec->raw_y[i], rec->raw_sad[i], !FS);
+                    l0_search<FS>(win, lbest, p.zero, cur, ref, ox, oy, bw, rows, ox + rx[q_], oy + ry[q_], rw[q_], rh[q_], false, 0, 0);
+                    if (lane == 0) decode_key(lbest[0], rx[q_], ry[q_], 4, rec->raw_x[i], rec->raw_y[i], rec->raw_sad[i], !FS);
                 }
             }
             return;
@@ -453,9 +479,8 @@ __device__ __forceinline__ void l0_item(const P &p, uint32_t *win, int b64x, int
         ops_k   = 2;
     }
     if (lane == 0) count_ops(p, ops_k, (unsigned long long)max(skip ? h >> 1 : (int)h, 0) * max((int)w, 0) * rows * bw);
-    u64       none;
-    const u64 key = l0_search<FS>(win, p.zero, cur, ref, ox, oy, bw, rows, ox + org_x, oy + org_y, w, h, skip, 0, none);
-    if (lane == 0) decode_key(key, org_x, org_y, 4, *res_x, *res_y, *res_sad, !FS);
+    l0_search<FS>(win, lbest, p.zero, cur, ref, ox, oy, bw, rows, ox + org_x, oy + org_y, w, h, skip, 0, 0);
+    if (lane == 0) decode_key(lbest[0], org_x, org_y, 4, *res_x, *res_y, *res_sad, !FS);
 }
 
 template <bool FS, class PICS>
