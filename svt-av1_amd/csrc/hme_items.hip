@@ -291,11 +291,17 @@ __device__ __forceinline__ void l0_search(uint32_t *win, u64 (&key)[4], int zero
             // (a row costs up to 4 / (2 STEP) dwords more: the gap pieces, one per STEP T >= 2 STEP rows)
             const int     pdg   = pd + 2 / STEP;
             const int     cap   = (int)magic_div(HI_WIN_BYTES / 4, (uint32_t)pdg, div_magic((uint32_t)pdg));
-            int           band  = cap - under - 16;
-            band           = band >= 16 ? band & ~15 : max(band, 1);
-            if (MODE == 2) band = sa_h; // (fits: l0_quad_fits)
+            // The overrun (up to 16 rows) only exists under a band whose rows are not whole units, which only the window's
+            // last band can be: the bands before it take all the rows the budget holds, in multiples of 16 (whole units for
+            // every choice of rows per unit), the last one what fits with the overrun.
+            const int     full = (cap - under) & ~15;
+            int           last = cap - under - 16;
+            last           = last >= 16 ? last & ~15 : max(last, 1);
+            int band;
             for (int y0 = 0; y0 < sa_h; y0 += band) {
-                const int brows = min(band, sa_h - y0);
+                const int left = sa_h - y0;
+                band           = MODE == 2 ? sa_h /* (fits: l0_quad_fits) */ : (left <= last || full < 16 ? last : full);
+                const int brows = min(band, left);
                 // rows per unit (8, 4 or 2): the choice that costs the wave the fewest cycles - trips of 64 units, each
                 // 16 QSADs per source row and search row (16 cycles apiece) and some 230 + 36 T cycles of bookkeeping
                 int t = 2;
