@@ -365,7 +365,10 @@ int svtme_picture_done(svtme_engine *e, svtme_ticket ticket);
  * stderr), tail.enable = 0 and serial_hme = 0 (SVTME_ERR_UNSUPPORTED otherwise). The call returns when the results are in
  * `result_block`. All calls on one GPU share that GPU's array: within a process they take turns (a lock), calls from
  * different processes each have their own copy; the call clears what has to start from zero, whatever the last call left.
- * No hipMalloc / hipFree / hipHostMalloc, stream or event creation happens inside.
+ * No hipMalloc / hipFree / hipHostMalloc, stream or event creation happens inside. The call holds the engine's lock from
+ * its first launch to the end of its last kernel: submits, puts and waits of other threads on the same engine stall for
+ * that long, and it shares its stream with the svtme_gm_* / svtme_tpl_search calls (they take turns). A result_block that
+ * is neither device memory nor page-locked host memory is refused with SVTME_ERR_BAD_ARG.
  */
 #define SVTME_STATIC_MAX_B64 2040
 #define SVTME_STATIC_RESULT_BYTES(n_b64, n_refs) \
@@ -463,6 +466,7 @@ typedef struct svtme_gm_warp { /* the fields of EbWarpedMotionParams (EbDefiniti
     int16_t alpha, beta, gamma, delta;
 } svtme_gm_warp;
 int svtme_gm_set_tables(svtme_engine *e, const int16_t *warped_filter, const int32_t *error_measure_lut);
+/* max_points: at most SVTME_GM_MAX_CORNERS (SVTME_ERR_BAD_ARG beyond it); the first max_points corners in raster order */
 int svtme_gm_corners(svtme_engine *e, uint64_t key, int downsample_level, int32_t *points, int32_t max_points, int32_t *num_points);
 int svtme_gm_correspondences(svtme_engine *e, uint64_t cur_key, uint64_t ref_key, int downsample_level,
                              int32_t *correspondences /* [4 * SVTME_GM_MAX_CORNERS] */, int32_t *num_correspondences);
@@ -507,8 +511,9 @@ int svtme_gm_frame_error(svtme_engine *e, uint64_t cur_key, uint64_t ref_key, in
  * itself.
  *
  * The ME results come in the layout of MeSbResults (EbMotionEstimationLcuResults.h:29-52), n_pu entries per 64x64 block
- * (SQUARE_PU_COUNT or MAX_SB64_PU_COUNT_NO_8X8), one 64x64 block after the other. Synchronous; takes turns with the
- * global-motion calls. */
+ * (SQUARE_PU_COUNT 85, MAX_SB64_PU_COUNT_NO_8X8 21, or 5 when enable_me_16x16 is 0: EbPictureControlSet.c:112-117), one
+ * 64x64 block after the other. A candidate count above max_cand, or a candidate that names a reference beyond n_ref, makes
+ * the call fail with SVTME_ERR_BAD_ARG. Synchronous; takes turns with the global-motion calls. */
 #define SVTME_TPL_BLOCKS 21
 typedef struct svtme_tpl_picture {
     uint64_t cur_key; /* pcs->enhanced_picture_ptr: the picture's own store entry */

@@ -13,6 +13,7 @@
 #include <algorithm>
 #include <math.h>
 
+#include <condition_variable>
 #include <mutex>
 #include <new>
 #include <stdio.h>
@@ -45,7 +46,9 @@ struct Slot {
     bool       release_pending = false;
     uint64_t   key = 0, picture_number = 0;
     uint64_t   gen = 0; // number of the put that built the planes: tells a cached by-product (corner lists) from a stale one
-    int        readers = 0; // submitted pictures that have not been waited for yet (and global-motion calls that are running)
+    int        readers = 0; // submitted pictures that have not been waited for yet (and global-motion / TPL calls that are running)
+    int        sync_readers = 0; // of those, the global-motion / TPL calls: no event orders a rewrite behind them, a put waits
+    int        put_waiting = 0; // puts that wait for them: new global-motion / TPL readers queue up behind such a put
     uint32_t   width = 0, height = 0;
     DevPicture pic{};
     uint8_t   *mem = nullptr; // device
@@ -176,6 +179,7 @@ struct svtme_engine {
     uint8_t            *static_scratch = nullptr; // this device's copy of `scratch` (device address), set by svtme_create
     svtme_config        cfg{};
     std::mutex          mu;
+    std::condition_variable cv_sync_readers; // a slot's last global-motion / TPL reader has left, or a put has been enqueued (with mu)
     hipStream_t         s_store[2] = {nullptr, nullptr}, s_me[4] = {nullptr, nullptr, nullptr, nullptr}, s_copy = nullptr;
     unsigned            next_me = 0, next_upload = 0, n_upload = 1;
     int                 copy_on_search_stream = -1; // -1: with three search streams only; 0 / 1: diagnostic override
@@ -285,7 +289,7 @@ extern "C" int svtme_create(const svtme_config *cfg, svtme_engine **out) {
     e->static_scratch = static_scratch_of(cfg->device);
     if (!e->static_scratch) return fail(SVTME_ERR_DEVICE);
     if (const char *v = getenv("SVTME_UPLOAD_RINGS")) e->n_upload = atoi(v) == 2 ? 2 : 1;
-    // (only the streams that will carry work: every stream beyond the hardware queues shares one with another stream)
+    // (s_me[0..2] carry the searches, s_me[3] the allocation-free search and the synchronous global-motion / TPL calls)
     if (hipStreamCreateWithFlags(&e->s_store[0], hipStreamNonBlocking) != hipSuccess ||
         (e->n_upload == 2 && hipStreamCreateWithFlags(&e->s_store[1], hipStreamNonBlocking) != hipSuccess) ||
         hipStreamCreateWithFlags(&e->s_me[0], hipStreamNonBlocking) != hipSuccess ||
@@ -404,8 +408,17 @@ static int store_put_impl(svtme_engine *e, uint64_t key, uint64_t picture_number
     bool     fresh, wait_upload;
     unsigned ring;
     {
-        std::lock_guard<std::mutex> lock(e->mu);
-        si    = find_slot(e, key, true);
+        std::unique_lock<std::mutex> lock(e->mu);
+        // A rewrite is ordered behind the pictures that read the slot through their events. The synchronous readers
+        // (svtme_gm_*, svtme_tpl_search) record none: the put waits here until they have returned.
+        for (;;) {
+            si = find_slot(e, key, true);
+            if (si < 0 || e->slots[si].sync_readers == 0) break;
+            Slot &w = e->slots[si];
+            w.put_waiting++; // (readers that arrive from now on let this put go first)
+            e->cv_sync_readers.wait(lock);
+            w.put_waiting--;
+        }
         fresh = si < 0;
         if (fresh) {
             for (size_t i = 0; i < e->slots.size(); ++i)
@@ -429,6 +442,7 @@ static int store_put_impl(svtme_engine *e, uint64_t key, uint64_t picture_number
         std::lock_guard<std::mutex> lock(e->mu);
         s.putting = false;
         if (fresh) s.used = false;
+        e->cv_sync_readers.notify_all();
         return code;
     };
     // ---- outside the lock: the slot's staging buffer is free once its previous upload has run, whether or not the slot
@@ -466,6 +480,7 @@ static int store_put_impl(svtme_engine *e, uint64_t key, uint64_t picture_number
     }
     if (err == hipSuccess) err = hipEventRecord(s.ready, ss);
     s.putting = false;
+    e->cv_sync_readers.notify_all(); // global-motion / TPL calls that met the slot while it was being put
     if (err != hipSuccess) {
         fprintf(stderr, "svtme: svtme_store_put: %s\n", hipGetErrorString(err));
         (void)hipStreamSynchronize(ss); // nothing of a failed put stays in flight
@@ -900,6 +915,20 @@ extern "C" int svtme_picture_search_static(svtme_engine *e, const svtme_picture 
     if (pic->tail.enable) return SVTME_ERR_UNSUPPORTED; // the device tail's outputs are not part of this form's result block
     if (e->cfg.serial_hme) return SVTME_ERR_UNSUPPORTED;
     if (reinterpret_cast<uintptr_t>(result_block) % 64) return SVTME_ERR_BAD_ARG;
+    {
+        // the kernels write into the block: it has to be device memory or page-locked host memory (pageable memory would
+        // be a GPU memory fault, not an error code). hipPointerGetAttributes allocates nothing.
+        DeviceGuard guard(e->cfg.device);
+        if (!guard.ok) return SVTME_ERR_DEVICE;
+        hipPointerAttribute_t attr;
+        memset(&attr, 0, sizeof(attr));
+        const hipError_t perr = hipPointerGetAttributes(&attr, result_block);
+        if (perr != hipSuccess || (attr.type != hipMemoryTypeDevice && attr.type != hipMemoryTypeHost && attr.type != hipMemoryTypeManaged)) {
+            (void)hipGetLastError();
+            fprintf(stderr, "svtme: svtme_picture_search_static: result_block is neither device memory nor page-locked host memory\n");
+            return SVTME_ERR_BAD_ARG;
+        }
+    }
     const size_t n_b64 = (size_t)((pic->width + 63) / 64) * ((pic->height + 63) / 64);
     if (n_b64 > SVTME_STATIC_MAX_B64) {
         fprintf(stderr, "svtme: svtme_picture_search_static takes pictures of at most %d 64x64 blocks (3840x2160); %ux%u has %zu\n",
@@ -933,7 +962,9 @@ extern "C" int svtme_picture_search_static(svtme_engine *e, const svtme_picture 
 
     // The array keeps the last call's contents, so what the kernels expect to start from zero (HME records, counters) is
     // cleared here whatever the last call left.
-    const hipStream_t sm = e->s_me[3]; // created by svtme_create, used by this entry point only
+    // (created by svtme_create; the global-motion and TPL calls queue on the same stream under their own lock: a static
+    // search and such a call take turns on it, in the order they were queued)
+    const hipStream_t sm = e->s_me[3];
     for (int i = 0; i < n_used; ++i) HIP_TRY(hipStreamWaitEvent(sm, e->slots[used[i]].ready, 0));
     HIP_TRY(hipMemsetAsync(sc, 0, n_b64 * SVTME_MAX_LISTS * SVTME_MAX_REFS * sizeof(HmeRefOut), sm));
     HIP_TRY(hipMemsetAsync(sc + kStaticOpsOff, 0, SVTME_OPS_BYTES, sm));
@@ -947,6 +978,14 @@ extern "C" int svtme_picture_search_static(svtme_engine *e, const svtme_picture 
     if (launch_err != hipSuccess || sync_err != hipSuccess) {
         fprintf(stderr, "svtme: svtme_picture_search_static: %s\n", hipGetErrorString(launch_err != hipSuccess ? launch_err : sync_err));
         return SVTME_ERR_DEVICE;
+    }
+    {
+        // the search kernels flag a work-item grid smaller than a window needs (a sizing bug, never a data condition), as
+        // svtme_picture_wait reports it: 8 bytes of the block's counter area, read back whatever memory the block is
+        unsigned long long flag[SVTME_OPS_SLOTS];
+        HIP_TRY(hipMemcpy2D(flag, 8, res + lay.off_ops + 7 * 8, 64, 8, SVTME_OPS_SLOTS, hipMemcpyDefault));
+        for (int s = 0; s < SVTME_OPS_SLOTS; ++s)
+            if (flag[s]) return SVTME_ERR_DEVICE;
     }
     out->n_b64                = (uint32_t)n_b64;
     out->p_sb_best_sad        = reinterpret_cast<const uint32_t *>(res + lay.off_sad);
@@ -1121,15 +1160,22 @@ struct GmPlanes {
     uint64_t      gen[kMax];
     explicit GmPlanes(svtme_engine *e_) : e(e_) {}
     int take(const uint64_t *keys, int count, int level) {
-        std::lock_guard<std::mutex> lock(e->mu);
+        std::unique_lock<std::mutex> lock(e->mu);
         for (int i = 0; i < count; ++i) {
-            const int si = find_slot(e, keys[i]);
+            int si;
+            // a key that is being put (its planes are on their way), or whose put waits for earlier readers: after that put
+            for (;;) {
+                si = find_slot(e, keys[i], true);
+                if (si < 0 || (!e->slots[si].putting && e->slots[si].put_waiting == 0)) break;
+                e->cv_sync_readers.wait(lock);
+            }
             if (si < 0) {
                 drop_locked();
                 return SVTME_ERR_NOT_FOUND;
             }
             Slot &s = e->slots[si];
             s.readers++;
+            s.sync_readers++;
             slot[n]  = si;
             plane[n] = s.pic.lvl[2 - level]; // GM_FULL 0 -> the full plane, GM_DOWN 1 -> quarter, GM_DOWN16 2 -> sixteenth
             ready[n] = s.ready;
@@ -1139,14 +1185,17 @@ struct GmPlanes {
         return SVTME_OK;
     }
     void drop_locked() {
+        bool wake = false;
         for (int i = 0; i < n; ++i) {
             Slot &s = e->slots[slot[i]];
+            if (--s.sync_readers == 0) wake = true;
             if (--s.readers == 0 && s.release_pending) {
                 s.used            = false;
                 s.release_pending = false;
             }
         }
         n = 0;
+        if (wake) e->cv_sync_readers.notify_all();
     }
     ~GmPlanes() {
         if (n) {
@@ -1200,7 +1249,8 @@ extern "C" int svtme_gm_set_tables(svtme_engine *e, const int16_t *warped_filter
 }
 
 extern "C" int svtme_gm_corners(svtme_engine *e, uint64_t key, int downsample_level, int32_t *points, int32_t max_points, int32_t *num_points) {
-    if (!e || !points || !num_points || max_points < 0 || downsample_level < 0 || downsample_level > 2) return SVTME_ERR_BAD_ARG;
+    if (!e || !points || !num_points || max_points < 0 || max_points > SVTME_GM_MAX_CORNERS || downsample_level < 0 || downsample_level > 2)
+        return SVTME_ERR_BAD_ARG;
     DEVICE_OR_FAIL(e->cfg.device);
     std::lock_guard<std::mutex> gm_lock(e->gm.mu);
     if (const int rc = gm_init(e)) return rc;
@@ -1289,7 +1339,10 @@ extern "C" int svtme_tpl_search(svtme_engine *e, const svtme_tpl_picture *pic, s
     if (!e || !pic || !out || !pic->total_me_candidate_index || !pic->me_candidate_array || !pic->me_mv_array) return SVTME_ERR_BAD_ARG;
     if (pic->width < 64 || pic->height < 64 || pic->width > e->cfg.max_width || pic->height > e->cfg.max_height || pic->width % 8 ||
         pic->height % 8 || pic->dispenser_search_level > 2 || pic->n_ref[0] > SVTME_MAX_REFS || pic->n_ref[1] > SVTME_MAX_REFS ||
-        (pic->n_pu != SVTME_PU_COUNT && pic->n_pu != 21) || pic->max_cand == 0 || pic->max_refs == 0 ||
+        // MeSbResults holds 85, 21 (no 8x8 partitions) or 5 (no 16x16 either) entries per block (EbPictureControlSet.c:112-117);
+        // the blocks' 16x16 entries are read unless enable_me_16x16 is 0, the 32x32 ones then (:827-828)
+        (pic->n_pu != SVTME_PU_COUNT && pic->n_pu != 21 && !(pic->n_pu == 5 && !pic->enable_me_16x16)) || pic->max_cand == 0 ||
+        pic->max_refs == 0 ||
         pic->max_l0 + (pic->n_ref[1] ? pic->n_ref[1] : 0) > pic->max_refs || pic->n_ref[0] > pic->max_l0)
         return SVTME_ERR_BAD_ARG;
     // transform-domain costs are there for whole 16x16 transforms, the source distortion for the transforms the tpl levels

@@ -448,7 +448,11 @@ __device__ __forceinline__ void tpl_block(ConstTplParams &p, int b64, int bi, in
 
     int me_off = kTplMeIndex[bi]; // :826-834
     if (!p.enable_me_16x16) me_off = (me_off - 1) / 4;
-    const int      n_cand = p.i_slice ? 0 : p.cnt[(size_t)b64 * p.n_pu + me_off];
+    int            n_cand = p.i_slice ? 0 : p.cnt[(size_t)b64 * p.n_pu + me_off];
+    if (n_cand > p.max_cand) { // a count the arrays cannot hold: flagged (the call returns SVTME_ERR_BAD_ARG), not followed
+        if (lane == 0) atomicOr(p.error, 2);
+        n_cand = p.max_cand;
+    }
     const uint8_t *cand   = p.cand + ((size_t)b64 * p.n_pu + me_off) * p.max_cand;
     const uint32_t *mvs   = p.mv + ((size_t)b64 * p.n_pu + me_off) * p.max_refs;
     for (int ci = 0; ci < n_cand; ++ci) { // :836-930

@@ -134,3 +134,41 @@ def test_gm_error_codes_and_cache_after_a_new_put():
         assert len(c) and np.array_equal(c[:, :2], c[:, 2:])
     finally:
         eng.close()
+
+
+def test_a_put_of_a_key_waits_for_the_global_motion_call_that_reads_it():
+    """A source picture rewritten (same key) while svtme_gm_correspondences reads its planes: the put waits for the call,
+    so every result is one of the two clean outcomes, never a mixture of the old and the new planes."""
+    import threading
+    import svtme
+    name = next(iter(gm_cases.CASES))
+    case = gm_cases.CASES[name]
+    eng, frames = _engine(case)
+    try:
+        job = case["jobs"][0]
+        cur, ref, lvl = 100 + job["cur"], 100 + job["ref"], job["level"]
+        old = np.ascontiguousarray(frames[job["ref"]])
+        new = np.ascontiguousarray(old[::-1, ::-1])
+        clean = [eng.gm_correspondences(cur, ref, lvl)]
+        eng.store_put(ref, job["ref"], new)
+        clean.append(eng.gm_correspondences(cur, ref, lvl))
+        assert not np.array_equal(clean[0], clean[1])
+        eng.store_put(ref, job["ref"], old)
+
+        def putter():
+            for i in range(30):
+                eng.store_put(ref, job["ref"], new if i % 2 == 0 else old)
+
+        t = threading.Thread(target=putter)
+        t.start()
+        results = []
+        while t.is_alive() or len(results) < 4:
+            results.append(eng.gm_correspondences(cur, ref, lvl))
+        t.join()
+        for r in results:
+            assert any(np.array_equal(r, c) for c in clean)
+        with pytest.raises(svtme.SvtmeError) as ei:  # more corners than the engine's lists hold
+            eng.gm_corners(cur, lvl, max_points=svtme.GM_MAX_CORNERS + 1)
+        assert ei.value.code == svtme.ERR_BAD_ARG
+    finally:
+        eng.close()

@@ -129,6 +129,14 @@ def test_unsupported_controls_and_bad_arguments():
         with pytest.raises(svtme.SvtmeError) as ei:
             eng.tpl_search(p)
         assert ei.value.code == svtme.ERR_BAD_ARG
+        # a candidate count the arrays cannot hold
+        bad = dict(me)
+        bad["total_me_candidate_index"] = np.array(me["total_me_candidate_index"], copy=True)
+        bad["total_me_candidate_index"][0, :] = me["max_cand"] + 1
+        p, keep, refs = picture_of(frames, pic, ctrl, bad)
+        with pytest.raises(svtme.SvtmeError) as ei:
+            eng.tpl_search(p)
+        assert ei.value.code == svtme.ERR_BAD_ARG
         # a key the store does not hold; a picture size the store's planes do not have
         p, keep, refs = picture_of(frames, pic, ctrl, me)
         p.ref_key[0][0] = 9999

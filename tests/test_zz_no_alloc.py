@@ -144,6 +144,14 @@ def test_static_scratch_entry_point_rejects_what_it_cannot_hold():
         with pytest.raises(svtme.SvtmeError) as ei:  # result block too small
             eng.search_static(pic, block, svtme.static_result_bytes(4, 1) - 1)
         assert ei.value.code == svtme.ERR_BAD_ARG
+        # pageable host memory (numpy's) is neither device memory nor page-locked: refused, not a GPU memory fault
+        pageable = np.zeros(svtme.static_result_bytes(4, 1) + 64, np.uint8)
+        addr = (pageable.ctypes.data + 63) & ~63
+        with pytest.raises(svtme.SvtmeError) as ei:
+            eng.search_static(pic, C.c_void_p(addr), svtme.static_result_bytes(4, 1))
+        assert ei.value.code == svtme.ERR_BAD_ARG
+        r = eng.search_static(pic, block, 1 << 16)  # and the same picture into the page-locked block goes through
+        assert r.n_b64 == 4
         with pytest.raises(svtme.SvtmeError) as ei:  # the device tail is not part of this form
             pic.tail = svtme.Tail(enable=1, enable_me_8x8=1, enable_me_16x16=1, max_refs=1, max_cand=1, max_l0=1)
             eng.search_static(pic, block, 1 << 16)
