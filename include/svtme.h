@@ -166,6 +166,27 @@ void svtme_destroy(svtme_engine *e);
 int svtme_store_put(svtme_engine *e, uint64_t key, uint64_t picture_number, const uint8_t *luma,
                     uint32_t stride, uint32_t width, uint32_t height);
 /*
+ * The same for the n source pictures that become final together - the pictures of a mini-GOP after their temporal
+ * filtering, right before send_picture_out posts them (EbPictureDecisionProcess.c:6815-6827): one pass over the store's
+ * bookkeeping, n uploads queued back to back and ONE launch of each store-building kernel for all of them, instead of
+ * two launches per picture. All pictures have the size width x height and rows `stride` apart; keys[i] / lumas[i] /
+ * picture_numbers[i] belong to picture i; n <= SVTME_MAX_PUT_BATCH. pinned != 0: the rows are fetched by DMA from the
+ * callers' page-locked buffers as they lie (the rules of svtme_store_put_pinned apply to every buffer), else they are
+ * packed into the engine's staging buffers first and the callers' buffers are free on return. Either all pictures are
+ * put or none (an error leaves the store as it was, except that keys that existed before keep their slots).
+ */
+#define SVTME_MAX_PUT_BATCH 16
+int svtme_store_put_many(svtme_engine *e, uint32_t n, const uint64_t *keys, const uint64_t *picture_numbers,
+                         const uint8_t *const *lumas, uint32_t stride, uint32_t width, uint32_t height, int pinned);
+/*
+ * Copies the three built planes of `key` from another engine's store (another GPU of the node) into this one's, device
+ * to device - over xGMI where the GPUs are peers - instead of a second upload over PCIe and a second run of the
+ * store-building kernels. No counterpart in the reference (it has one address space). Both engines must have been
+ * created with the same max_width / max_height. Synchronous: returns when the planes have arrived, so that the source
+ * slot may be rewritten or released right after; SVTME_ERR_NOT_FOUND if `src` does not hold the key.
+ */
+int svtme_store_copy_peer(svtme_engine *dst, svtme_engine *src, uint64_t key);
+/*
  * The same put without the host-side frame copy, for luma that already lies in page-locked memory: the rows are fetched
  * by DMA from the caller's buffer as they lie, `stride` apart (the encoder's y8b input buffers, the pool created at
  * Source/Lib/Encoder/Globals/EbEncHandle.c:1778-1787 by svt_input_y8b_creator, which the PA reference object's full
@@ -401,15 +422,25 @@ int svtme_unpack_b64(const svtme_results *res, uint32_t b64_index, uint32_t *p_s
  * Several engines, one per GPU of a node, behind one handle: the picture-sharding scheduler. It has no counterpart in the
  * reference (which has one address space); it sits where send_picture_out() posts the pictures of a mini-GOP back to back
  * (EbPictureDecisionProcess.c:5031-5125, :6842-6874). Open-loop ME reads source pictures only, so those pictures are
- * independent: picture i of the submit order runs on engine i mod N. svtme_group_store_put only announces a source (the
+ * independent: svtme_group_pictures_submit takes a mini-GOP's pictures (the constraints of svtme_pictures_submit apply),
+ * gives each to the engine where it ends earliest - the engines' accumulated estimated work plus the picture's own and
+ * what it costs to bring the sources it lacks there - and submits every engine's share as one batch;
+ * svtme_group_picture_submit is the same for one picture. svtme_group_store_put only announces a source (the
  * buffer must stay valid and unchanged until svtme_group_store_release: true of the encoder's y8b buffers, which live as
- * long as their PA reference object; `pinned` != 0 says it is page-locked, see svtme_store_put_pinned); the group uploads
+ * long as their PA reference object; `pinned` != 0 says it is page-locked, see svtme_store_put_pinned); the group brings
  * it to an engine the first time a picture that runs there reads it, so every source reaches exactly the GPUs that need
- * it. Announcing an existing key again (the temporal filter rewrote the planes) makes every copy stale. Results come
- * from each GPU to its own pinned host buffers: no exchange between GPUs, no collective. `cfg` applies to every engine
- * (its `device` is replaced by devices[i]; the same device may appear more than once). Tickets of a group are only
- * valid with the group's wait / done. svtme_group_stats: pictures submitted, sources announced, uploads made (uploads /
- * sources = how many GPUs a source travels to on average).
+ * it: as a device-to-device copy of the built planes from an engine that holds them already (svtme_store_copy_peer: two
+ * engines on one GPU, or two GPUs that are peers - over xGMI -; svtme_group_set_peer_copies(g, 0) turns that off), else as
+ * an upload from the host, the sources an engine lacks for a batch in one svtme_store_put_many. Announcing an existing key
+ * again (the temporal filter rewrote the planes) makes every copy stale; the release frees the key's slot on every engine
+ * that ever took a copy. Results come from each GPU to its own pinned host buffers: no exchange between GPUs inside a
+ * picture, no collective. `cfg` applies to every engine (its `device` is replaced by devices[i]; the same device may
+ * appear more than once; at most 56 engines). Tickets of a group are only valid with the group's wait / done;
+ * svtme_group_ticket_engine says which engine (index into devices[]) runs the picture. If a submit fails part of the way
+ * (an engine out of resources), the tickets that are not 0 on return were submitted and are waited for and handed back
+ * as usual. svtme_group_stats: pictures submitted, sources announced, uploads made ((uploads + peer copies) / sources = how
+ * many GPUs a source travels to on average); svtme_group_peer_stats: device-to-device copies made, and how many
+ * (engine, engine) directions can copy that way.
  */
 typedef struct svtme_group svtme_group;
 int      svtme_group_create(const int32_t *devices, uint32_t n_devices, const svtme_config *cfg, svtme_group **out);
@@ -419,6 +450,10 @@ int svtme_group_store_put(svtme_group *g, uint64_t key, uint64_t picture_number,
                           uint32_t width, uint32_t height, int pinned);
 int svtme_group_store_release(svtme_group *g, uint64_t key);
 int svtme_group_picture_submit(svtme_group *g, const svtme_picture *pic, svtme_ticket *ticket);
+int svtme_group_pictures_submit(svtme_group *g, const svtme_picture *pics, uint32_t n, svtme_ticket *tickets);
+uint32_t svtme_group_ticket_engine(svtme_ticket ticket);
+int svtme_group_set_peer_copies(svtme_group *g, int enable);
+int svtme_group_peer_stats(svtme_group *g, uint64_t *peer_copies, uint64_t *peer_links);
 int svtme_group_picture_wait(svtme_group *g, svtme_ticket ticket, svtme_results *out);
 int svtme_group_picture_done(svtme_group *g, svtme_ticket ticket);
 int svtme_group_stats(svtme_group *g, uint64_t *pictures, uint64_t *sources, uint64_t *uploads);

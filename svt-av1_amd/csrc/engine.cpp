@@ -199,6 +199,7 @@ struct svtme_engine {
     size_t              slot_bytes = 0, max_b64 = 0;
     uint8_t            *d_upload[2] = {nullptr, nullptr}; // un-padded luma of the pictures being put (a store stream orders the reuse of its buffer)
     size_t              upload_bytes = 0;
+    uint8_t            *d_upload_many = nullptr; // the same for svtme_store_put_many: SVTME_MAX_PUT_BATCH pictures (its first call allocates)
     GmState             gm;
     uint64_t            put_gen = 0;
     // the sequence's tiles per 64x64 block (svtme_set_tile_rects): room for max_b64 records, valid for pictures of
@@ -367,6 +368,7 @@ extern "C" void svtme_destroy(svtme_engine *e) {
     }
     for (auto d : e->d_upload)
         if (d) (void)hipFree(d);
+    if (e->d_upload_many) (void)hipFree(e->d_upload_many);
     for (auto &f : e->flights) free_flight(f);
     if (e->d_res_arena) (void)hipFree(e->d_res_arena);
     if (e->h_res_arena) (void)hipHostFree(e->h_res_arena);
@@ -500,6 +502,240 @@ extern "C" int svtme_store_put(svtme_engine *e, uint64_t key, uint64_t picture_n
 extern "C" int svtme_store_put_pinned(svtme_engine *e, uint64_t key, uint64_t picture_number, const uint8_t *luma, uint32_t stride,
                                       uint32_t width, uint32_t height) {
     return store_put_impl(e, key, picture_number, luma, stride, width, height, true);
+}
+
+// The n pictures of a mini-GOP in one go: the slots are reserved in one pass under the lock, the frame copies (when the
+// rows are not page-locked) run outside it, then n uploads and one launch of each store-building kernel are queued.
+extern "C" int svtme_store_put_many(svtme_engine *e, uint32_t n, const uint64_t *keys, const uint64_t *picture_numbers,
+                                    const uint8_t *const *lumas, uint32_t stride, uint32_t width, uint32_t height, int pinned) {
+    if (!e || !keys || !picture_numbers || !lumas || n < 1 || n > SVTME_MAX_PUT_BATCH || width < 64 || height < 64 || width % 8 ||
+        height % 8 || width > e->cfg.max_width || height > e->cfg.max_height || stride < width)
+        return SVTME_ERR_BAD_ARG;
+    for (uint32_t i = 0; i < n; ++i) {
+        if (!lumas[i]) return SVTME_ERR_BAD_ARG;
+        for (uint32_t j = 0; j < i; ++j)
+            if (keys[j] == keys[i]) return SVTME_ERR_BAD_ARG;
+    }
+    if (pinned && (stride % 4 || stride - width > kMaxExtraStride)) pinned = 0;
+    DEVICE_OR_FAIL(e->cfg.device);
+    int  si[SVTME_MAX_PUT_BATCH];
+    bool fresh[SVTME_MAX_PUT_BATCH], wait_upload[SVTME_MAX_PUT_BATCH];
+    {
+        std::unique_lock<std::mutex> lock(e->mu);
+        if (!e->d_upload_many && hipMalloc((void **)&e->d_upload_many, e->upload_bytes * SVTME_MAX_PUT_BATCH) != hipSuccess) {
+            (void)hipGetLastError();
+            return SVTME_ERR_NO_RESOURCES;
+        }
+        // existing keys first wait for their synchronous readers (see store_put_impl): until none of the keys has any
+        for (bool again = true; again;) {
+            again = false;
+            for (uint32_t i = 0; i < n && !again; ++i) {
+                const int s0 = find_slot(e, keys[i], true);
+                if (s0 < 0 || e->slots[s0].sync_readers == 0) continue;
+                Slot &w = e->slots[s0];
+                w.put_waiting++;
+                e->cv_sync_readers.wait(lock);
+                w.put_waiting--;
+                again = true;
+            }
+        }
+        uint32_t got = 0;
+        int      rc = SVTME_OK;
+        for (; got < n && rc == SVTME_OK; ++got) {
+            int s0 = find_slot(e, keys[got], true);
+            fresh[got] = s0 < 0;
+            if (s0 < 0)
+                for (size_t k = 0; k < e->slots.size() && s0 < 0; ++k)
+                    if (!e->slots[k].used) s0 = (int)k;
+            if (s0 < 0) rc = SVTME_ERR_NO_RESOURCES;
+            else if (e->slots[s0].putting) rc = SVTME_ERR_BAD_ARG; // two puts of one key at the same time
+            if (rc != SVTME_OK) break;
+            Slot &s = e->slots[s0];
+            s.used = s.putting = true;
+            s.release_pending  = false;
+            s.key              = keys[got];
+            wait_upload[got]   = s.uploaded;
+            si[got]            = s0;
+        }
+        if (rc != SVTME_OK) {
+            for (uint32_t i = 0; i < got; ++i) {
+                e->slots[si[i]].putting = false;
+                if (fresh[i]) e->slots[si[i]].used = false;
+            }
+            e->cv_sync_readers.notify_all();
+            return rc;
+        }
+    }
+    auto undo = [&](int code) {
+        std::lock_guard<std::mutex> lock(e->mu);
+        for (uint32_t i = 0; i < n; ++i) {
+            e->slots[si[i]].putting = false;
+            if (fresh[i]) e->slots[si[i]].used = false;
+        }
+        e->cv_sync_readers.notify_all();
+        return code;
+    };
+    // ---- outside the lock: the frame copies
+    const uint8_t *src[SVTME_MAX_PUT_BATCH];
+    uint32_t       src_stride = stride;
+    size_t         bytes      = (size_t)(height - 1) * stride + width;
+    for (uint32_t i = 0; i < n; ++i) src[i] = lumas[i];
+    if (!pinned) {
+        for (uint32_t i = 0; i < n; ++i) {
+            Slot &s = e->slots[si[i]];
+            if (wait_upload[i] && hipEventSynchronize(s.ready) != hipSuccess) return undo(SVTME_ERR_DEVICE);
+            if (stride == width) memcpy(s.host_stage, lumas[i], (size_t)width * height);
+            else
+                for (uint32_t y = 0; y < height; ++y) memcpy(s.host_stage + (size_t)y * width, lumas[i] + (size_t)y * stride, width);
+            src[i] = s.host_stage;
+        }
+        src_stride = width;
+        bytes      = (size_t)width * height;
+    }
+    // ---- enqueue
+    std::lock_guard<std::mutex> lock(e->mu);
+    const hipStream_t ss = e->s_store[0];
+    hipError_t        err = hipSuccess;
+    StoreBatch        b;
+    memset(&b, 0, sizeof(b));
+    for (uint32_t i = 0; i < n && err == hipSuccess; ++i) {
+        Slot &s = e->slots[si[i]];
+        for (int m = 0; m < 4 && err == hipSuccess; ++m) // rewrite after the readers
+            if (s.read_recorded[m]) err = hipStreamWaitEvent(ss, s.last_read[m], 0);
+        if (err == hipSuccess && s.uploaded) err = hipStreamWaitEvent(ss, s.ready, 0);
+        s.picture_number = picture_numbers[i];
+        s.width          = width;
+        s.height         = height;
+        s.gen            = ++e->put_gen;
+        size_t plane_bytes;
+        layout_planes(s.mem, width, height, &s.pic, &plane_bytes);
+        uint8_t *up = e->d_upload_many + (size_t)i * e->upload_bytes;
+        if (err == hipSuccess) err = hipMemcpyAsync(up, src[i], bytes, hipMemcpyHostToDevice, ss);
+        b.luma[i]   = up;
+        b.stride[i] = (int32_t)src_stride;
+        b.pic[i]    = s.pic;
+    }
+    if (err == hipSuccess) {
+        launch_store_build_many(b, (int)n, 1, ss);
+        err = hipGetLastError();
+    }
+    // (one point of the stream marks all of them built; every slot keeps an event of its own)
+    for (uint32_t i = 0; i < n && err == hipSuccess; ++i) err = hipEventRecord(e->slots[si[i]].ready, ss);
+    for (uint32_t i = 0; i < n; ++i) e->slots[si[i]].putting = false;
+    e->cv_sync_readers.notify_all();
+    if (err != hipSuccess) {
+        fprintf(stderr, "svtme: svtme_store_put_many: %s\n", hipGetErrorString(err));
+        (void)hipStreamSynchronize(ss);
+        for (uint32_t i = 0; i < n; ++i)
+            if (fresh[i]) e->slots[si[i]].used = false;
+        return SVTME_ERR_DEVICE;
+    }
+    for (uint32_t i = 0; i < n; ++i) {
+        Slot &s = e->slots[si[i]];
+        s.uploaded = true;
+        s.ready_seen[0] = s.ready_seen[1] = s.ready_seen[2] = s.ready_seen[3] = false;
+    }
+    return SVTME_OK;
+}
+
+// Device-to-device replication of a built slot from another engine (another GPU): one copy of the slot's three planes.
+extern "C" int svtme_store_copy_peer(svtme_engine *dst, svtme_engine *src, uint64_t key) {
+    if (!dst || !src || dst == src || dst->slot_bytes != src->slot_bytes) return SVTME_ERR_BAD_ARG;
+    // the source slot: held like a synchronous reader for the duration of the copy
+    int        ssi;
+    Slot       from;
+    {
+        std::unique_lock<std::mutex> lock(src->mu);
+        for (;;) {
+            ssi = find_slot(src, key, true);
+            if (ssi < 0 || (!src->slots[ssi].putting && src->slots[ssi].put_waiting == 0)) break;
+            src->cv_sync_readers.wait(lock);
+        }
+        if (ssi < 0) return SVTME_ERR_NOT_FOUND;
+        Slot &s = src->slots[ssi];
+        s.readers++;
+        s.sync_readers++;
+        from = s; // (descriptor and event handle: plain values)
+    }
+    auto release_src = [&]() {
+        std::lock_guard<std::mutex> lock(src->mu);
+        Slot &s = src->slots[ssi];
+        if (--s.sync_readers == 0) src->cv_sync_readers.notify_all();
+        if (--s.readers == 0 && s.release_pending) {
+            s.used            = false;
+            s.release_pending = false;
+        }
+    };
+    int rc = SVTME_OK;
+    {
+        DeviceGuard guard(dst->cfg.device);
+        if (!guard.ok) {
+            release_src();
+            return SVTME_ERR_DEVICE;
+        }
+        int  di;
+        bool fresh;
+        {
+            std::unique_lock<std::mutex> lock(dst->mu);
+            for (;;) {
+                di = find_slot(dst, key, true);
+                if (di < 0 || dst->slots[di].sync_readers == 0) break;
+                Slot &w = dst->slots[di];
+                w.put_waiting++;
+                dst->cv_sync_readers.wait(lock);
+                w.put_waiting--;
+            }
+            fresh = di < 0;
+            if (fresh)
+                for (size_t k = 0; k < dst->slots.size() && di < 0; ++k)
+                    if (!dst->slots[k].used) di = (int)k;
+            if (di < 0) rc = SVTME_ERR_NO_RESOURCES;
+            else if (dst->slots[di].putting) rc = SVTME_ERR_BAD_ARG;
+            if (rc == SVTME_OK) {
+                Slot &d = dst->slots[di];
+                d.used = d.putting = true;
+                d.release_pending  = false;
+                d.key              = key;
+            }
+        }
+        if (rc == SVTME_OK) {
+            Slot             &d  = dst->slots[di];
+            const hipStream_t ss = dst->s_store[0];
+            hipError_t        err = hipSuccess;
+            {
+                std::lock_guard<std::mutex> lock(dst->mu);
+                for (int m = 0; m < 4 && err == hipSuccess; ++m)
+                    if (d.read_recorded[m]) err = hipStreamWaitEvent(ss, d.last_read[m], 0);
+                if (err == hipSuccess && d.uploaded) err = hipStreamWaitEvent(ss, d.ready, 0);
+                if (err == hipSuccess) err = hipStreamWaitEvent(ss, from.ready, 0); // the source planes are built (an event of the other device)
+                size_t plane_bytes = 0;
+                d.picture_number = from.picture_number;
+                d.width          = from.width;
+                d.height         = from.height;
+                d.gen            = ++dst->put_gen;
+                layout_planes(d.mem, d.width, d.height, &d.pic, &plane_bytes);
+                if (err == hipSuccess)
+                    err = hipMemcpyPeerAsync(d.mem, dst->cfg.device, from.mem, src->cfg.device, plane_bytes, ss);
+                if (err == hipSuccess) err = hipEventRecord(d.ready, ss);
+            }
+            if (err == hipSuccess) err = hipEventSynchronize(d.ready); // outside the lock: the source slot is free after this
+            std::lock_guard<std::mutex> lock(dst->mu);
+            d.putting = false;
+            dst->cv_sync_readers.notify_all();
+            if (err != hipSuccess) {
+                fprintf(stderr, "svtme: svtme_store_copy_peer: %s\n", hipGetErrorString(err));
+                (void)hipStreamSynchronize(ss);
+                (void)hipGetLastError();
+                if (fresh) d.used = false;
+                rc = SVTME_ERR_DEVICE;
+            } else {
+                d.uploaded = true;
+                d.ready_seen[0] = d.ready_seen[1] = d.ready_seen[2] = d.ready_seen[3] = false;
+            }
+        }
+    }
+    release_src();
+    return rc;
 }
 
 extern "C" int svtme_store_wait(svtme_engine *e, uint64_t key) {

@@ -166,6 +166,14 @@ struct Batch {
 
 // store kernels (store_kernels.hip)
 void launch_store_build(const uint8_t *luma, int luma_stride, const DevPicture &pic, int hme_level1, hipStream_t s);
+// the same for n <= SVTME_MAX_PUT_BATCH pictures of one size in one launch of each kernel
+struct StoreBatch {
+    const uint8_t *luma[SVTME_MAX_PUT_BATCH]; // un-padded luma in device memory
+    int32_t        stride[SVTME_MAX_PUT_BATCH];
+    DevPicture     pic[SVTME_MAX_PUT_BATCH];
+    unsigned long long m_side[3], m_pw[3]; // per plane: ceil(2^40 / (2 pad)), ceil(2^40 / (width + 2 pad)); filled by the launcher
+};
+void launch_store_build_many(StoreBatch &b, int n, int hme_level1, hipStream_t s);
 // search kernels
 // Each launcher records marks[i] (when not null) on the stream after its i-th kernel (timing only). The buffers hold
 // zeroed hme_out and operation counters on entry (me_finish_kernel leaves them so).

@@ -121,8 +121,11 @@ EXPORTS = ("svtme_version", "svtme_derive_controls", "svtme_derive_tf_controls",
            "svtme_group_picture_submit", "svtme_group_picture_wait", "svtme_group_picture_done", "svtme_group_stats",
            "svtme_group_engine_for", "svtme_group_gm_set_tables",
            "svtme_gm_set_tables", "svtme_gm_corners", "svtme_gm_correspondences", "svtme_gm_warp_error", "svtme_gm_frame_error",
-           "svtme_tpl_search", "svtme_set_tile_rects", "svtme_group_set_tile_rects")
+           "svtme_tpl_search", "svtme_set_tile_rects", "svtme_group_set_tile_rects",
+           "svtme_store_put_many", "svtme_store_copy_peer", "svtme_group_pictures_submit", "svtme_group_ticket_engine",
+           "svtme_group_set_peer_copies", "svtme_group_peer_stats")
 MAX_BATCH = 32
+MAX_PUT_BATCH = 16
 GM_MAX_CORNERS = 4096
 
 
@@ -181,6 +184,14 @@ def load_library():
     lib.svtme_store_release.argtypes = [C.c_void_p, C.c_uint64]
     lib.svtme_store_put_pinned.argtypes = lib.svtme_store_put.argtypes
     lib.svtme_store_wait.argtypes = [C.c_void_p, C.c_uint64]
+    lib.svtme_store_put_many.argtypes = [C.c_void_p, C.c_uint32, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.POINTER(C.c_void_p),
+                                         C.c_uint32, C.c_uint32, C.c_uint32, C.c_int]
+    lib.svtme_store_copy_peer.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64]
+    lib.svtme_group_pictures_submit.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.POINTER(C.c_uint64)]
+    lib.svtme_group_ticket_engine.argtypes = [C.c_uint64]
+    lib.svtme_group_ticket_engine.restype = C.c_uint32
+    lib.svtme_group_set_peer_copies.argtypes = [C.c_void_p, C.c_int]
+    lib.svtme_group_peer_stats.argtypes = [C.c_void_p, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
     lib.svtme_host_register.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
     lib.svtme_host_unregister.argtypes = [C.c_void_p, C.c_void_p]
     lib.svtme_host_alloc.argtypes = [C.c_void_p, C.c_size_t, C.POINTER(C.c_void_p)]
@@ -356,12 +367,37 @@ class Group:
             raise SvtmeError(rc, "svtme_group_picture_submit")
         return t.value
 
+    def submit_batch(self, pics):
+        """svtme_group_pictures_submit: the pictures are split over the engines by accumulated work, one batch per engine."""
+        n = len(pics)
+        arr = (Picture * n)(*pics)
+        t = (C.c_uint64 * n)()
+        rc = self.lib.svtme_group_pictures_submit(self.h, arr, n, t)
+        if rc:
+            raise SvtmeError(rc, "svtme_group_pictures_submit")
+        return list(t)
+
+    def engine_of(self, ticket):
+        return int(self.lib.svtme_group_ticket_engine(ticket))
+
+    def set_peer_copies(self, enable):
+        rc = self.lib.svtme_group_set_peer_copies(self.h, int(bool(enable)))
+        if rc:
+            raise SvtmeError(rc, "svtme_group_set_peer_copies")
+
     def wait(self, ticket, copy=True):
         r = Results()
         rc = self.lib.svtme_group_picture_wait(self.h, ticket, C.byref(r))
         if rc:
             raise SvtmeError(rc, "svtme_group_picture_wait")
         return results_to_arrays(r, copy)
+
+    def wait_raw(self, ticket):
+        r = Results()
+        rc = self.lib.svtme_group_picture_wait(self.h, ticket, C.byref(r))
+        if rc:
+            raise SvtmeError(rc, "svtme_group_picture_wait")
+        return r
 
     def done(self, ticket):
         rc = self.lib.svtme_group_picture_done(self.h, ticket)
@@ -395,7 +431,11 @@ class Group:
         rc = self.lib.svtme_group_stats(self.h, *[C.byref(x) for x in v])
         if rc:
             raise SvtmeError(rc, "svtme_group_stats")
-        return dict(pictures=v[0].value, sources=v[1].value, uploads=v[2].value)
+        p = [C.c_uint64() for _ in range(2)]
+        rc = self.lib.svtme_group_peer_stats(self.h, *[C.byref(x) for x in p])
+        if rc:
+            raise SvtmeError(rc, "svtme_group_peer_stats")
+        return dict(pictures=v[0].value, sources=v[1].value, uploads=v[2].value, peer_copies=p[0].value, peer_links=p[1].value)
 
 
 class Engine:
@@ -461,6 +501,28 @@ class Engine:
         rc = self.lib.svtme_store_put_pinned(self.h, key, picture_number, luma.ctypes.data, luma.strides[0], w, h)
         if rc:
             raise SvtmeError(rc, "svtme_store_put_pinned")
+
+    def store_put_many(self, keys, picture_numbers, lumas, pinned=False):
+        """svtme_store_put_many: 2-D uint8 arrays of one size and one row stride (contiguous rows), at most MAX_PUT_BATCH.
+        pinned: the arrays lie in page-locked memory (host_alloc) and stay unchanged until their store_wait."""
+        n = len(keys)
+        if not pinned:
+            lumas = [np.ascontiguousarray(a, dtype=np.uint8) for a in lumas]
+        h, w = lumas[0].shape
+        stride = lumas[0].strides[0]
+        assert all(a.shape == (h, w) and a.strides == (stride, 1) and a.dtype == np.uint8 for a in lumas)
+        k = (C.c_uint64 * n)(*keys)
+        pn = (C.c_uint64 * n)(*picture_numbers)
+        ptr = (C.c_void_p * n)(*[a.ctypes.data for a in lumas])
+        rc = self.lib.svtme_store_put_many(self.h, n, k, pn, ptr, stride, w, h, 1 if pinned else 0)
+        if rc:
+            raise SvtmeError(rc, "svtme_store_put_many")
+
+    def store_copy_from(self, other, key):
+        """svtme_store_copy_peer: the built planes of `key` from another engine's store, device to device."""
+        rc = self.lib.svtme_store_copy_peer(self.h, other.h, key)
+        if rc:
+            raise SvtmeError(rc, "svtme_store_copy_peer")
 
     def store_wait(self, key):
         rc = self.lib.svtme_store_wait(self.h, key)

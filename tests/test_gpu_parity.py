@@ -563,6 +563,47 @@ def test_device_store_planes_match_oracle():
         eng.close()
 
 
+@pytest.mark.parametrize("w,h", [(200, 136), (256, 192), (1920, 1080)])
+def test_batched_put_and_peer_copy_build_the_same_planes(w, h):
+    """svtme_store_put_many (one launch of each store kernel for all pictures; 200 is a width whose last 16-pixel group
+    is half) from pageable and from page-locked rows with the encoder's stride, a batch that overwrites existing keys, and
+    svtme_store_copy_peer into a second engine: byte for byte the planes the oracle builds."""
+    frames, pics, rc = support.make_job(w, h, 5, 8, seed=6)
+    _, planes = refio.run_oracle(frames, [], 8, mode=refio.MODE_PLANES, ref_counts=rc)
+    eng = svtme.Engine(w, h, store_slots=12)
+    other = svtme.Engine(w, h, store_slots=4)
+    pool = eng.host_alloc((5, h + 144, w + 144))
+    try:
+        pool[:] = 0x5A
+        pool[:, 72:72 + h, 72:72 + w] = frames
+        eng.store_put_many([10 + i for i in range(5)], list(range(5)), [frames[i] for i in range(5)])
+        eng.store_put_many([20 + i for i in range(5)], list(range(5)), [pool[i, 72:72 + h, 72:72 + w] for i in range(5)], pinned=True)
+        for base in (10, 20):
+            for i in range(5):
+                for level in range(3):
+                    assert np.array_equal(eng.store_read(base + i, level, frames[i].shape), planes[i][level]), (base, i, level)
+        # the same keys again in another order (a rewrite), one fresh key among them
+        eng.store_put_many([12, 11, 30], [0, 1, 2], [frames[0], frames[1], frames[2]])
+        for key, i in ((12, 0), (11, 1), (30, 2), (10, 0)):
+            assert np.array_equal(eng.store_read(key, 2, frames[i].shape), planes[i][2]), key
+        with pytest.raises(svtme.SvtmeError) as ei:  # one key twice in a batch
+            eng.store_put_many([40, 40], [0, 1], [frames[0], frames[1]])
+        assert ei.value.code == svtme.ERR_BAD_ARG
+        # device to device into another engine's store (here: the same GPU), over a key that engine holds already
+        other.store_put(21, 9, frames[4])
+        for key, i in ((21, 1), (30, 2)):
+            other.store_copy_from(eng, key)
+            for level in range(3):
+                assert np.array_equal(other.store_read(key, level, frames[i].shape), planes[i][level]), (key, level)
+        with pytest.raises(svtme.SvtmeError) as ei:
+            other.store_copy_from(eng, 999)
+        assert ei.value.code == svtme.ERR_NOT_FOUND
+    finally:
+        eng.host_free(pool)
+        other.close()
+        eng.close()
+
+
 def test_zero_copy_put_from_a_strided_page_locked_buffer_builds_the_same_planes():
     """svtme_store_put_pinned: rows fetched by DMA as they lie in the caller's buffer (the encoder's padded input buffer:
     origin (72, 72), stride = width + 144) in page-locked memory from svtme_host_alloc; same planes as the oracle's, also
@@ -1031,51 +1072,84 @@ def test_engine_group_hands_the_tiles_to_every_engine():
 
 
 def test_engine_group_shards_one_sequence_and_moves_sources_only_where_they_are_read():
-    """svtme_group (the in-process multi-GPU path of the C ABI) with two engines on the one GPU of this box: pictures go
-    round robin, every source is uploaded once per engine that reads it, results equal the oracle's; a key announced
+    """svtme_group (the in-process multi-GPU path of the C ABI) with two engines on the one GPU of this box: a mini-GOP
+    handed over at once is split by accumulated work, one batch per engine; every source reaches an engine once, from the
+    host or - the second time - device to device from the engine that has it; results equal the oracle's; a key announced
     again (the temporal filter's rewrite) reaches the engines afresh."""
     frames, pics, rc = support.make_job(256, 128, 17, 8, seed=9)
     recs = support.oracle_handover(frames, pics, 8, rc)
     ctrl = svtme.derive_controls(8, 256, 128)
-    grp = svtme.Group([0, 0], 256, 128, store_slots=20, max_in_flight=4)
-    try:
-        assert grp.lib.svtme_group_size(grp.h) == 2
-        for i in range(len(frames)):
-            grp.store_put(i, i, frames[i])
-        tickets, got = [], {}
-        for i, p in enumerate(pics):
-            if len(tickets) == 6:
-                j, t = tickets.pop(0)
+    for peers in (1, 0):
+        grp = svtme.Group([0, 0], 256, 128, store_slots=20, max_in_flight=16)
+        try:
+            assert grp.lib.svtme_group_size(grp.h) == 2
+            grp.set_peer_copies(peers)
+            for i in range(len(frames)):
+                grp.store_put(i, i, frames[i])
+            descs = [grp.make_picture(256, 128, p.poc, p.temporal_layer, p.is_ref, p.refs, ctrl) for p in pics]
+            tickets = grp.submit_batch(descs[:8]) + grp.submit_batch(descs[8:])
+            got = {}
+            for j, t in enumerate(tickets):
                 got[j] = grp.wait(t)
                 grp.done(t)
-            tickets.append((i, grp.submit(grp.make_picture(256, 128, p.poc, p.temporal_layer, p.is_ref, p.refs, ctrl))))
-        for j, t in tickets:
-            got[j] = grp.wait(t)
+            owners = [grp.engine_of(t) for t in tickets]
+            assert owners == [t >> 56 for t in tickets] and set(owners) == {0, 1}  # both engines took part
+            assert 4 <= owners.count(0) <= 12
+            msgs = []
+            for i, p in enumerate(pics):
+                msgs += support.compare_picture(got[i], recs[i], p, "poc %d" % p.poc)
+            assert not msgs, "\n".join(msgs[:10])
+            st = grp.stats()
+            assert st["pictures"] == len(pics) and st["sources"] == len(frames) and st["peer_links"] == 2
+            # every engine received exactly the sources its pictures read, each once
+            need = [set(), set()]
+            for i, p in enumerate(pics):
+                need[owners[i]].update([p.poc] + [r for lst in p.refs for r in lst])
+            assert st["uploads"] + st["peer_copies"] == len(need[0]) + len(need[1])
+            if peers:  # a source goes up from the host once; its second engine takes it from the first
+                assert st["uploads"] == len(need[0] | need[1]) and st["peer_copies"] == len(need[0] & need[1]) > 0
+            else:
+                assert st["peer_copies"] == 0
+            # a rewritten source: announced again, brought again to where the next picture reads it
+            changed = frames[pics[0].refs[0][0]].copy()
+            changed[:64, :64] = 255 - changed[:64, :64]
+            grp.store_put(pics[0].refs[0][0], pics[0].refs[0][0], changed)
+            t = grp.submit(descs[0])
+            again = grp.wait(t)
             grp.done(t)
-        assert [t >> 56 for _, t in tickets[-2:]] in ([0, 1], [1, 0])  # the engine index rides in the ticket
-        msgs = []
-        for i, p in enumerate(pics):
-            msgs += support.compare_picture(got[i], recs[i], p, "poc %d" % p.poc)
-        assert not msgs, "\n".join(msgs[:10])
-        st = grp.stats()
-        assert st["pictures"] == len(pics) and st["sources"] == len(frames)
-        # what each engine needs by the round-robin rule, exactly
-        need = [set(), set()]
-        for i, p in enumerate(pics):
-            need[i % 2].update([p.poc] + [r for lst in p.refs for r in lst])
-        assert st["uploads"] == len(need[0]) + len(need[1])
-        # a rewritten source: announced again, uploaded again where the next picture reads it
-        changed = frames[pics[0].refs[0][0]].copy()
-        changed[:64, :64] = 255 - changed[:64, :64]
-        grp.store_put(pics[0].refs[0][0], pics[0].refs[0][0], changed)
-        t = grp.submit(grp.make_picture(256, 128, pics[0].poc, pics[0].temporal_layer, pics[0].is_ref, pics[0].refs, ctrl))
-        again = grp.wait(t)
-        grp.done(t)
-        assert grp.stats()["uploads"] == st["uploads"] + 1
-        assert not np.array_equal(again["best_sad"], got[0]["best_sad"])
-        grp.store_release(0)
-        with pytest.raises(svtme.SvtmeError) as ei:
+            st2 = grp.stats()
+            assert st2["uploads"] + st2["peer_copies"] == st["uploads"] + st["peer_copies"] + 1 and st2["uploads"] == st["uploads"] + 1
+            assert not np.array_equal(again["best_sad"], got[0]["best_sad"])
             grp.store_release(0)
-        assert ei.value.code == svtme.ERR_NOT_FOUND
+            with pytest.raises(svtme.SvtmeError) as ei:
+                grp.store_release(0)
+            assert ei.value.code == svtme.ERR_NOT_FOUND
+        finally:
+            grp.close()
+
+
+def test_engine_group_release_frees_the_slots_of_every_engine_that_ever_held_the_key():
+    """Keys announced, read on some engine, announced again (a rewrite), read again - wherever the balance sends the
+    picture - and released, round after round with fresh key values and a store of six slots per engine: a slot that a
+    release left behind on an engine that held a stale copy would exhaust that engine's store after a few rounds."""
+    frames, _, _ = support.make_job(128, 128, 3, 8, seed=4)
+    ctrl = svtme.derive_controls(8, 128, 128)
+    grp = svtme.Group([0, 0], 128, 128, store_slots=6, max_in_flight=2)
+    try:
+        for rnd in range(12):
+            keys = [1000 * (rnd + 1) + i for i in range(3)]
+            for i, k in enumerate(keys):
+                grp.store_put(k, i, frames[i])
+            pic = grp.make_picture(128, 128, 1, 1, 1, [[0], [2]], ctrl, key_of=lambda poc, keys=keys: keys[poc])
+            seen = set()
+            for rep in range(4):  # the rewrite in between makes the copies stale; the balance alternates the engines
+                t = grp.submit(pic)
+                seen.add(grp.engine_of(t))
+                grp.wait(t)
+                grp.done(t)
+                grp.store_put(keys[0], 0, frames[(rep + 1) % 3])
+            assert seen == {0, 1}
+            for k in keys:
+                grp.store_release(k)
     finally:
         grp.close()
