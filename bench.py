@@ -143,9 +143,17 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-verify", action="store_true",
                     help="skip the check (outside the timed region) of one more step's results against the reference's digest")
-    ap.add_argument("--with-upload", action="store_true",
+    ap.add_argument("--with-upload", action="store_true", default=None,
                     help="every step also puts each of its source pictures into the device store once, inside the timed "
-                         "region (host -> device included; reported as a second line of evidence, never as `value` of the default run)")
+                         "region (host -> device included). The default with more than one GPU, where how far the sources "
+                         "travel is part of what is measured; with one GPU the default line keeps the inputs resident")
+    ap.add_argument("--no-upload", dest="with_upload", action="store_false",
+                    help="more than one GPU: every rank holds every source before the clock starts (the ranks are then "
+                         "independent streams of searches)")
+    ap.add_argument("--group", action="store_true",
+                    help="one process drives --gpus engines through svtme_group (the encoder's shape: one host process, a "
+                         "mini-GOP at a time split over the GPUs, sources from engine to engine where the GPUs are peers); "
+                         "start it as a single process")
     ap.add_argument("--upload-mode", default="pinned", choices=["pinned", "copy"],
                     help="--with-upload: zero-copy puts from page-locked buffers with the encoder's stride, or svtme_store_put")
     ap.add_argument("--device-tail-only", action="store_true", help="--device-tail, and do not copy the search arrays back")
@@ -176,7 +184,11 @@ def main():
 
     import svtme
     wl = dict(WORKLOADS[args.workload], name=args.workload)
-    sharded = world > 1  # one sequence, split over the ranks
+    sharded = world > 1 and not args.group  # one sequence, split over the ranks
+    if args.group and world > 1 and rank == 0:
+        print("bench.py --group drives all GPUs from one process: the other ranks only keep the barriers company", file=sys.stderr)
+    if args.with_upload is None:
+        args.with_upload = sharded or args.group
     if args.batch <= 0:
         args.batch = wl.get("batch", 1)
         if args.with_upload:  # a batch waits for the puts of all its pictures: shorter batches overlap better with the uploads
@@ -241,13 +253,13 @@ def main():
 
     puts_made = [0]
 
-    def put_source(e, k_, ks):
-        view = pool[k_, 72:72 + h, 72:72 + w]
-        if args.upload_mode == "pinned":
-            e.store_put_pinned(1000 * ks + k_, k_, view)
-        else:
-            e.store_put(1000 * ks + k_, k_, view)
-        puts_made[0] += 1
+    def put_sources(e, ks_list, ks):
+        """The sources a submission needs and the store does not hold yet, as one batched put (svtme_store_put_many)."""
+        for a in range(0, len(ks_list), svtme.MAX_PUT_BATCH):
+            part = ks_list[a:a + svtme.MAX_PUT_BATCH]
+            e.store_put_many([1000 * ks + k_ for k_ in part], part, [pool[k_, 72:72 + h, 72:72 + w] for k_ in part],
+                             pinned=args.upload_mode == "pinned")
+        puts_made[0] += len(ks_list)
 
     def run_steps(k, collect, e=None, ds=None, upload=False, owners=None, sample=None, keep=None):
         """k steps back to back: at most --in-flight pictures outstanding, also across step boundaries (mini-GOPs follow
@@ -256,7 +268,7 @@ def main():
         durations of every stride-th submission are added to stats (one svtme_picture_timing call for the submission: its
         pictures share their launches and report equal shares). keep: a list that receives every picture's results."""
         e, ds = e or eng, ds or descs
-        tickets, group = [], []
+        tickets, group, new_sources = [], [], []
         sampled, n_flush = set(), [0]
 
         def finish(e, t, collect):
@@ -277,6 +289,9 @@ def main():
         def flush():
             while len(tickets) + len(group) > args.in_flight:
                 finish(e, tickets.pop(0), collect)
+            if new_sources:
+                put_sources(e, new_sources, flush.ks)
+                new_sources.clear()
             new = e.submit_batch(group) if len(group) > 1 else [e.submit(group[0])]
             if sample is not None and n_flush[0] % sample[1] == 0:
                 sampled.add(new[0])
@@ -294,14 +309,57 @@ def main():
                     for k_ in dict.fromkeys([pics[i].poc] + [r for lst in pics[i].refs for r in lst]):
                         if k_ not in seen:
                             seen.add(k_)
-                            put_source(e, k_, ks)
+                            new_sources.append(k_)
+                flush.ks = ks
                 group.append(d)
                 if len(group) == args.batch:
                     flush()
+            if group and upload:  # (a step's key set ends with the step)
+                flush()
         if group:
             flush()
         while tickets:
             finish(e, tickets.pop(0), collect)
+
+    # --group: one process, one engine per GPU behind svtme_group. Every step announces its sources afresh (new pictures:
+    # every copy on the GPUs is stale) and hands the mini-GOP over in submissions of --batch pictures; the group decides
+    # where they run and brings the sources there, from the host or from the engine that already has them.
+    grp, gdescs, per_engine = None, None, [0] * max(1, args.gpus)
+    if args.group and rank == 0:
+        devices = [0] * args.gpus if rehearsal else list(range(args.gpus))
+        cap = args.in_flight * args.gpus
+        grp = svtme.Group(devices, w, h, store_slots=KEY_SETS * n + 1, max_in_flight=cap, search_streams=args.search_streams)
+        gdescs = [[grp.make_picture(w, h, p.poc, p.temporal_layer, p.is_ref, p.refs, ctrl, tail=tail,
+                                    tf_me_exit_th=tf[1] if tf else None, first_pass_bypass_zz=fp[0] if fp else None,
+                                    b64_step=wl.get("b64_step", 0), key_of=lambda poc, ks=ks: 1000 * ks + poc) for p in pics]
+                  for ks in range(KEY_SETS)]
+
+    def run_group_steps(k, keep=None, count=False):
+        tickets = []
+        cap = args.in_flight * args.gpus
+
+        def finish(t):
+            if keep is not None:
+                keep.append(grp.wait(t))
+            else:
+                grp.wait_raw(t)
+            grp.done(t)
+
+        for step in range(k):
+            ks = step % KEY_SETS
+            for k_ in range(n):
+                grp.store_put(1000 * ks + k_, k_, pool[k_, 72:72 + h, 72:72 + w], pinned=1 if args.upload_mode == "pinned" else 0)
+            for a in range(0, len(pics), args.batch):
+                part = gdescs[ks][a:a + args.batch]
+                while len(tickets) + len(part) > cap:
+                    finish(tickets.pop(0))
+                new = grp.submit_batch(part)
+                if count:
+                    for t in new:
+                        per_engine[grp.engine_of(t)] += 1
+                tickets.extend(new)
+        while tickets:
+            finish(tickets.pop(0))
 
     def barrier():
         if use_dist:
@@ -326,20 +384,38 @@ def main():
         owners_warm = scheduler.assign_balanced(costs * max(1, args.warmup), world)
         owners_timed = scheduler.assign_balanced(costs * args.steps, world)
         per_rank = [owners_timed.count(r) for r in range(world)]
-    run_steps(args.warmup, None, upload=args.with_upload, owners=owners_warm)
+    if grp is not None:
+        run_group_steps(args.warmup)
+    elif not args.group:
+        run_steps(args.warmup, None, upload=args.with_upload, owners=owners_warm)
     barrier()
     puts_made[0] = 0
+    g0 = grp.stats() if grp is not None else None
     t0 = time.perf_counter()
     # nothing but (put,) submit / wait / done per picture inside the timed region - and, with one search stream, one
     # svtme_picture_timing call for every few submissions (at most ~64 over the region): the kernels' HIP events
     timed = new_stats()
     n_submits = max(1, args.steps * ((per_rank[rank] // args.steps + args.batch - 1) // args.batch))
-    run_steps(args.steps, None, upload=args.with_upload, owners=owners_timed,
-              sample=(timed, max(1, n_submits // 64)) if streams == 1 else None)
-    torch.cuda.synchronize()
+    if grp is not None:
+        run_group_steps(args.steps, count=True)
+    elif not args.group:
+        run_steps(args.steps, None, upload=args.with_upload, owners=owners_timed,
+                  sample=(timed, max(1, n_submits // 64)) if streams == 1 else None)
+    if grp is not None and not rehearsal:
+        for d in range(args.gpus):
+            torch.cuda.synchronize(d)
+    else:
+        torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
     barrier()
     puts_timed = puts_made[0]
+    group_stats = None
+    if grp is not None:
+        g1 = grp.stats()
+        group_stats = {k_: g1[k_] - g0[k_] for k_ in ("pictures", "sources", "uploads", "peer_copies")}
+        group_stats["peer_links"] = g1["peer_links"]
+        puts_timed = group_stats["uploads"] + group_stats["peer_copies"]
+        per_rank = list(per_engine)
     if use_dist:  # the slowest rank's time (before rank 0 goes on to its reporting passes, so that no rank waits in a collective)
         tt = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if rehearsal else "cuda")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
@@ -378,7 +454,10 @@ def main():
             verified, verify_note = False, "the synthetic pictures differ from the ones the reference digested"
         else:
             outs = []
-            run_steps(1, None, keep=outs)
+            if grp is not None:
+                run_group_steps(1, keep=outs)  # (through the group: what was timed)
+            else:
+                run_steps(1, None, keep=outs)
             got = verify.engine_digest(outs, pics, verify.kind_of(wl), (w + 63) // 64, wl.get("b64_step", 0))
             verified = got == want["sha256"]
             verify_note = ("%d pictures of one more step (submitted %d at a time, as in the timed region): sha256 over their search "
@@ -442,18 +521,24 @@ def main():
         alg_bytes = (1 + refs_per_pic) * plane_bytes + (w // 64) * ((h + 63) // 64) * refs_per_pic * 85 * 8
         kernel_ms = float(ms[5])
         out = {
-            "metric": "open-loop ME pictures/s", "value": pictures / elapsed, "unit": "pictures/s", "n_gpus": world,
+            "metric": "open-loop ME pictures/s", "value": pictures / elapsed, "unit": "pictures/s",
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "u8", "data": "synthetic",
+            "n_gpus": args.gpus if args.group else world,
             "config": {"workload": args.workload, "width": w, "height": h,
                        "preset": ("tf hme_me_level %d, me_exit_th %d" % tf if tf else
                                   "first pass, bypass_zz_check %d, reduce_me_search %d" % fp if fp else wl["enc_mode"]),
                        "pred_structure": wl["structure"], "pictures_per_step": len(descs),
                        "refs_per_picture": round(refs_per_pic, 2), "bit_depth": wl["bit_depth"],
                        "parallelism": "the pictures of one sequence sharded over %d GPU(s) by least accumulated work, "
-                                      "no data-path collective" % world},
-            "sharding": {"pictures_per_rank": per_rank,
+                                      "no data-path collective" % (args.gpus if args.group else world)},
+            "sharding": {"mode": ("one process, svtme_group over %d engines" % args.gpus) if args.group else "one process per GPU",
+                         "pictures_per_rank": per_rank,
+                         # how many GPUs a source travelled to, per picture searched; of those, device to device
                          "sources_put_per_picture": (puts_timed / float(pictures)) if args.with_upload else None,
+                         "peer_copies": group_stats["peer_copies"] if group_stats else 0,
+                         "uploads": group_stats["uploads"] if group_stats else (puts_timed if args.with_upload else 0),
+                         "peer_links": group_stats["peer_links"] if group_stats else 0,
                          "sources_per_step": n},
             "roofline": {
                 "bound": "valu", "kernel": name, "achieved": achieved, "peak": PEAK_SAD_TOPS,
@@ -491,6 +576,8 @@ def main():
             except Exception as ex:  # the baseline is a reported number, never a reason to lose the GPU line
                 out["cpu_baseline"] = {"value": None, "unit": "pictures/s", "cores": 0, "kind": "port", "sample": "failed: %r" % (ex,)}
         print(json.dumps(out), flush=True)
+    if grp is not None:
+        grp.close()
     eng.close()
     if use_dist:
         dist.barrier()

@@ -771,7 +771,7 @@ extern "C" int svtme_host_alloc(svtme_engine *e, size_t bytes, void **out) {
     if (!e || !bytes || !out) return SVTME_ERR_BAD_ARG;
     DEVICE_OR_FAIL(e->cfg.device);
     void *ptr = nullptr;
-    if (hipHostMalloc(&ptr, bytes, hipHostMallocDefault) != hipSuccess || !ptr) {
+    if (hipHostMalloc(&ptr, bytes, hipHostMallocPortable) != hipSuccess || !ptr) { // (page-locked for every GPU: a group's engines all read it)
         (void)hipGetLastError();
         return SVTME_ERR_NO_RESOURCES;
     }

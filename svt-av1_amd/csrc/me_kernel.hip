@@ -671,27 +671,18 @@ __global__ void __launch_bounds__(256) me_finish_kernel(PICS pp) {
     p.best_mv[i]  = mv;
 }
 
-// The parameter records of a batch go to device memory as kernel arguments of a one-workgroup kernel, four per launch:
-// a copy engine in the middle of a stream of kernels costs the stream tens of microseconds of hand-over each way, a kernel
-// in front of kernels costs a launch.
-constexpr int PARAMS_PER_LAUNCH = 4;
-struct ParamsArg {
-    PicParams p[PARAMS_PER_LAUNCH];
-};
-static_assert(sizeof(ParamsArg) + 16 <= 4096, "kernel arguments are limited to 4 KB");
-__global__ void __launch_bounds__(256) params_write_kernel(ParamsArg a, PicParams *dst, int n) {
-    const uint32_t *src = reinterpret_cast<const uint32_t *>(&a);
-    uint32_t       *d   = reinterpret_cast<uint32_t *>(dst);
-    for (int i = threadIdx.x; i < n * (int)(sizeof(PicParams) / 4); i += 256) d[i] = src[i];
+// The parameter records of a batch go to device memory through one small kernel that reads them from the engine's
+// page-locked host copy (which the device can address): a copy engine in the middle of a stream of kernels costs the
+// stream tens of microseconds of hand-over each way, a kernel in front of kernels costs a launch - one for the whole
+// batch. The host leaves the records alone until the batch's pictures have been handed back.
+__global__ void __launch_bounds__(256) params_write_kernel(const uint32_t *__restrict__ src, uint32_t *__restrict__ dst, int n_words) {
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < n_words; i += gridDim.x * 256) dst[i] = src[i];
 }
 
 void launch_params_write(const PicParams *host, PicParams *dev, int n, hipStream_t s) {
-    for (int i = 0; i < n; i += PARAMS_PER_LAUNCH) {
-        ParamsArg a;
-        const int m = n - i < PARAMS_PER_LAUNCH ? n - i : PARAMS_PER_LAUNCH;
-        for (int j = 0; j < PARAMS_PER_LAUNCH; ++j) a.p[j] = host[i + (j < m ? j : 0)];
-        hipLaunchKernelGGL(params_write_kernel, dim3(1), dim3(256), 0, s, a, dev + i, m);
-    }
+    const int n_words = n * (int)(sizeof(PicParams) / 4);
+    hipLaunchKernelGGL(params_write_kernel, dim3((n_words + 1023) / 1024), dim3(256), 0, s, reinterpret_cast<const uint32_t *>(host),
+                       reinterpret_cast<uint32_t *>(dev), n_words);
 }
 
 template <class PICS>
