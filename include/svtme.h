@@ -469,8 +469,9 @@ int svtme_group_set_tile_rects(svtme_group *g, uint32_t width, uint32_t height, 
 
 /* ---- Global-motion estimation: the data-parallel stages of compute_global_motion
  * (Source/Lib/Encoder/Codec/EbGlobalMotionEstimation.c:155-301) on the planes the store already holds. The encoder keeps
- * its own RANSAC (ransac.c), refinement loop (svt_av1_refine_integerized_param, global_motion.c:135-263), shear derivation
- * and parameter costs; it calls the engine where it called these four functions:
+ * its own RANSAC (ransac.c, double precision, a few hundred points), the final shear derivation and the parameter costs; it
+ * calls the engine where it called these functions (the refinement loop either as a whole, svtme_gm_refine, or - keeping
+ * its own loop - error by error, svtme_gm_warp_error):
  *
  *   svtme_gm_corners          <- svt_av1_fast_corner_detect (corner_detect.c:19-32): FAST-9, barrier 18, non-maximum
  *                                suppression, the first max_points corners in raster order as (x, y) pairs
@@ -485,6 +486,17 @@ int svtme_group_set_tile_rects(svtme_group *g, uint32_t width, uint32_t height, 
  *                                the error table; as in the reference the sum stops at the first block, in raster order,
  *                                that takes it above best_error
  *   svtme_gm_frame_error      <- svt_av1_frame_error (EbEncWarpedMotion.c:215-227) for 8 bit: the same measure, no warp
+ *
+ *   svtme_gm_refine           <- svt_av1_refine_integerized_param (global_motion.c:135-263) for 8 bit, with the
+ *                                svt_av1_warp_error calls it makes (svt_get_shear_params, EbWarpedMotion.c:1115-1144,
+ *                                included): the whole loop - every refinement step of every parameter, each an error over
+ *                                the picture - as one chain of launches that the device advances by itself; the host
+ *                                looks at it once it has ended. wm: the model as svt_av1_convert_model_to_params left it
+ *                                (wmmat[0..5] and, for completeness, the shear the struct holds); on return the refined
+ *                                model as the reference's function leaves it (wmmat[6] and [7], which this struct does not
+ *                                carry, are 0 then), its type (get_wmtype) and the function's return value in *error.
+ *                                *evaluations (may be NULL): how many errors the loop took. Replaces the encoder's loop
+ *                                around svtme_gm_warp_error; RANSAC and the parameter costs stay with the encoder
  *
  * downsample_level is pcs->gm_ctrls.downsample_level (GM_FULL 0, GM_DOWN 1, GM_DOWN16 2, EbDefinitions.h:155-159) and
  * selects the full, quarter or sixteenth plane of both pictures (EbGlobalMotionEstimation.c:109-122). The calls are
@@ -508,6 +520,16 @@ int svtme_gm_correspondences(svtme_engine *e, uint64_t cur_key, uint64_t ref_key
 int svtme_gm_warp_error(svtme_engine *e, uint64_t cur_key, uint64_t ref_key, int downsample_level, const svtme_gm_warp *wm,
                         int64_t best_error, int64_t *error);
 int svtme_gm_frame_error(svtme_engine *e, uint64_t cur_key, uint64_t ref_key, int downsample_level, int64_t *error);
+typedef struct svtme_gm_model { /* EbWarpedMotionParams (EbDefinitions.h:1969-1975) without wmmat[6], [7] and invalid */
+    int32_t wmmat[6];
+    int16_t alpha, beta, gamma, delta;
+    int32_t wmtype; /* TransformationType: IDENTITY 0, TRANSLATION 1, ROTZOOM 2, AFFINE 3 */
+} svtme_gm_model;
+/* wmtype: the type to force (the reference passes the model's own, EbGlobalMotionEstimation.c:231-246); n_refinements:
+ * gm_ctrls.params_refinement_steps, at least 1; best_frame_error: the best error of the models tried before (INT64_MAX for
+ * the first) */
+int svtme_gm_refine(svtme_engine *e, uint64_t cur_key, uint64_t ref_key, int downsample_level, svtme_gm_model *wm, int wmtype,
+                    int n_refinements, int64_t best_frame_error, int64_t *error, uint32_t *evaluations);
 
 /* ---- TPL dispenser: the source-based mode search of tpl_mc_flow_dispenser_sb_generic
  * (Source/Lib/Encoder/Codec/EbSourceBasedOperationsProcess.c:632-933): for every block of the dispenser's grid the cost of

@@ -4,13 +4,14 @@
  * Drives the REAL reference global-motion estimation (compute_global_motion,
  * Source/Lib/Encoder/Codec/EbGlobalMotionEstimation.c:155-301) over pairs of synthetic pictures and records what it
  * computed: the final model and, in call order, every svt_av1_fast_corner_detect, svt_av1_determine_correspondence,
- * svt_av1_warp_error and svt_av1_frame_error call with its inputs and result. Compiled only where /root/reference exists,
+ * svt_av1_warp_error, svt_av1_frame_error and svt_av1_refine_integerized_param call with its inputs and result. Compiled only where /root/reference exists,
  * against the reference's own headers and objects (oracle/Makefile, target ref); the binary lands in oracle/_ref/.
  *
- * The four functions are the seam of the GPU engine's svtme_gm_* entry points (include/svtme.h). They are reached through
+ * These functions are the seam of the GPU engine's svtme_gm_* entry points (include/svtme.h). They are reached through
  * the linker's --wrap: the reference's objects call __wrap_<name> below, which either passes the call on to the
  * reference's own function (mode 0) or sends it to the engine (mode 1, the reference-side binding end to end: the
- * reference's RANSAC, refinement loop, shear derivation and costs run unchanged around the engine's results).
+ * reference's RANSAC, refinement loop, shear derivation and costs run unchanged around the engine's results; mode 1 + 4:
+ * the refinement loop as a whole goes to the engine too, svtme_gm_refine, and the reference's own loop does not run).
  *
  * Usage: ref_gm <job file> <output file> [libsvtme.so, mode 1 only]
  *        ref_gm tables <output file>      the warp filter (193 x 8 int16) and the error table (512 int32) of the build,
@@ -45,7 +46,7 @@ int64_t svt_av1_calc_frame_error_avx2(const uint8_t *const ref, int stride, cons
                                       int p_stride);
 #endif
 
-#define GM_JOB_MAGIC "SVTGMJ01"
+#define GM_JOB_MAGIC "SVTGMJ02"
 #define GM_OUT_MAGIC "SVTGMO01"
 
 #pragma pack(push, 1)
@@ -56,17 +57,24 @@ typedef struct gm_job_header {
     uint32_t n_jobs; /* then n_jobs gm_job */
     uint32_t mode; /* 0: the reference alone; 1: the four seam functions on the GPU engine; +2: the reference's AVX2 kernels
                       for the warp filter and the frame error (as setup_rtcd_internal binds them on an
-                      AVX2 machine, aom_dsp_rtcd.c / common_dsp_rtcd.c), for the CPU side of a timing comparison */
+                      AVX2 machine, aom_dsp_rtcd.c / common_dsp_rtcd.c), for the CPU side of a timing comparison;
+                      +4 (with 1): svt_av1_refine_integerized_param as a whole on the engine */
 } gm_job_header;
 typedef struct gm_job {
     uint32_t cur_frame, ref_frame;
     uint32_t downsample_level; /* gm_ctrls.downsample_level */
     uint32_t rotzoom_model_only, params_refinement_steps, allow_high_precision_mv;
+    /* direct != 0: not compute_global_motion but one svt_av1_refine_integerized_param call on the pair, with this model
+     * (zero shear), forced type and error to beat - for models the estimation itself does not arrive at */
+    uint32_t direct;
+    int32_t  mat[6];
+    int32_t  wmtype;
+    int64_t  best_frame_error;
 } gm_job;
 #pragma pack(pop)
 
 /* ---- the record of one run: int64 words. Each entry: kind, number of payload words, payload. */
-enum { REC_CORNERS = 1, REC_CORRESPONDENCES = 2, REC_WARP_ERROR = 3, REC_FRAME_ERROR = 4, REC_FINAL = 9 };
+enum { REC_CORNERS = 1, REC_CORRESPONDENCES = 2, REC_WARP_ERROR = 3, REC_FRAME_ERROR = 4, REC_REFINE = 5, REC_FINAL = 9 };
 static FILE *g_out;
 static void rec(int64_t kind, const int64_t *payload, int64_t n) {
     fwrite(&kind, 8, 1, g_out);
@@ -87,9 +95,10 @@ typedef struct Shim {
     int (*gm_correspondences)(svtme_engine *, uint64_t, uint64_t, int, int32_t *, int32_t *);
     int (*gm_warp_error)(svtme_engine *, uint64_t, uint64_t, int, const svtme_gm_warp *, int64_t, int64_t *);
     int (*gm_frame_error)(svtme_engine *, uint64_t, uint64_t, int, int64_t *);
+    int (*gm_refine)(svtme_engine *, uint64_t, uint64_t, int, svtme_gm_model *, int, int, int64_t, int64_t *, uint32_t *);
 } Shim;
 static Shim g_shim;
-static int  g_use_engine;
+static int  g_use_engine, g_engine_refine;
 /* the pair compute_global_motion is working on */
 static const uint8_t *g_frm_buf, *g_ref_buf;
 static uint64_t       g_frm_key, g_ref_key;
@@ -200,6 +209,40 @@ int64_t __wrap_svt_av1_frame_error(int use_hbd, int bd, const uint8_t *ref, int 
     return err;
 }
 
+int64_t __real_svt_av1_refine_integerized_param(EbWarpedMotionParams *wm, TransformationType wmtype, int use_hbd, int bd, uint8_t *ref,
+                                                uint8_t *ref_2b, int r_width, int r_height, int r_stride, uint8_t *dst, int d_width,
+                                                int d_height, int d_stride, int n_refinements, int64_t best_frame_error);
+int64_t __wrap_svt_av1_refine_integerized_param(EbWarpedMotionParams *wm, TransformationType wmtype, int use_hbd, int bd, uint8_t *ref,
+                                                uint8_t *ref_2b, int r_width, int r_height, int r_stride, uint8_t *dst, int d_width,
+                                                int d_height, int d_stride, int n_refinements, int64_t best_frame_error) {
+    /* in: the model, the type to force, the steps, the error to beat; out: the model, its type, the shear, the result */
+    int64_t w[26] = {wm->wmmat[0], wm->wmmat[1], wm->wmmat[2], wm->wmmat[3], wm->wmmat[4], wm->wmmat[5], wm->alpha, wm->beta,
+                     wm->gamma,    wm->delta,    wm->wmtype,   wmtype,       n_refinements, best_frame_error};
+    int64_t err;
+    if (g_engine_refine) {
+        if (use_hbd || ref != g_ref_buf || dst != g_frm_buf) die("refinement outside what the engine covers");
+        svtme_gm_model m;
+        for (int i = 0; i < 6; ++i) m.wmmat[i] = wm->wmmat[i];
+        m.alpha = wm->alpha; m.beta = wm->beta; m.gamma = wm->gamma; m.delta = wm->delta;
+        m.wmtype = wm->wmtype;
+        if (g_shim.gm_refine(g_shim.engine, g_frm_key, g_ref_key, g_level, &m, (int)wmtype, n_refinements, best_frame_error, &err, NULL) !=
+            SVTME_OK)
+            die("svtme_gm_refine failed");
+        for (int i = 0; i < 6; ++i) wm->wmmat[i] = m.wmmat[i];
+        wm->wmmat[6] = wm->wmmat[7] = 0; /* force_wmtype, global_motion.c:130 */
+        wm->alpha = m.alpha; wm->beta = m.beta; wm->gamma = m.gamma; wm->delta = m.delta;
+        wm->wmtype = (TransformationType)m.wmtype;
+    } else
+        err = __real_svt_av1_refine_integerized_param(wm, wmtype, use_hbd, bd, ref, ref_2b, r_width, r_height, r_stride, dst, d_width,
+                                                      d_height, d_stride, n_refinements, best_frame_error);
+    for (int i = 0; i < 6; ++i) w[14 + i] = wm->wmmat[i];
+    w[20] = wm->alpha; w[21] = wm->beta; w[22] = wm->gamma; w[23] = wm->delta;
+    w[24] = wm->wmtype;
+    w[25] = err;
+    rec(REC_REFINE, w, 26);
+    return err;
+}
+
 /* ------------------------------------------------------------------------------------------------------------------ */
 static uint8_t *plane_origin(EbPictureBufferDesc *d) { return d->buffer_y + d->origin_x + (size_t)d->origin_y * d->stride_y; }
 
@@ -254,6 +297,8 @@ int main(int argc, char **argv) {
         *(void **)&g_shim.gm_correspondences = shim_sym("svtme_gm_correspondences");
         *(void **)&g_shim.gm_warp_error      = shim_sym("svtme_gm_warp_error");
         *(void **)&g_shim.gm_frame_error     = shim_sym("svtme_gm_frame_error");
+        *(void **)&g_shim.gm_refine          = shim_sym("svtme_gm_refine");
+        g_engine_refine                      = (hdr.mode & 4) != 0;
         svtme_config cfg;
         memset(&cfg, 0, sizeof(cfg));
         cfg.max_width = w; cfg.max_height = h;
@@ -287,7 +332,14 @@ int main(int argc, char **argv) {
         g_level   = (int)g->downsample_level;
         EbWarpedMotionParams best;
         memset(&best, 0, sizeof(best));
-        compute_global_motion(pcs, in, rf, &best, (int)g->allow_high_precision_mv);
+        if (g->direct) {
+            for (int i = 0; i < 6; ++i) best.wmmat[i] = g->mat[i];
+            best.wmtype = (TransformationType)g->wmtype;
+            svt_av1_refine_integerized_param(&best, (TransformationType)g->wmtype, EB_FALSE, EB_8BIT, g_ref_buf, NULL, rf->width, rf->height,
+                                             rf->stride_y, (uint8_t *)g_frm_buf, in->width, in->height, in->stride_y,
+                                             (int)g->params_refinement_steps, g->best_frame_error);
+        } else
+            compute_global_motion(pcs, in, rf, &best, (int)g->allow_high_precision_mv);
         int64_t fin[14] = {best.wmtype,   best.wmmat[0], best.wmmat[1], best.wmmat[2], best.wmmat[3], best.wmmat[4], best.wmmat[5],
                            best.wmmat[6], best.wmmat[7], best.alpha,    best.beta,     best.gamma,    best.delta,    best.invalid};
         rec(REC_FINAL, fin, 14);

@@ -252,3 +252,124 @@ int64_t orc_gm_warp_error(const orc_gm_tables *t, const orc_gm_warp *wm, const u
         }
     return sum;
 }
+
+/* ------------------------------------------------------------------------------------------- parameter refinement
+ * svt_av1_refine_integerized_param (Source/Lib/Encoder/Codec/global_motion.c:135-263) for 8 bit with everything it calls:
+ * svt_av1_warp_error's prologue (EbEncWarpedMotion.c:233-235: the shear parameters, result 1 when they are invalid),
+ * svt_get_shear_params (Source/Lib/Common/Codec/EbWarpedMotion.c:1115-1144, with resolve_divisor_32, :343-357, whose table
+ * div_lut[f], :301-322, is round(2^22 / (256 + f))), svt_warp_plane's rotation-zoom fix-up (:701-704), force_wmtype,
+ * add_param_offset and get_wmtype (global_motion.c:71-133).
+ */
+static int64_t round_pow2_signed_64(int64_t v, int n) {
+    return v < 0 ? -((-v + (((int64_t)1 << n) >> 1)) >> n) : ((v + (((int64_t)1 << n) >> 1)) >> n);
+}
+static int round_pow2_signed(int v, int n) { return v < 0 ? -((-v + ((1 << n) >> 1)) >> n) : ((v + ((1 << n) >> 1)) >> n); }
+
+int orc_gm_shear(orc_gm_model *wm) {
+    const int32_t *mat = wm->wmmat;
+    if (!(mat[2] > 0)) return 0;
+    wm->alpha = (int16_t)clampi(mat[2] - (1 << 16), INT16_MIN, INT16_MAX);
+    wm->beta  = (int16_t)clampi(mat[3], INT16_MIN, INT16_MAX);
+    int       shift = 31 - __builtin_clz((unsigned)mat[2]);
+    const int e = mat[2] - (1 << shift);
+    const int f = shift > 8 ? (e + ((1 << (shift - 8)) >> 1)) >> (shift - 8) : e << (8 - shift);
+    shift += 14;
+    const int16_t y = (int16_t)(((1 << 22) + (256 + f) / 2) / (256 + f));
+    int64_t       v = ((int64_t)mat[4] * (1 << 16)) * y;
+    wm->gamma = (int16_t)clampi((int)round_pow2_signed_64(v, shift), INT16_MIN, INT16_MAX);
+    v         = ((int64_t)mat[3] * mat[4]) * y;
+    wm->delta = (int16_t)clampi(mat[5] - (int)round_pow2_signed_64(v, shift) - (1 << 16), INT16_MIN, INT16_MAX);
+    wm->alpha = (int16_t)(round_pow2_signed(wm->alpha, 6) * (1 << 6));
+    wm->beta  = (int16_t)(round_pow2_signed(wm->beta, 6) * (1 << 6));
+    wm->gamma = (int16_t)(round_pow2_signed(wm->gamma, 6) * (1 << 6));
+    wm->delta = (int16_t)(round_pow2_signed(wm->delta, 6) * (1 << 6));
+    if (4 * abs(wm->alpha) + 7 * abs(wm->beta) >= (1 << 16) || 4 * abs(wm->gamma) + 4 * abs(wm->delta) >= (1 << 16)) return 0;
+    return 1;
+}
+
+static int32_t add_param_offset(int index, int32_t value, int32_t offset) {
+    const int scale = index < 2 ? 16 - 6 : 16 - 15; /* GM_TRANS_PREC_DIFF, GM_ALPHA_PREC_DIFF */
+    const int one   = (index == 2 || index == 5) ? 1 : 0;
+    value = (value - (one << 16)) >> scale;
+    value += offset;
+    value = clampi(value, -(1 << 12), 1 << 12); /* GM_TRANS_MAX, GM_ALPHA_MAX */
+    value *= 1 << scale;
+    return value + (one << 16);
+}
+
+static void force_wmtype(orc_gm_model *wm, int wmtype) {
+    if (wmtype == 0) wm->wmmat[0] = wm->wmmat[1] = 0;
+    if (wmtype <= 1) {
+        wm->wmmat[2] = 1 << 16;
+        wm->wmmat[3] = 0;
+    }
+    if (wmtype <= 2) {
+        wm->wmmat[4] = -wm->wmmat[3];
+        wm->wmmat[5] = wm->wmmat[2];
+    }
+    wm->wmtype = wmtype;
+}
+
+typedef struct refine_ctx {
+    const orc_gm_tables *t;
+    const uint8_t       *ref, *dst;
+    int                  width, height, r_stride, d_stride;
+    int                  evals;
+} refine_ctx;
+
+/* svt_av1_warp_error as the loop calls it: it changes the model (shear, rotation-zoom fix-up) */
+static int64_t refine_error(refine_ctx *c, orc_gm_model *wm, int64_t best_error) {
+    c->evals++;
+    if (!orc_gm_shear(wm)) return 1;
+    if (wm->wmtype == 2) {
+        wm->wmmat[5] = wm->wmmat[2];
+        wm->wmmat[4] = -wm->wmmat[3];
+    }
+    orc_gm_warp w;
+    memcpy(w.wmmat, wm->wmmat, sizeof(w.wmmat));
+    w.alpha = wm->alpha; w.beta = wm->beta; w.gamma = wm->gamma; w.delta = wm->delta;
+    return orc_gm_warp_error(c->t, &w, c->ref, c->width, c->height, c->r_stride, c->dst, c->width, c->height, c->d_stride, best_error);
+}
+
+int64_t orc_gm_refine(const orc_gm_tables *t, orc_gm_model *wm, int wmtype, const uint8_t *ref, int r_stride, const uint8_t *dst,
+                      int width, int height, int d_stride, int n_refinements, int64_t best_frame_error, int *evaluations) {
+    refine_ctx c = {t, ref, dst, width, height, r_stride, d_stride, 0};
+    const int  n_params = 2 * wmtype; /* max_trans_model_params */
+    int32_t   *mat = wm->wmmat;
+    force_wmtype(wm, wmtype);
+    int64_t best_error = refine_error(&c, wm, best_frame_error);
+    if (best_frame_error < best_error) best_error = best_frame_error;
+    int step = 1 << (n_refinements - 1);
+    for (int i = 0; i < n_refinements; i++, step >>= 1)
+        for (int p = 0; p < n_params; ++p) {
+            int           step_dir = 0;
+            const int32_t curr = mat[p];
+            int32_t       best = curr;
+            for (int dir = -1; dir <= 1; dir += 2) { /* left, then right */
+                mat[p] = add_param_offset(p, curr, dir * step);
+                const int64_t err = refine_error(&c, wm, best_error);
+                if (err < best_error) {
+                    best_error = err;
+                    best       = mat[p];
+                    step_dir   = dir;
+                }
+            }
+            mat[p] = best;
+            while (step_dir) { /* on in that direction while the error falls */
+                mat[p] = add_param_offset(p, best, step * step_dir);
+                const int64_t err = refine_error(&c, wm, best_error);
+                if (err < best_error) {
+                    best_error = err;
+                    best       = mat[p];
+                } else {
+                    mat[p]   = best;
+                    step_dir = 0;
+                }
+            }
+        }
+    force_wmtype(wm, wmtype);
+    if (mat[5] == (1 << 16) && !mat[4] && mat[2] == (1 << 16) && !mat[3]) wm->wmtype = (!mat[1] && !mat[0]) ? 0 : 1;
+    else wm->wmtype = (mat[2] == mat[5] && mat[3] == -mat[4]) ? 2 : 3;
+    if (evaluations) *evaluations = c.evals;
+    return best_error;
+}

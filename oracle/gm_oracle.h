@@ -30,4 +30,14 @@ int64_t orc_gm_warp_error(const orc_gm_tables *t, const orc_gm_warp *wm, const u
                           const uint8_t *dst, int p_width, int p_height, int p_stride, int64_t best_error);
 int64_t orc_gm_frame_error(const orc_gm_tables *t, const uint8_t *ref, int stride, const uint8_t *dst, int p_width, int p_height,
                            int p_stride);
+
+/* the fields of EbWarpedMotionParams (EbDefinitions.h:1969-1975) the refinement loop touches */
+typedef struct orc_gm_model {
+    int32_t wmmat[6];
+    int16_t alpha, beta, gamma, delta;
+    int32_t wmtype;
+} orc_gm_model;
+int     orc_gm_shear(orc_gm_model *wm);
+int64_t orc_gm_refine(const orc_gm_tables *t, orc_gm_model *wm, int wmtype, const uint8_t *ref, int r_stride, const uint8_t *dst,
+                      int width, int height, int d_stride, int n_refinements, int64_t best_frame_error, int *evaluations);
 #endif

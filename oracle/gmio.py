@@ -13,8 +13,12 @@ REF_GM = os.path.join(HERE, "_ref", "ref_gm")
 ORACLE_LIB = os.path.join(HERE, "build", "libme_oracle.so")
 MAX_CORNERS = 4096
 
-REC_CORNERS, REC_CORRESPONDENCES, REC_WARP_ERROR, REC_FRAME_ERROR, REC_FINAL = 1, 2, 3, 4, 9
+REC_CORNERS, REC_CORRESPONDENCES, REC_WARP_ERROR, REC_FRAME_ERROR, REC_REFINE, REC_FINAL = 1, 2, 3, 4, 5, 9
 WARP_FIELDS = ("m0", "m1", "m2", "m3", "m4", "m5", "alpha", "beta", "gamma", "delta", "wmtype", "best_error", "error")
+# one svt_av1_refine_integerized_param call: the model that goes in (with the struct's shear and type), the type to force, the
+# steps, the error to beat; the model that comes out and the function's result
+REFINE_FIELDS = ("i0", "i1", "i2", "i3", "i4", "i5", "i_alpha", "i_beta", "i_gamma", "i_delta", "i_wmtype", "force_wmtype", "steps",
+                 "best_frame_error", "o0", "o1", "o2", "o3", "o4", "o5", "o_alpha", "o_beta", "o_gamma", "o_delta", "o_wmtype", "error")
 FINAL_FIELDS = ("wmtype", "m0", "m1", "m2", "m3", "m4", "m5", "m6", "m7", "alpha", "beta", "gamma", "delta", "invalid")
 
 
@@ -23,18 +27,21 @@ def have_reference():
 
 
 def write_job(path, frames, jobs, mode=0):
-    """frames: uint8 [n, h, w]; jobs: dicts with cur, ref, level, rotzoom_only, steps, allow_hp."""
+    """frames: uint8 [n, h, w]; jobs: dicts with cur, ref, level, rotzoom_only, steps, allow_hp, and optionally direct."""
     n, h, w = frames.shape
     with open(path, "wb") as f:
-        f.write(struct.pack("<8sIIIII", b"SVTGMJ01", w, h, n, len(jobs), mode))
+        f.write(struct.pack("<8sIIIII", b"SVTGMJ02", w, h, n, len(jobs), mode))
         f.write(np.ascontiguousarray(frames, np.uint8).tobytes())
         for j in jobs:
             f.write(struct.pack("<6I", j["cur"], j["ref"], j.get("level", 0), j.get("rotzoom_only", 1), j.get("steps", 5), j.get("allow_hp", 0)))
+            d = j.get("direct")  # (mat [6], wmtype, best_frame_error): one refinement call instead of the estimation
+            f.write(struct.pack("<I6iiq", 1, *d[0], d[1], d[2]) if d else struct.pack("<I6iiq", 0, 0, 0, 0, 0, 0, 0, 0, 0))
 
 
 def read_records(path, n_jobs):
     """-> one dict per job: corners_frm, corners_ref (int [n, 2]), correspondences (int [n, 4], the first call's),
-    calls (list of ('corners' | 'corr' | 'warp' | 'frame', payload) in call order), final (dict)."""
+    calls (list of ('corners' | 'corr' | 'warp' | 'frame' | 'refine', payload) in call order; a 'refine' entry follows the
+    'warp' entries of the errors its loop took), final (dict)."""
     with open(path, "rb") as f:
         raw = f.read()
     assert raw[:8] == b"SVTGMO01", "bad record magic"
@@ -58,6 +65,8 @@ def read_records(path, n_jobs):
             cur["calls"].append(("warp", dict(zip(WARP_FIELDS, (int(v) for v in p)))))
         elif kind == REC_FRAME_ERROR:
             cur["calls"].append(("frame", int(p[0])))
+        elif kind == REC_REFINE:
+            cur["calls"].append(("refine", dict(zip(REFINE_FIELDS, (int(v) for v in p)))))
         elif kind == REC_FINAL:
             cur["final"] = dict(zip(FINAL_FIELDS, (int(v) for v in p)))
             out.append(cur)
@@ -68,13 +77,14 @@ def read_records(path, n_jobs):
     return out
 
 
-def run_reference(frames, jobs, library=None, timeout=1200, use_avx2=False):
+def run_reference(frames, jobs, library=None, timeout=1200, use_avx2=False, engine_refine=False):
     """Runs compute_global_motion of the real reference per job; with `library` (path of libsvtme.so) its four data-parallel
-    functions go to the GPU engine instead (the reference-side binding end to end). use_avx2: the reference's AVX2 kernels
-    instead of its C ones for the warp filter and the frame error."""
+    functions go to the GPU engine instead (the reference-side binding end to end), with engine_refine its refinement loop
+    as a whole too (svtme_gm_refine). use_avx2: the reference's AVX2 kernels instead of its C ones for the warp filter and
+    the frame error."""
     with tempfile.TemporaryDirectory() as d:
         jp, op = os.path.join(d, "job.bin"), os.path.join(d, "out.bin")
-        write_job(jp, frames, jobs, mode=(1 if library else 0) | (2 if use_avx2 else 0))
+        write_job(jp, frames, jobs, mode=(1 if library else 0) | (2 if use_avx2 else 0) | (4 if library and engine_refine else 0))
         cmd = [REF_GM, jp, op] + ([library] if library else [])
         r = subprocess.run(cmd, capture_output=True, text=True, timeout=timeout)
         if r.returncode != 0:
@@ -100,6 +110,11 @@ class _Tables(ctypes.Structure):
     _fields_ = [("warped_filter", ctypes.POINTER(ctypes.c_int16)), ("error_lut", ctypes.POINTER(ctypes.c_int32))]
 
 
+class _Model(ctypes.Structure):
+    _fields_ = [("wmmat", ctypes.c_int32 * 6), ("alpha", ctypes.c_int16), ("beta", ctypes.c_int16), ("gamma", ctypes.c_int16),
+                ("delta", ctypes.c_int16), ("wmtype", ctypes.c_int32)]
+
+
 class _Warp(ctypes.Structure):
     _fields_ = [("wmmat", ctypes.c_int32 * 6), ("alpha", ctypes.c_int16), ("beta", ctypes.c_int16), ("gamma", ctypes.c_int16),
                 ("delta", ctypes.c_int16)]
@@ -114,6 +129,7 @@ def _oracle():
         _lib = ctypes.CDLL(ORACLE_LIB)
         _lib.orc_gm_warp_error.restype = ctypes.c_int64
         _lib.orc_gm_frame_error.restype = ctypes.c_int64
+        _lib.orc_gm_refine.restype = ctypes.c_int64
     return _lib
 
 
@@ -163,6 +179,18 @@ def oracle_frame_error(tables, ref, frm):
     a, pa = _u8(ref)
     b, pb = _u8(frm)
     return int(_oracle().orc_gm_frame_error(ctypes.byref(t), pa, a.shape[1], pb, b.shape[1], b.shape[0], b.shape[1]))
+
+
+def oracle_refine(tables, mat, shear, model_wmtype, wmtype, ref, frm, steps, best_frame_error):
+    """-> (mat [6], shear [4], wmtype, error, evaluations) of the restated svt_av1_refine_integerized_param."""
+    t, keep = _tables(tables)
+    a, pa = _u8(ref)
+    b, pb = _u8(frm)
+    m = _Model((ctypes.c_int32 * 6)(*[int(v) for v in mat]), *[int(v) for v in shear], int(model_wmtype))
+    n = ctypes.c_int(0)
+    err = int(_oracle().orc_gm_refine(ctypes.byref(t), ctypes.byref(m), int(wmtype), pa, a.shape[1], pb, b.shape[1], b.shape[0], b.shape[1],
+                                      int(steps), ctypes.c_int64(int(best_frame_error)), ctypes.byref(n)))
+    return list(m.wmmat), [m.alpha, m.beta, m.gamma, m.delta], int(m.wmtype), err, n.value
 
 
 def plane_of(frame, level):

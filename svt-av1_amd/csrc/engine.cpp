@@ -125,6 +125,7 @@ struct GmState {
     int       *d_match = nullptr; // [SVTME_GM_MAX_CORNERS][5]
     uint32_t  *d_block_err = nullptr; // per 32x32 block
     long long *d_result = nullptr;
+    GmRefineState *d_refine = nullptr; // svtme_gm_refine's loop state
     int16_t   *d_filter = nullptr; // the caller's warp filter [193][8]
     int32_t   *d_lut = nullptr; // and error table [512]
     int       *h_buf = nullptr; // pinned: what a call brings back
@@ -1376,7 +1377,8 @@ int gm_init(svtme_engine *e) { // e->gm.mu held, device current
         hipMalloc((void **)&g.d_corners[1], kGmCornerInts * sizeof(int)) != hipSuccess ||
         hipMalloc((void **)&g.d_match, kGmMatchInts * sizeof(int)) != hipSuccess ||
         hipMalloc((void **)&g.d_block_err, blocks * sizeof(uint32_t)) != hipSuccess ||
-        hipMalloc((void **)&g.d_result, sizeof(long long)) != hipSuccess || hipMalloc((void **)&g.d_filter, 193 * 8 * sizeof(int16_t)) != hipSuccess ||
+        hipMalloc((void **)&g.d_result, sizeof(long long)) != hipSuccess || hipMalloc((void **)&g.d_refine, sizeof(GmRefineState)) != hipSuccess ||
+        hipMalloc((void **)&g.d_filter, 193 * 8 * sizeof(int16_t)) != hipSuccess ||
         hipMalloc((void **)&g.d_lut, 512 * sizeof(int32_t)) != hipSuccess ||
         hipHostMalloc((void **)&g.h_buf, (kGmCornerInts + kGmMatchInts + 4) * sizeof(int), hipHostMallocDefault) != hipSuccess) {
         (void)hipGetLastError();
@@ -1568,6 +1570,60 @@ extern "C" int svtme_gm_warp_error(svtme_engine *e, uint64_t cur_key, uint64_t r
 
 extern "C" int svtme_gm_frame_error(svtme_engine *e, uint64_t cur_key, uint64_t ref_key, int downsample_level, int64_t *error) {
     return gm_error(e, cur_key, ref_key, downsample_level, nullptr, INT64_MAX, error);
+}
+
+extern "C" int svtme_gm_refine(svtme_engine *e, uint64_t cur_key, uint64_t ref_key, int downsample_level, svtme_gm_model *wm, int wmtype,
+                               int n_refinements, int64_t best_frame_error, int64_t *error, uint32_t *evaluations) {
+    // n_refinements: the loop's first step is 1 << (n_refinements - 1); the parameters' ranges (GM_TRANS_MAX, GM_ALPHA_MAX =
+    // 1 << 12 units) bound what a step can be
+    if (!e || !wm || !error || downsample_level < 0 || downsample_level > 2 || wmtype < 0 || wmtype > 3 || n_refinements < 1 || n_refinements > 13)
+        return SVTME_ERR_BAD_ARG;
+    DEVICE_OR_FAIL(e->cfg.device);
+    std::lock_guard<std::mutex> gm_lock(e->gm.mu);
+    if (!e->gm.ready || !e->gm.tables) return SVTME_ERR_BAD_ARG; // svtme_gm_set_tables first
+    GmPlanes       pl(e);
+    const uint64_t keys[2] = {cur_key, ref_key};
+    if (const int rc = pl.take(keys, 2, downsample_level)) return rc;
+    if (pl.plane[0].width != pl.plane[1].width || pl.plane[0].height != pl.plane[1].height) return SVTME_ERR_BAD_ARG;
+    const hipStream_t st = e->s_me[3];
+    GmState          &g = e->gm;
+    GM_TRY(hipStreamWaitEvent(st, pl.ready[0], 0));
+    GM_TRY(hipStreamWaitEvent(st, pl.ready[1], 0));
+    GmRefineState init{};
+    for (int i = 0; i < 6; ++i) init.mat[i] = wm->wmmat[i];
+    init.alpha         = wm->alpha;
+    init.beta          = wm->beta;
+    init.gamma         = wm->gamma;
+    init.delta         = wm->delta;
+    init.wmtype        = wmtype;
+    init.n_refinements = n_refinements;
+    init.best_error    = (long long)best_frame_error;
+    launch_gm_refine_begin(g.d_refine, init, st);
+    // The loop's shortest run: the first evaluation, then left and right for every parameter of every step; a walk adds to it.
+    // That many launches go out at once, with some to spare for walks (a launch after the loop's end costs next to
+    // nothing), then the state comes back; while the loop has not ended, more of them.
+    GmRefineState *back = reinterpret_cast<GmRefineState *>(g.h_buf);
+    int            chunk = 1 + 2 * (2 * wmtype) * n_refinements + 8;
+    for (int launched = 0;; chunk = 16) {
+        launch_gm_refine_evaluations(pl.plane[0], pl.plane[1], g.d_refine, g.d_filter, g.d_lut, g.d_block_err, chunk, st);
+        launched += chunk;
+        GM_TRY(hipGetLastError());
+        GM_TRY(hipMemcpyAsync(back, g.d_refine, sizeof(GmRefineState), hipMemcpyDeviceToHost, st));
+        GM_TRY(hipStreamSynchronize(st));
+        if (back->done) break;
+        // every walk step moves a clamped parameter by at least one unit, so the loop ends; this guards the host against a
+        // device that does not report it
+        if (launched > 6 * 13 * 2 * 8192 + 64) return SVTME_ERR_DEVICE;
+    }
+    for (int i = 0; i < 6; ++i) wm->wmmat[i] = back->mat[i];
+    wm->alpha  = back->alpha;
+    wm->beta   = back->beta;
+    wm->gamma  = back->gamma;
+    wm->delta  = back->delta;
+    wm->wmtype = back->wmtype;
+    *error     = (int64_t)back->best_error;
+    if (evaluations) *evaluations = (uint32_t)back->evals;
+    return SVTME_OK;
 }
 
 // ---- TPL dispenser: source-based mode search

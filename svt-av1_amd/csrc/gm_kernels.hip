@@ -270,70 +270,343 @@ __global__ __launch_bounds__(64) void gm_match_kernel(DevPlane frm, DevPlane ref
 }
 
 // -------------------------------------------------------------------------------------------------- warp / frame error
-// One wave per 32x32 block of the error measure (WARP_ERROR_BLOCK, EbEncWarpedMotion.c:20): its 8x8 blocks one after the
-// other, 15 x 8 horizontally filtered values through LDS, then a lane per output pixel; block_err[block] = the block's sum
-// of error_measure(frame - warped). identity != 0: no warp, the frame error against the reference picture itself.
-__global__ __launch_bounds__(64) void gm_warp_error_kernel(DevPlane frm, DevPlane ref, svtme_gm_warp wm, int identity, const int16_t *filter,
-                                                           const int32_t *lut, uint32_t *block_err) {
-    __shared__ int16_t s_filter[193 * 8];
-    __shared__ int32_t s_lut[512];
-    __shared__ int32_t tmp[15 * 8];
-    const int          lane = threadIdx.x;
-    const int          w = frm.width, h = frm.height, bw = (w + 31) >> 5;
-    const int          bx = blockIdx.x % bw, by = blockIdx.x / bw;
-    const int          j0 = bx * 32, i0 = by * 32, ww = min(32, w - j0), wh = min(32, h - i0);
-    for (int k = lane; k < 512; k += 64) s_lut[k] = lut[k];
-    if (!identity)
-        for (int k = lane; k < 193 * 8 / 2; k += 64) reinterpret_cast<uint32_t *>(s_filter)[k] = reinterpret_cast<const uint32_t *>(filter)[k];
-    wave_sync();
-    uint32_t acc = 0;
+// One workgroup of four waves per 32x32 block of the error measure (WARP_ERROR_BLOCK, EbEncWarpedMotion.c:20), a wave per
+// 16x16 quadrant: its 8x8 blocks one after the other, 15 x 8 horizontally filtered values through LDS, then a lane per output
+// pixel. The waves share the filter and the error table in LDS; block_err[block] = the block's sum of
+// error_measure(frame - warped). identity != 0: no warp, the frame error against the reference picture itself.
+struct alignas(16) WarpTables {
+    int16_t filter[193 * 8]; // a filter's eight coefficients: 16 bytes, read as one piece
+    int32_t lut[512];
+    int32_t tmp[4][15 * 8];
+    uint32_t part[4];
+};
+
+__device__ __forceinline__ void stage_warp_tables(WarpTables &t, const int16_t *filter, const int32_t *lut, bool with_filter) {
+    for (int k = threadIdx.x; k < 512; k += 256) t.lut[k] = lut[k];
+    if (with_filter)
+        for (int k = threadIdx.x; k < 193 * 8 / 2; k += 256) reinterpret_cast<uint32_t *>(t.filter)[k] = reinterpret_cast<const uint32_t *>(filter)[k];
+    __syncthreads();
+}
+
+typedef short short2_t __attribute__((ext_vector_type(2)));
+// acc + a.lo * b.lo + a.hi * b.hi on the signed 16-bit halves
+__device__ __forceinline__ int32_t dot2(int32_t a, int32_t b, int32_t acc) {
+    return __builtin_amdgcn_sdot2(__builtin_bit_cast(short2_t, a), __builtin_bit_cast(short2_t, b), acc, false);
+}
+// acc + the eight bytes of (lo, hi) times the eight 16-bit coefficients of f
+__device__ __forceinline__ int32_t taps8(uint32_t lo, uint32_t hi, const int4 &f, int32_t acc) {
+    acc = dot2((int32_t)__builtin_amdgcn_perm(0, lo, 0x0c010c00), f.x, acc);
+    acc = dot2((int32_t)__builtin_amdgcn_perm(0, lo, 0x0c030c02), f.y, acc);
+    acc = dot2((int32_t)__builtin_amdgcn_perm(0, hi, 0x0c010c00), f.z, acc);
+    return dot2((int32_t)__builtin_amdgcn_perm(0, hi, 0x0c030c02), f.w, acc);
+}
+
+// The wave's share of a 32x32 block's error (svt_av1_warp_affine_c, EbWarpedMotion.c:577-694, on the 8x8 blocks of the
+// quadrant; svt_av1_calc_frame_error_c, EbEncWarpedMotion.c:162-171). The same sum in every lane.
+__device__ uint32_t warp_block_share(const DevPlane &frm, const DevPlane &ref, const svtme_gm_warp &wm, int identity, WarpTables &t, int block) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int w = frm.width, h = frm.height, bw = (w + 31) >> 5;
+    const int bx = block % bw, by = block / bw;
+    const int j0 = bx * 32, i0 = by * 32, ww = min(32, w - j0), wh = min(32, h - i0);
+    uint32_t  acc = 0;
     if (identity) {
-        for (int p = lane; p < 32 * 32; p += 64) {
+        for (int p = threadIdx.x; p < 32 * 32; p += 256) {
             const int y = p >> 5, x = p & 31;
             if (x < ww && y < wh)
-                acc += (uint32_t)s_lut[255 + frm.pix[(ptrdiff_t)(i0 + y) * frm.stride + j0 + x] - ref.pix[(ptrdiff_t)(i0 + y) * ref.stride + j0 + x]];
+                acc += (uint32_t)t.lut[255 + frm.pix[(ptrdiff_t)(i0 + y) * frm.stride + j0 + x] - ref.pix[(ptrdiff_t)(i0 + y) * ref.stride + j0 + x]];
         }
-    } else {
-        for (int i = i0; i < i0 + wh; i += 8)
-            for (int j = j0; j < j0 + ww; j += 8) {
-                const int32_t src_x = j + 4, src_y = i + 4;
-                const int32_t x4 = (int32_t)((uint32_t)wm.wmmat[2] * (uint32_t)src_x + (uint32_t)wm.wmmat[3] * (uint32_t)src_y + (uint32_t)wm.wmmat[0]);
-                const int32_t y4 = (int32_t)((uint32_t)wm.wmmat[4] * (uint32_t)src_x + (uint32_t)wm.wmmat[5] * (uint32_t)src_y + (uint32_t)wm.wmmat[1]);
-                const int32_t ix4 = x4 >> 16, iy4 = y4 >> 16;
-                int32_t       sx4 = x4 & 0xffff, sy4 = y4 & 0xffff;
-                sx4 += wm.alpha * -4 + wm.beta * -4;
-                sy4 += wm.gamma * -4 + wm.delta * -4;
-                sx4 &= ~63;
-                sy4 &= ~63;
-                // horizontal filter: rows iy4 - 7 .. iy4 + 7, 8 columns each
-                for (int t = lane; t < 15 * 8; t += 64) {
-                    const int      k = (t >> 3) - 7, l = (t & 7) - 4;
+        return wave_sum(acc);
+    }
+    int32_t  *tmp = t.tmp[wave];
+    const int iq = i0 + 16 * (wave >> 1), jq = j0 + 16 * (wave & 1);
+    for (int i = iq; i < min(iq + 16, i0 + wh); i += 8)
+        for (int j = jq; j < min(jq + 16, j0 + ww); j += 8) {
+            const int32_t src_x = j + 4, src_y = i + 4;
+            const int32_t x4 = (int32_t)((uint32_t)wm.wmmat[2] * (uint32_t)src_x + (uint32_t)wm.wmmat[3] * (uint32_t)src_y + (uint32_t)wm.wmmat[0]);
+            const int32_t y4 = (int32_t)((uint32_t)wm.wmmat[4] * (uint32_t)src_x + (uint32_t)wm.wmmat[5] * (uint32_t)src_y + (uint32_t)wm.wmmat[1]);
+            const int32_t ix4 = x4 >> 16, iy4 = y4 >> 16;
+            int32_t       sx4 = x4 & 0xffff, sy4 = y4 & 0xffff;
+            sx4 += wm.alpha * -4 + wm.beta * -4;
+            sy4 += wm.gamma * -4 + wm.delta * -4;
+            sx4 &= ~63;
+            sy4 &= ~63;
+            // horizontal filter: rows iy4 - 7 .. iy4 + 7, 8 columns each; value s = row * 8 + column
+            if (ix4 >= 7 && ix4 + 7 < ref.width && iy4 >= 7 && iy4 + 7 < ref.height) {
+                // all 15 x 15 pixels lie inside the picture (the usual block): a lane's eight taps are eight consecutive
+                // bytes, one load; pairs of them against pairs of coefficients
+                const uint8_t *base = ref.pix + (ptrdiff_t)(iy4 - 7) * ref.stride + (ix4 - 7);
+                for (int s = lane; s < 15 * 8; s += 64) {
+                    const int          r = s >> 3, c = s & 7;
+                    unsigned long long v;
+                    __builtin_memcpy(&v, base + (uint32_t)(r * ref.stride + c), 8);
+                    const int  sx = sx4 + wm.beta * (r - 3) + wm.alpha * c;
+                    const int4 f  = *reinterpret_cast<const int4 *>(t.filter + 8 * min(max(((sx + 512) >> 10) + 64, 0), 192));
+                    tmp[s]        = (taps8((uint32_t)v, (uint32_t)(v >> 32), f, 1 << 14) + 4) >> 3;
+                }
+            } else
+                for (int s = lane; s < 15 * 8; s += 64) {
+                    const int      k = (s >> 3) - 7, l = (s & 7) - 4;
                     const uint8_t *row = ref.pix + (ptrdiff_t)min(max(iy4 + k, 0), ref.height - 1) * ref.stride;
                     const int      sx = sx4 + wm.beta * (k + 4) + wm.alpha * (l + 4);
-                    const int16_t *f  = s_filter + 8 * min(max(((sx + 512) >> 10) + 64, 0), 192); // (0 .. 192 for a valid shear)
+                    const int16_t *f  = t.filter + 8 * min(max(((sx + 512) >> 10) + 64, 0), 192); // (0 .. 192 for a valid shear)
                     int32_t        sum = 1 << 14;
 #pragma unroll
                     for (int m = 0; m < 8; ++m) sum += row[min(max(ix4 + l - 3 + m, 0), ref.width - 1)] * f[m];
-                    tmp[t] = (sum + 4) >> 3;
+                    tmp[s] = (sum + 4) >> 3;
                 }
-                wave_sync();
-                {
-                    const int k = (lane >> 3) - 4, l = (lane & 7) - 4;
-                    if (k < min(4, i0 + wh - i - 4) && l < min(4, j0 + ww - j - 4)) {
-                        const int      sy = sy4 + wm.delta * (k + 4) + wm.gamma * (l + 4);
-                        const int16_t *f  = s_filter + 8 * min(max(((sy + 512) >> 10) + 64, 0), 192);
-                        int32_t        sum = 1 << 19;
-#pragma unroll
-                        for (int m = 0; m < 8; ++m) sum += tmp[(k + m + 4) * 8 + l + 4] * f[m];
-                        const int pix = min(max(((sum + 1024) >> 11) - 128 - 256, 0), 255);
-                        acc += (uint32_t)s_lut[255 + frm.pix[(ptrdiff_t)(i + k + 4) * frm.stride + j + l + 4] - pix];
-                    }
+            wave_sync();
+            {
+                const int k = (lane >> 3) - 4, l = (lane & 7) - 4;
+                if (k < min(4, i0 + wh - i - 4) && l < min(4, j0 + ww - j - 4)) {
+                    const int  sy = sy4 + wm.delta * (k + 4) + wm.gamma * (l + 4);
+                    const int4 f  = *reinterpret_cast<const int4 *>(t.filter + 8 * min(max(((sy + 512) >> 10) + 64, 0), 192));
+                    // the filtered values are positive and below 2^16 (an offset of 2^14 went into them, :630-640)
+                    const int32_t *col = tmp + lane;
+                    int32_t        sum = 1 << 19;
+                    sum = dot2(col[0] | (col[8] << 16), f.x, sum);
+                    sum = dot2(col[16] | (col[24] << 16), f.y, sum);
+                    sum = dot2(col[32] | (col[40] << 16), f.z, sum);
+                    sum = dot2(col[48] | (col[56] << 16), f.w, sum);
+                    const int pix = min(max(((sum + 1024) >> 11) - 128 - 256, 0), 255);
+                    acc += (uint32_t)t.lut[255 + frm.pix[(ptrdiff_t)(i + k + 4) * frm.stride + j + l + 4] - pix];
                 }
-                wave_sync();
             }
+            wave_sync();
+        }
+    return wave_sum(acc);
+}
+
+// the four waves' shares -> the block's sum, in thread 0
+__device__ __forceinline__ uint32_t warp_block_total(WarpTables &t, uint32_t share) {
+    if ((threadIdx.x & 63) == 0) t.part[threadIdx.x >> 6] = share;
+    __syncthreads();
+    return t.part[0] + t.part[1] + t.part[2] + t.part[3];
+}
+
+__global__ __launch_bounds__(256) void gm_warp_error_kernel(DevPlane frm, DevPlane ref, svtme_gm_warp wm, int identity, const int16_t *filter,
+                                                            const int32_t *lut, uint32_t *block_err) {
+    __shared__ WarpTables t;
+    stage_warp_tables(t, filter, lut, !identity);
+    const uint32_t total = warp_block_total(t, warp_block_share(frm, ref, wm, identity, t, blockIdx.x));
+    if (threadIdx.x == 0) block_err[blockIdx.x] = total;
+}
+
+// ------------------------------------------------------------------------------------------- parameter refinement
+// svt_av1_refine_integerized_param (Source/Lib/Encoder/Codec/global_motion.c:135-263) as a state machine that one lane
+// advances after every error evaluation: the loop's position (refinement step, parameter, which of "look left", "look right",
+// "keep walking" it is in) lives in GmRefineState, so that a chain of identical kernel launches, each one evaluation,
+// replays the loop without the host in between.
+//
+// What decides the loop is only whether an evaluation's error is below the best one so far: svt_av1_warp_error's early
+// return (EbEncWarpedMotion.c:206-209) hands back a partial sum above best_error, which fails that comparison exactly as the
+// whole sum would (the per-pixel errors are not negative), and a best error is only ever taken from a sum that ran to the end.
+// So every evaluation here is the whole picture's sum.
+enum { GM_PH_FIRST = 0, GM_PH_LEFT = 1, GM_PH_RIGHT = 2, GM_PH_WALK = 3 };
+
+// svt_get_shear_params (Source/Lib/Common/Codec/EbWarpedMotion.c:1115-1144) on the state's matrix. The divisor table
+// (div_lut, :301-322) in closed form: entry f = 2^22 / (256 + f), rounded to nearest.
+__device__ __forceinline__ bool gm_shear(GmRefineState &st) {
+    const int32_t *mat = st.mat;
+    if (mat[2] <= 0) return false; // is_affine_valid, :359-362
+    auto clamp16 = [](int v) { return min(max(v, -32768), 32767); };
+    auto round64 = [](long long v, int n) { // ROUND_POWER_OF_TWO_SIGNED_64
+        return v < 0 ? -((-v + ((1ll << n) >> 1)) >> n) : ((v + ((1ll << n) >> 1)) >> n);
+    };
+    auto reduce = [](int v) { // ROUND_POWER_OF_TWO_SIGNED(v, WARP_PARAM_REDUCE_BITS) * (1 << WARP_PARAM_REDUCE_BITS), into an int16_t
+        return (int16_t)((v < 0 ? -((-v + 32) >> 6) : ((v + 32) >> 6)) * 64);
+    };
+    int alpha = clamp16(mat[2] - (1 << 16)), beta = clamp16(mat[3]);
+    // resolve_divisor_32(mat[2]), :343-357
+    const uint32_t d     = (uint32_t)mat[2];
+    int            shift = 31 - __clz((int)d);
+    const int32_t  e     = (int32_t)(d - (1u << shift));
+    const int32_t  f     = shift > 8 ? (e + ((1 << (shift - 8)) >> 1)) >> (shift - 8) : e << (8 - shift);
+    shift += 14;
+    const int y = (int)(((1u << 22) + (uint32_t)(256 + f) / 2) / (uint32_t)(256 + f));
+    long long v = ((long long)mat[4] * (1 << 16)) * y;
+    const int gamma = clamp16((int)round64(v, shift));
+    v               = ((long long)mat[3] * mat[4]) * y;
+    const int delta = clamp16(mat[5] - (int)round64(v, shift) - (1 << 16));
+    st.alpha = reduce(alpha);
+    st.beta  = reduce(beta);
+    st.gamma = reduce(gamma);
+    st.delta = reduce(delta);
+    // is_affine_shear_allowed, :364-370
+    return !(4 * abs((int)st.alpha) + 7 * abs((int)st.beta) >= (1 << 16) || 4 * abs((int)st.gamma) + 4 * abs((int)st.delta) >= (1 << 16));
+}
+
+// add_param_offset, global_motion.c:91-113
+__device__ __forceinline__ int32_t gm_add_param_offset(int index, int32_t value, int32_t offset) {
+    const int scale = index < 2 ? 10 : 1; // GM_TRANS_PREC_DIFF, GM_ALPHA_PREC_DIFF
+    const int centre = (index == 2 || index == 5) ? (1 << 16) : 0;
+    value = (value - centre) >> scale;
+    value += offset;
+    value = min(max(value, -4096), 4096); // GM_TRANS_MAX = GM_ALPHA_MAX = 1 << 12
+    value *= 1 << scale;
+    return value + centre;
+}
+
+// force_wmtype, global_motion.c:115-133 (wmmat[6] and [7] are zero for every type; the state does not hold them)
+__device__ __forceinline__ void gm_force_wmtype(GmRefineState &st) {
+    switch (st.wmtype) {
+    case 0: st.mat[0] = st.mat[1] = 0; [[fallthrough]];
+    case 1: st.mat[2] = 1 << 16; st.mat[3] = 0; [[fallthrough]];
+    case 2: st.mat[4] = -st.mat[3]; st.mat[5] = st.mat[2]; [[fallthrough]];
+    default: break;
     }
-    acc = wave_sum(acc);
-    if (lane == 0) block_err[blockIdx.x] = acc;
+}
+
+// What svt_av1_warp_error does before it looks at the pictures (EbEncWarpedMotion.c:233-235, svt_warp_plane,
+// EbWarpedMotion.c:701-704): the shear from the matrix as it stands - an invalid one makes the evaluation's result 1 - and
+// only then, for a rotation-zoom model, the matrix's second row from its first.
+__device__ __forceinline__ void gm_prepare_evaluation(GmRefineState &st) {
+    st.skip = gm_shear(st) ? 0 : 1;
+    if (!st.skip && st.wmtype == 2) {
+        st.mat[5] = st.mat[2];
+        st.mat[4] = -st.mat[3];
+    }
+}
+
+__device__ __forceinline__ void gm_finish(GmRefineState &st) {
+    gm_force_wmtype(st);
+    // get_wmtype, global_motion.c:71-80
+    const int32_t *m = st.mat;
+    if (m[5] == (1 << 16) && !m[4] && m[2] == (1 << 16) && !m[3]) st.wmtype = (!m[1] && !m[0]) ? 0 : 1;
+    else st.wmtype = (m[2] == m[5] && m[3] == -m[4]) ? 2 : 3;
+    st.done = 1;
+}
+
+// wmmat[p] for a p that is not known before run time, with the matrix in registers
+__device__ __forceinline__ int32_t gm_mat(const GmRefineState &st, int p) {
+    const int32_t a = p & 1 ? st.mat[1] : st.mat[0], b = p & 1 ? st.mat[3] : st.mat[2], c = p & 1 ? st.mat[5] : st.mat[4];
+    return p < 2 ? a : (p < 4 ? b : c);
+}
+__device__ __forceinline__ void gm_set_mat(GmRefineState &st, int p, int32_t v) {
+    st.mat[0] = p == 0 ? v : st.mat[0];
+    st.mat[1] = p == 1 ? v : st.mat[1];
+    st.mat[2] = p == 2 ? v : st.mat[2];
+    st.mat[3] = p == 3 ? v : st.mat[3];
+    st.mat[4] = p == 4 ? v : st.mat[4];
+    st.mat[5] = p == 5 ? v : st.mat[5];
+}
+
+// One evaluation's error has arrived: the loop moves on to its next evaluation, or ends. (One copy of each piece of the
+// loop, reached by flags rather than by calls from every phase: the code runs once per launch, on one lane, from a cold
+// instruction cache, so its size is its cost.)
+__device__ __forceinline__ void gm_advance(GmRefineState &st, long long err) {
+    ++st.evals;
+    const bool better = err < st.best_error;
+    bool       begin = false, next = false;
+    switch (st.phase) {
+    case GM_PH_FIRST: // :152-171
+        st.best_error = min(err, st.best_error);
+        st.step       = 1 << (st.n_refinements - 1);
+        st.i = st.p = 0;
+        begin       = true;
+        break;
+    case GM_PH_LEFT: // :195-199, then "look to the right" :201-226
+        if (better) {
+            st.best_error = err;
+            st.best_param = gm_mat(st, st.p);
+            st.step_dir   = -1;
+        }
+        gm_set_mat(st, st.p, gm_add_param_offset(st.p, st.curr_param, st.step));
+        st.phase = GM_PH_RIGHT;
+        break;
+    case GM_PH_RIGHT: // :221-226, then the walk in the chosen direction :228-257
+        if (better) {
+            st.best_error = err;
+            st.best_param = gm_mat(st, st.p);
+            st.step_dir   = 1;
+        }
+        st.phase = GM_PH_WALK;
+        next     = st.step_dir == 0;
+        gm_set_mat(st, st.p, next ? st.best_param : gm_add_param_offset(st.p, st.best_param, st.step * st.step_dir));
+        break;
+    default: // GM_PH_WALK
+        if (better) {
+            st.best_error = err;
+            st.best_param = gm_mat(st, st.p);
+        }
+        next = !better;
+        gm_set_mat(st, st.p, next ? st.best_param : gm_add_param_offset(st.p, st.best_param, st.step * st.step_dir));
+        break;
+    }
+    if (next) { // the next parameter, after the last one the next refinement step
+        if (++st.p == st.n_params) {
+            st.p = 0;
+            ++st.i;
+            st.step >>= 1;
+        }
+        begin = true;
+    }
+    if (begin) { // the loop's head for parameter p of refinement step i: "look to the left" (:178-199)
+        if (st.i >= st.n_refinements || st.n_params == 0) {
+            gm_finish(st);
+            return;
+        }
+        st.step_dir   = 0;
+        st.curr_param = st.best_param = gm_mat(st, st.p);
+        gm_set_mat(st, st.p, gm_add_param_offset(st.p, st.curr_param, -st.step));
+        st.phase = GM_PH_LEFT;
+    }
+    gm_prepare_evaluation(st);
+}
+
+// `init`: the caller's model (mat, shear), the type to force, n_refinements, best_error = the caller's best_frame_error.
+__global__ void gm_refine_begin_kernel(GmRefineState *state, GmRefineState init) {
+    if (threadIdx.x) return;
+    GmRefineState st = init;
+    st.n_params      = 2 * st.wmtype; // max_trans_model_params {0, 2, 4, 6}, global_motion.c:140
+    st.phase    = GM_PH_FIRST;
+    st.i = st.p = st.step = st.step_dir = st.curr_param = st.best_param = 0;
+    st.done = st.evals = 0;
+    gm_force_wmtype(st);
+    gm_prepare_evaluation(st);
+    *state = st;
+}
+
+// One evaluation of the chain: every workgroup adds up its 32x32 block with the state's model, gm_refine_step_kernel then
+// adds the blocks up and advances the loop. (One kernel that did both, the workgroups counting themselves off with a
+// device-wide atomic each, took 1.6 times as long at 1080p.) After the loop has ended the launches that are still queued
+// return at once.
+__global__ __launch_bounds__(256) void gm_refine_eval_kernel(DevPlane frm, DevPlane ref, const GmRefineState *state, const int16_t *filter,
+                                                             const int32_t *lut, uint32_t *block_err) {
+    __shared__ WarpTables t;
+    const GmRefineState st = *state;
+    if (st.done || st.skip) return;
+    svtme_gm_warp wm;
+    for (int k = 0; k < 6; ++k) wm.wmmat[k] = st.mat[k];
+    wm.alpha = st.alpha;
+    wm.beta  = st.beta;
+    wm.gamma = st.gamma;
+    wm.delta = st.delta;
+    stage_warp_tables(t, filter, lut, true);
+    const uint32_t total = warp_block_total(t, warp_block_share(frm, ref, wm, 0, t, blockIdx.x));
+    if (threadIdx.x == 0) block_err[blockIdx.x] = total;
+}
+
+__global__ __launch_bounds__(256) void gm_refine_step_kernel(GmRefineState *state, const uint32_t *block_err, int n) {
+    __shared__ unsigned long long part[4];
+    GmRefineState      st = *state; // (asked for together with the sums below: one trip to memory, not two)
+    unsigned long long sum = 0;
+    for (int b0 = 0; b0 < n; b0 += 8 * 256) { // eight loads in flight per thread
+        uint32_t v[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const int b = b0 + k * 256 + (int)threadIdx.x;
+            v[k]        = b < n ? block_err[b] : 0;
+        }
+#pragma unroll
+        for (int k = 0; k < 8; ++k) sum += v[k];
+    }
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) sum += __shfl_xor(sum, m);
+    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = sum;
+    __syncthreads();
+    if (threadIdx.x || st.done) return;
+    gm_advance(st, st.skip ? 1 : (long long)(part[0] + part[1] + part[2] + part[3]));
+    *state = st;
 }
 
 // The reference adds the blocks up in raster order and returns at the first block that takes the sum above best_error
@@ -389,8 +662,19 @@ void launch_gm_error(const DevPlane &frm, const DevPlane &ref, const svtme_gm_wa
     const int     n = ((frm.width + 31) / 32) * ((frm.height + 31) / 32);
     svtme_gm_warp w{};
     if (wm) w = *wm;
-    gm_warp_error_kernel<<<n, 64, 0, s>>>(frm, ref, w, wm ? 0 : 1, filter, lut, block_err);
+    gm_warp_error_kernel<<<n, 256, 0, s>>>(frm, ref, w, wm ? 0 : 1, filter, lut, block_err);
     gm_error_scan_kernel<<<1, 1024, 0, s>>>(block_err, n, best_error, result);
+}
+
+void launch_gm_refine_begin(GmRefineState *state, const GmRefineState &init, hipStream_t s) { gm_refine_begin_kernel<<<1, 64, 0, s>>>(state, init); }
+
+void launch_gm_refine_evaluations(const DevPlane &frm, const DevPlane &ref, GmRefineState *state, const int16_t *filter, const int32_t *lut,
+                                  uint32_t *block_err, int count, hipStream_t s) {
+    const int n = ((frm.width + 31) / 32) * ((frm.height + 31) / 32);
+    for (int i = 0; i < count; ++i) {
+        gm_refine_eval_kernel<<<n, 256, 0, s>>>(frm, ref, state, filter, lut, block_err);
+        gm_refine_step_kernel<<<1, 256, 0, s>>>(state, block_err, n);
+    }
 }
 
 } // namespace svtme

@@ -193,6 +193,23 @@ void launch_gm_match(const DevPlane &frm, const DevPlane &ref, const int *frm_co
 void launch_gm_error(const DevPlane &frm, const DevPlane &ref, const svtme_gm_warp *wm, const int16_t *filter, const int32_t *lut,
                      uint32_t *block_err, long long best_error, long long *result, hipStream_t s);
 
+// svtme_gm_refine: where svt_av1_refine_integerized_param's loop (global_motion.c:135-263) stands, kept in device memory
+// between the evaluations of a chain
+struct GmRefineState {
+    int32_t   mat[6]; // wm->wmmat[0..5] as the loop holds it (the next evaluation's model)
+    int16_t   alpha, beta, gamma, delta; // wm's shear as the last svt_get_shear_params left it
+    int32_t   wmtype; // the type the loop forces; the resulting type once done
+    int32_t   n_refinements, n_params;
+    int32_t   phase, i, p, step, step_dir, curr_param, best_param; // the loop's position
+    int32_t   skip; // the next evaluation's result is 1 without a warp (the shear derivation failed)
+    int32_t   done, evals;
+    long long best_error;
+};
+void launch_gm_refine_begin(GmRefineState *state, const GmRefineState &init, hipStream_t s);
+// `count` evaluations of the chain: two launches each (the blocks' errors; their sum and the loop's next move)
+void launch_gm_refine_evaluations(const DevPlane &frm, const DevPlane &ref, GmRefineState *state, const int16_t *filter, const int32_t *lut,
+                                  uint32_t *block_err, int count, hipStream_t s);
+
 // TPL dispenser, source-based mode search (tpl_kernels.hip): the planes and the ME results of one picture
 struct TplParams {
     DevPlane cur; // full-resolution planes

@@ -121,6 +121,7 @@ EXPORTS = ("svtme_version", "svtme_derive_controls", "svtme_derive_tf_controls",
            "svtme_group_picture_submit", "svtme_group_picture_wait", "svtme_group_picture_done", "svtme_group_stats",
            "svtme_group_engine_for", "svtme_group_gm_set_tables",
            "svtme_gm_set_tables", "svtme_gm_corners", "svtme_gm_correspondences", "svtme_gm_warp_error", "svtme_gm_frame_error",
+           "svtme_gm_refine",
            "svtme_tpl_search", "svtme_set_tile_rects", "svtme_group_set_tile_rects",
            "svtme_store_put_many", "svtme_store_copy_peer", "svtme_group_pictures_submit", "svtme_group_ticket_engine",
            "svtme_group_set_peer_copies", "svtme_group_peer_stats")
@@ -153,6 +154,11 @@ class TplPicture(C.Structure):
 class GmWarp(C.Structure):
     _fields_ = [("wmmat", C.c_int32 * 6), ("alpha", C.c_int16), ("beta", C.c_int16), ("gamma", C.c_int16), ("delta", C.c_int16)]
 STATIC_MAX_B64 = 2040
+
+
+class GmModel(C.Structure):
+    _fields_ = [("wmmat", C.c_int32 * 6), ("alpha", C.c_int16), ("beta", C.c_int16), ("gamma", C.c_int16), ("delta", C.c_int16),
+                ("wmtype", C.c_int32)]
 
 
 def static_result_bytes(n_b64, n_refs):
@@ -223,6 +229,8 @@ def load_library():
     lib.svtme_gm_correspondences.argtypes = [C.c_void_p, C.c_uint64, C.c_uint64, C.c_int, C.c_void_p, C.POINTER(C.c_int32)]
     lib.svtme_gm_warp_error.argtypes = [C.c_void_p, C.c_uint64, C.c_uint64, C.c_int, C.POINTER(GmWarp), C.c_int64, C.POINTER(C.c_int64)]
     lib.svtme_gm_frame_error.argtypes = [C.c_void_p, C.c_uint64, C.c_uint64, C.c_int, C.POINTER(C.c_int64)]
+    lib.svtme_gm_refine.argtypes = [C.c_void_p, C.c_uint64, C.c_uint64, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int64, C.POINTER(C.c_int64),
+                                    C.POINTER(C.c_uint32)]
     lib.svtme_tpl_search.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
     lib.svtme_set_tile_rects.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p, C.c_uint32]
     lib.svtme_group_set_tile_rects.argtypes = lib.svtme_set_tile_rects.argtypes
@@ -665,6 +673,16 @@ class Engine:
         if rc:
             raise SvtmeError(rc, "svtme_gm_frame_error")
         return err.value
+
+    def gm_refine(self, cur_key, ref_key, level, mat, wmtype, steps, best_frame_error=(1 << 63) - 1, shear=(0, 0, 0, 0), model_wmtype=None):
+        """svt_av1_refine_integerized_param as one call -> (mat [6], shear [4], wmtype, error, evaluations)."""
+        m = GmModel((C.c_int32 * 6)(*[int(v) for v in mat]), *[int(v) for v in shear], int(wmtype if model_wmtype is None else model_wmtype))
+        err, n = C.c_int64(0), C.c_uint32(0)
+        rc = self.lib.svtme_gm_refine(self.h, cur_key, ref_key, level, C.byref(m), int(wmtype), int(steps), int(best_frame_error), C.byref(err),
+                                      C.byref(n))
+        if rc:
+            raise SvtmeError(rc, "svtme_gm_refine")
+        return list(m.wmmat), [m.alpha, m.beta, m.gamma, m.delta], int(m.wmtype), err.value, n.value
 
     def tpl_search(self, pic):
         """pic: a TplPicture (or any ctypes structure of that layout). Returns TPL_BLOCK records [n_b64, 21]."""

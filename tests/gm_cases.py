@@ -33,6 +33,43 @@ CASES = {
     "rotzoom_1920x1080": dict(kind="warped", width=1920, height=1080, n_frames=2, seed=3, rot=(25, 0), zoom=(60, 0), shift=(4, -2),
                               jobs=[dict(cur=1, ref=0, level=0, rotzoom_only=1, steps=5), dict(cur=1, ref=0, level=1, rotzoom_only=1, steps=5)]),
 }
+# Single svt_av1_refine_integerized_param calls (tests/golden/gm_refine_*.npz) on a case's pictures, for what the estimation
+# itself does not arrive at: every model type forced, matrices whose shear is invalid (result 1 without a warp), parameters at
+# their clamps, an error to beat that nothing beats. A call: level, matrix, type to force, refinement steps, error to beat.
+I64_MAX = (1 << 63) - 1
+REFINE_CASES = {
+    "affine_392x264": dict(cur=1, ref=0, calls=[
+        dict(level=0, mat=[185344, 108544, 65628, -52, 80, 65700], wmtype=3, steps=5, best=I64_MAX),
+        dict(level=1, mat=[61440, 56320, 65836, 110, -60, 65700], wmtype=3, steps=3, best=I64_MAX),
+        dict(level=2, mat=[30720, 28160, 65836, 110, -60, 65700], wmtype=3, steps=5, best=I64_MAX),
+        dict(level=0, mat=[178176, 106496, 65670, -36, 36, 65670], wmtype=1, steps=5, best=I64_MAX),
+        dict(level=0, mat=[178176, 106496, 65670, -36, 36, 65670], wmtype=0, steps=5, best=I64_MAX),
+        dict(level=1, mat=[0, 0, -5, 0, 0, 65536], wmtype=3, steps=5, best=I64_MAX),  # is_affine_valid fails at first
+        dict(level=1, mat=[0, 0, 65536, 12000, 0, 65536], wmtype=3, steps=4, best=I64_MAX),  # the shear is not allowed at first
+        dict(level=0, mat=[178176, 106496, 65670, -36, 36, 65670], wmtype=2, steps=5, best=1000),
+        dict(level=0, mat=[178176, 106496, 65670, -36, 36, 65670], wmtype=2, steps=5, best=83009032),  # the recorded run's result: a tie
+        dict(level=1, mat=[4194304, -4194304, 65536, 0, 0, 65536], wmtype=2, steps=2, best=I64_MAX),  # translations at their clamps
+        dict(level=0, mat=[0, 0, 65536 + 8190, 8190, -8190, 65536 - 8190], wmtype=3, steps=1, best=I64_MAX),  # the other parameters at theirs
+    ]),
+    "translation_512x256": dict(cur=1, ref=0, calls=[
+        dict(level=0, mat=[300000, -180000, 65536, 0, 0, 65536], wmtype=1, steps=5, best=I64_MAX),  # a walk of several steps
+        dict(level=1, mat=[120000, -110000, 65536, 0, 0, 65536], wmtype=1, steps=6, best=I64_MAX),
+        dict(level=0, mat=[327680, -196608, 65536, 0, 0, 65536], wmtype=2, steps=1, best=I64_MAX),
+    ]),
+}
+
+
+def refine_jobs(name):
+    c = REFINE_CASES[name]
+    return [dict(cur=c["cur"], ref=c["ref"], level=k["level"], steps=k["steps"], direct=(k["mat"], k["wmtype"], k["best"])) for k in c["calls"]]
+
+
+def refine_golden_of(name):
+    """-> per call (refine_call [len(gmio.REFINE_FIELDS)], warp_calls [n, len(gmio.WARP_FIELDS)])."""
+    z = np.load(os.path.join(GOLDEN, "gm_refine_%s.npz" % name))
+    return [(z["c%d_refine" % i], z["c%d_warp_calls" % i]) for i in range(len(REFINE_CASES[name]["calls"]))]
+
+
 # fixtures too large for the CPU restatement to replay call by call in the CPU suite (the GPU tests replay them in full)
 HEAVY = ("rotzoom_1920x1080",)
 

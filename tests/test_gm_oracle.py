@@ -1,6 +1,7 @@
 """The CPU restatement of the global-motion stages (oracle/gm_oracle.c) against the fixtures the real reference produced
 (tests/golden/gm_*.npz): FAST-9 corners, correspondences, and - with the warp filter and error tables taken from the
-reference build at run time, they are not kept in this repository - every warp / frame error call of the recorded runs."""
+reference build at run time, they are not kept in this repository - every warp / frame error call of the recorded runs and
+every refinement (svt_av1_refine_integerized_param as a whole: the recorded runs' and tests/golden/gm_refine_*.npz)."""
 import os
 import sys
 
@@ -53,6 +54,41 @@ def test_every_recorded_error_call_is_reproduced(name):
             assert got == c["error"], (name, c, got)
         for e in g["frame_errors"]:
             assert gmio.oracle_frame_error(tables, ref, frm) == int(e)
+
+
+def _check_refine(tables, rec, n_warp_calls, ref, frm):
+    c = dict(zip(gmio.REFINE_FIELDS, (int(v) for v in rec)))
+    mat, shear, wmtype, err, evals = gmio.oracle_refine(tables, [c["i%d" % i] for i in range(6)], [c["i_alpha"], c["i_beta"], c["i_gamma"], c["i_delta"]],
+                                                        c["i_wmtype"], c["force_wmtype"], ref, frm, c["steps"], c["best_frame_error"])
+    assert (mat, shear, wmtype, err) == ([c["o%d" % i] for i in range(6)], [c["o_alpha"], c["o_beta"], c["o_gamma"], c["o_delta"]], c["o_wmtype"],
+                                         c["error"]), c
+    assert evals == n_warp_calls
+
+
+@pytest.mark.skipif(not gmio.have_reference(), reason="the tables come from oracle/_ref/ref_gm, built where the reference sources are")
+@pytest.mark.parametrize("name", LIGHT)
+def test_every_recorded_refinement_is_reproduced(name):
+    tables = gmio.reference_tables()
+    case = gm_cases.CASES[name]
+    frames = gm_cases.frames_of(case)
+    for job, g in zip(case["jobs"], gm_cases.golden_of(name)):
+        frm = gmio.plane_of(frames[job["cur"]], job["level"])
+        ref = gmio.plane_of(frames[job["ref"]], job["level"])
+        assert len(g["refine_calls"]) <= 1  # (one RANSAC motion per model; the warp calls of a job are its refinement's)
+        for rec in g["refine_calls"]:
+            _check_refine(tables, rec, len(g["warp_calls"]), ref, frm)
+
+
+@pytest.mark.skipif(not gmio.have_reference(), reason="the tables come from oracle/_ref/ref_gm, built where the reference sources are")
+@pytest.mark.parametrize("name", list(gm_cases.REFINE_CASES))
+def test_single_refinements_of_every_model_type_are_reproduced(name):
+    tables = gmio.reference_tables()
+    c = gm_cases.REFINE_CASES[name]
+    frames = gm_cases.frames_of(gm_cases.CASES[name])
+    for call, (rec, warps) in zip(c["calls"], gm_cases.refine_golden_of(name)):
+        frm = gmio.plane_of(frames[c["cur"]], call["level"])
+        ref = gmio.plane_of(frames[c["ref"]], call["level"])
+        _check_refine(tables, rec, len(warps), ref, frm)
 
 
 @pytest.mark.skipif(not gmio.have_reference(), reason="needs oracle/_ref/ref_gm")

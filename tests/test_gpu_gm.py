@@ -18,6 +18,12 @@ pytestmark = pytest.mark.gpu
 needs_ref_build = pytest.mark.skipif(not gmio.have_reference(), reason="oracle/_ref/ref_gm (built where the reference sources are) is not here")
 
 
+# The fields of a refinement record that the reference defines: compute_global_motion hands over a model whose shear fields
+# it never wrote (tmp_wm_params, EbGlobalMotionEstimation.c:194, :228; the loop overwrites them before it reads them), so the
+# recorded input shear is whatever the process's stack held.
+_REFINE_DEFINED = [i for i, f in enumerate(gmio.REFINE_FIELDS) if f not in ("i_alpha", "i_beta", "i_gamma", "i_delta")]
+
+
 def _engine(case, tables=None):
     import svtme
     frames = gm_cases.frames_of(case)
@@ -100,13 +106,75 @@ def test_reference_global_motion_with_the_engine_behind_its_seam(name):
     import svtme
     case = gm_cases.CASES[name]
     recs = gmio.run_reference(gm_cases.frames_of(case), case["jobs"], library=svtme.LIB_PATH)
-    kind_no = {"corners": 1, "corr": 2, "warp": 3, "frame": 4}
+    kind_no = {"corners": 1, "corr": 2, "warp": 3, "frame": 4, "refine": 5}
     for r, g in zip(recs, gm_cases.golden_of(name)):
         assert [kind_no[k] for k, _ in r["calls"]] == [int(v) for v in g["call_kinds"]]
         assert np.array_equal(r["corners_frm"], g["corners_frm"]) and np.array_equal(r["corners_ref"], g["corners_ref"])
         assert np.array_equal(r["correspondences"], g["correspondences"])
         warps = np.array([[c[f] for f in gmio.WARP_FIELDS] for k, c in r["calls"] if k == "warp"], np.int64).reshape(-1, len(gmio.WARP_FIELDS))
         assert np.array_equal(warps, g["warp_calls"])
+        refines = np.array([[c[f] for f in gmio.REFINE_FIELDS] for k, c in r["calls"] if k == "refine"], np.int64).reshape(-1, len(gmio.REFINE_FIELDS))
+        assert np.array_equal(refines[:, _REFINE_DEFINED], g["refine_calls"][:, _REFINE_DEFINED])
+        assert [c for k, c in r["calls"] if k == "frame"] == [int(v) for v in g["frame_errors"]]
+        assert [r["final"][f] for f in gmio.FINAL_FIELDS] == [int(v) for v in g["final"]]
+
+
+def _refine_matches(eng, cur, ref, lvl, rec, n_warp_calls):
+    c = dict(zip(gmio.REFINE_FIELDS, (int(v) for v in rec)))
+    got = eng.gm_refine(cur, ref, lvl, [c["i%d" % i] for i in range(6)], c["force_wmtype"], c["steps"], c["best_frame_error"],
+                        shear=[c["i_alpha"], c["i_beta"], c["i_gamma"], c["i_delta"]], model_wmtype=c["i_wmtype"])
+    want = ([c["o%d" % i] for i in range(6)], [c["o_alpha"], c["o_beta"], c["o_gamma"], c["o_delta"]], c["o_wmtype"], c["error"], n_warp_calls)
+    assert got == want, (c, got)
+
+
+@needs_ref_build
+@pytest.mark.parametrize("name", list(gm_cases.CASES))
+def test_every_recorded_refinement_is_reproduced_by_one_call(name):
+    """svtme_gm_refine against svt_av1_refine_integerized_param of the real reference: the refined model, its type, the shear
+    the struct is left with, the returned error and the number of error evaluations the loop took."""
+    case = gm_cases.CASES[name]
+    eng, _ = _engine(case, gmio.reference_tables())
+    try:
+        for job, g in zip(case["jobs"], gm_cases.golden_of(name)):
+            for rec in g["refine_calls"]:
+                _refine_matches(eng, 100 + job["cur"], 100 + job["ref"], job["level"], rec, len(g["warp_calls"]))
+    finally:
+        eng.close()
+
+
+@needs_ref_build
+@pytest.mark.parametrize("name", list(gm_cases.REFINE_CASES))
+def test_single_refinements_of_every_model_type(name):
+    """Every model type forced, invalid shears (result 1 without a warp), parameters at their clamps, an error to beat that
+    nothing beats or that ties: tests/golden/gm_refine_*.npz, single calls of the reference's function."""
+    import svtme
+    c = gm_cases.REFINE_CASES[name]
+    eng, _ = _engine(gm_cases.CASES[name], gmio.reference_tables())
+    try:
+        for call, (rec, warps) in zip(c["calls"], gm_cases.refine_golden_of(name)):
+            _refine_matches(eng, 100 + c["cur"], 100 + c["ref"], call["level"], rec, len(warps))
+        for bad in (dict(wmtype=4, steps=5), dict(wmtype=2, steps=0), dict(wmtype=-1, steps=5)):
+            with pytest.raises(svtme.SvtmeError) as ei:
+                eng.gm_refine(101, 100, 0, [0, 0, 65536, 0, 0, 65536], bad["wmtype"], bad["steps"])
+            assert ei.value.code == svtme.ERR_BAD_ARG
+    finally:
+        eng.close()
+
+
+@needs_ref_build
+@pytest.mark.parametrize("name", ["rotzoom_320x192", "affine_392x264", "translation_512x256", "noise_640x360", "rotzoom_1920x1080"])
+def test_reference_global_motion_with_the_engine_refining(name):
+    """ref_gm with the refinement loop as a whole on the engine (svtme_gm_refine behind svt_av1_refine_integerized_param):
+    the reference's own loop does not run, so no single warp error is recorded; every refinement's result, the frame
+    errors and the final model equal the fixture of the unmodified reference."""
+    import svtme
+    case = gm_cases.CASES[name]
+    recs = gmio.run_reference(gm_cases.frames_of(case), case["jobs"], library=svtme.LIB_PATH, engine_refine=True)
+    for r, g in zip(recs, gm_cases.golden_of(name)):
+        assert not [1 for k, _ in r["calls"] if k == "warp"]
+        assert np.array_equal(r["correspondences"], g["correspondences"])
+        refines = np.array([[c[f] for f in gmio.REFINE_FIELDS] for k, c in r["calls"] if k == "refine"], np.int64).reshape(-1, len(gmio.REFINE_FIELDS))
+        assert np.array_equal(refines[:, _REFINE_DEFINED], g["refine_calls"][:, _REFINE_DEFINED])
         assert [c for k, c in r["calls"] if k == "frame"] == [int(v) for v in g["frame_errors"]]
         assert [r["final"][f] for f in gmio.FINAL_FIELDS] == [int(v) for v in g["final"]]
 

@@ -65,17 +65,23 @@ if have_ref and len(g["warp_calls"]):
     timed("warp error, whole picture", lambda: eng.gm_warp_error(1, 0, lvl, mat, shear))
     timed("warp error, stops at the first block", lambda: eng.gm_warp_error(1, 0, lvl, mat, shear, 0))
     timed("frame error", lambda: eng.gm_frame_error(1, 0, lvl))
+    for rec in g["refine_calls"]:
+        r = dict(zip(gmio.REFINE_FIELDS, (int(v) for v in rec)))
+        dt = timed("refinement loop, one call", lambda: eng.gm_refine(1, 0, lvl, [r["i%d" % i] for i in range(6)], r["force_wmtype"], r["steps"]), reps=10)
+        n = eng.gm_refine(1, 0, lvl, [r["i%d" % i] for i in range(6)], r["force_wmtype"], r["steps"])[4]
+        print("    %d evaluations, %.1f us each" % (n, dt * 1e6 / n))
 eng.close()
 if have_ref and not calls_only:
     for lib, avx2, label in ((None, False, "reference alone (C kernels)"), (None, True, "reference alone (AVX2 warp and frame error)"),
-                             (svtme.LIB_PATH, False, "reference with the engine behind its seam")):
+                             (svtme.LIB_PATH, False, "reference with the engine behind its seam"),
+                             (svtme.LIB_PATH, "refine", "the same, refinement loop on the engine")):
         best = 1e9
         for _ in range(3):
             t0 = time.perf_counter()
-            gmio.run_reference(frames, [job] * 4, library=lib, use_avx2=avx2)
+            gmio.run_reference(frames, [job] * 4, library=lib, use_avx2=avx2 is True, engine_refine=avx2 == "refine")
             best = min(best, time.perf_counter() - t0)
         t0 = time.perf_counter()
-        gmio.run_reference(frames, [], library=lib, use_avx2=avx2)  # start-up, picture store, engine creation: not global motion
+        gmio.run_reference(frames, [], library=lib, use_avx2=avx2 is True, engine_refine=avx2 == "refine")  # start-up, picture store, engine creation: not global motion
         base = time.perf_counter() - t0
         print("%-44s %9.1f ms per compute_global_motion (4 runs %.0f ms, set-up %.0f ms)" % (label, (best - base) / 4 * 1e3, best * 1e3, base * 1e3),
               flush=True)
