@@ -1728,7 +1728,7 @@ extern "C" int svtme_tpl_search(svtme_engine *e, const svtme_tpl_picture *pic, s
     GM_TRY(hipMemcpyAsync(g.d_tpl, g.h_tpl, mv_off + mv_bytes, hipMemcpyHostToDevice, st));
     GM_TRY(hipMemcpyAsync(g.d_tpl + par_off, g.h_tpl + par_off, sizeof(p), hipMemcpyHostToDevice, st));
     GM_TRY(hipMemsetAsync(g.d_tpl + out_off, 0, out_bytes + 64, st));
-    launch_tpl_search(reinterpret_cast<const TplParams *>(g.d_tpl + par_off), n_b64, st);
+    launch_tpl_search(reinterpret_cast<const TplParams *>(g.d_tpl + par_off), n_b64, p.mode_end > 0 || !p.sad_inter || !p.sad_intra, st);
     GM_TRY(hipGetLastError());
     GM_TRY(hipMemcpyAsync(g.h_tpl + out_off, g.d_tpl + out_off, out_bytes + 64, hipMemcpyDeviceToHost, st));
     GM_TRY(hipStreamSynchronize(st));

@@ -230,7 +230,9 @@ struct TplParams {
     svtme_tpl_block *out; // [n_b64][SVTME_TPL_BLOCKS], zeroed
     int             *error; // bit 0: a candidate named a reference beyond n_ref
 };
-void launch_tpl_search(const TplParams *dev, int n_b64, hipStream_t s); // dev: the record in device memory
+// dev: the record in device memory; transform_costs: it asks for costs in the transform domain (every intra mode, or
+// sad_intra / sad_inter not set): the kernel that takes them four at a time
+void launch_tpl_search(const TplParams *dev, int n_b64, bool transform_costs, hipStream_t s);
 
 int  occupancy_me_search();
 void occupancy_hme_items(int out[2]);

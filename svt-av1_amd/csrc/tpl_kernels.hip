@@ -4,7 +4,9 @@
 // vector, costed by the sum of absolute differences or by the sum of the absolute coefficients of the residual's 16x16
 // forward DCT, and the quantisation error of the candidate that wins (:935-982). One wave per block; a lane holds the
 // block's pixels 4 at a time (dword idx = lane + 64 k of the block's rows), so a 16x16 block is one dword per lane and a
-// 64x64 block 16. The transform runs on 16 lanes of the wave: a lane per column, then a lane per row, through LDS.
+// 64x64 block 16. A 16x16 transform takes 16 lanes - a lane per column, then a lane per row, through LDS - so the costs of
+// up to four predictions of a block (four intra modes, four candidates, or three candidates and the intra mode the rounds of
+// four left over) are taken together, one in each quarter of the wave.
 #include "search_common.h"
 
 namespace svtme {
@@ -27,7 +29,9 @@ __constant__ const uint8_t kTplMeIndex[SVTME_TPL_BLOCKS] = {0, 1, 2, 3, 4, 5, 6,
 // reference's 64-bit sums give. c[k / 2] = cos(k pi / 128) with BIT fractional bits, k even.
 template <int BIT>
 __device__ __forceinline__ int32_t rot(int32_t a, int32_t ca, int32_t b, int32_t cb) {
-    return (a * ca + b * cb + (1 << (BIT - 1))) >> BIT;
+    // (24-bit multiplications, a quarter of the cost of 32-bit ones: the terms stay below 2^18 with 8-bit residuals - at most
+    // 32 inputs of 11 bits added up, rotations grow a value by less than sqrt(2) - and the cosines below 2^14)
+    return (__mul24(a, ca) + __mul24(b, cb) + (1 << (BIT - 1))) >> BIT;
 }
 #define TPL_C(k) c[(k) >> 1]
 
@@ -158,7 +162,8 @@ __device__ __forceinline__ void fdct_n(const int32_t (&x)[32], int32_t (&X)[32],
 }
 #undef TPL_C
 
-constexpr int kTplLdsInts = 16 * 33; // a 32x8 or 16x16 residual with a pitch one dword over the width (no bank conflicts)
+// a 32x8 or 16x16 residual, or four 16x16 ones, with a pitch one dword over the width (no bank conflicts)
+constexpr int kTplLdsInts = 16 * 33, kTplLdsIntsX4 = 4 * 16 * 17;
 
 // The residual src - prd of a block of side W whose transform takes every (W / H)-th row (a lane holds N dwords of 4 pixels:
 // dword lane + 64 k of the block's rows) -> sum of the absolute coefficients of its W x H forward DCT (svt_aom_satd,
@@ -262,6 +267,87 @@ __device__ __forceinline__ void tpl_transform(ConstTplParams &p, const uint32_t 
             }
             *rate = (long long)(eob + 1 + logs) << 9;
         }
+    }
+}
+
+// tpl_transform<16, 16, 1> for up to four predictions of one 16x16 block at a time (quarter g of the wave takes prd[g] when
+// bit g of `mask` is set): the costs, errors and rates of all of them, in every lane.
+__device__ __forceinline__ void tpl_transform_x4(ConstTplParams &p, uint32_t src, const uint32_t (&prd)[4], uint32_t mask, int32_t *lds, bool quant,
+                                                 bool want_rate, long long (&satd)[4], long long (&recon_error)[4], long long (&rate)[4]) {
+    constexpr int PITCH = 17, AREA = 16 * PITCH;
+    const int     lane = threadIdx.x & 63, g = lane >> 4, c = lane & 15;
+    wave_sync(); // the previous use of the buffer is over
+    {
+        const int r = lane >> 2, d = lane & 3;
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+            if ((mask >> q) & 1) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) lds[q * AREA + r * PITCH + 4 * d + j] = (int32_t)((src >> (8 * j)) & 0xff) - (int32_t)((prd[q] >> (8 * j)) & 0xff);
+            }
+    }
+    wave_sync();
+    int32_t   *mine = lds + g * AREA;
+    const bool on = (mask >> g) & 1;
+    {
+        int32_t in[16], out[16];
+        if (on) {
+#pragma unroll
+            for (int i = 0; i < 16; ++i) in[i] = mine[i * PITCH + c] * 4;
+            fdct_n<13>(in, out, p.cos13);
+        }
+        wave_sync();
+        if (on) {
+#pragma unroll
+            for (int i = 0; i < 16; ++i) mine[i * PITCH + c] = (out[i] + 2) >> 2;
+        }
+    }
+    wave_sync();
+    long long a_sum = 0, e_sum = 0;
+    int       eob = 0, logs = 0;
+    const int kw = 16 >> p.pf_shape, kh = 16 >> p.pf_shape;
+    if (on && c < kh) {
+        int32_t in[16], out[16];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) in[i] = mine[c * PITCH + i];
+        fdct_n<12>(in, out, p.cos12);
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const int32_t v = i < kw ? out[i] : 0;
+            const int32_t a = v < 0 ? -v : v;
+            a_sum += a;
+            if (quant) {
+                const int ac = (c | i) != 0;
+                int32_t   dq = 0;
+                if ((a << 1) >= p.dequant[ac]) {
+                    const int32_t t     = min(a + p.round_fp[ac], 32767);
+                    const int32_t level = (int32_t)(((long long)t * p.quant_fp[ac]) >> 16);
+                    dq                  = level * p.dequant[ac];
+                    if (want_rate && level) {
+                        eob = max(eob, tpl_scan_pos16(c, i) + 1);
+                        logs += 31 - __clz(level + 1);
+                    }
+                }
+                const long long diff = (long long)a - dq; // |v - sign(v) dq|: same square
+                e_sum += diff * diff;
+            }
+        }
+    }
+#pragma unroll
+    for (int m = 8; m >= 1; m >>= 1) { // within the quarter
+        a_sum += __shfl_xor(a_sum, m);
+        e_sum += __shfl_xor(e_sum, m);
+        eob = max(eob, __shfl_xor(eob, m));
+        logs += __shfl_xor(logs, m);
+    }
+    e_sum >>= 2;
+    e_sum = e_sum < 1 ? 1 : e_sum;
+    const long long r = (long long)(eob + 1 + logs) << 9;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        satd[q]        = __shfl(a_sum, 16 * q);
+        recon_error[q] = __shfl(e_sum, 16 * q);
+        rate[q]        = __shfl(r, 16 * q);
     }
 }
 
@@ -375,7 +461,9 @@ __device__ __forceinline__ uint32_t tpl_intra_dword(int mode, const uint8_t *abo
     return out;
 }
 
-template <int S>
+// G: how many predictions of a 16x16 block are costed together in the transform domain (4: the intra modes and the candidates
+// four at a time; 1: one by one, for pictures whose costs are sums of absolute differences - less state, more waves per CU)
+template <int S, int G>
 __device__ __forceinline__ void tpl_block(ConstTplParams &p, int b64, int bi, int x, int y, int32_t *lds, uint8_t *edges) {
     constexpr int DW = S / 4, N = S * S / 256; // dwords per row, dwords per lane
     const int     lane = threadIdx.x & 63;
@@ -388,37 +476,54 @@ __device__ __forceinline__ void tpl_block(ConstTplParams &p, int b64, int bi, in
     }
     long long best_intra = INT64_MAX, best_inter = INT64_MAX, best_err = 0, best_rate = 0;
     int       best_rf = -1, best_mvx = 0, best_mvy = 0, best_mode = 0;
+    // an intra mode left over after the rounds of four (the thirteenth, or the ninth): its prediction, costed in the free
+    // quarter of the first round of candidates
+    uint32_t late_prd  = 0;
+    int      late_mode = -1;
 
-    if (S == 16 && !p.disable_intra_pred && p.mode_end > 0) {
+    if (S == 16 && G == 4 && !p.disable_intra_pred && p.mode_end > 0) {
         // every mode from DC_PRED to mode_end in the transform domain, the first of the cheapest stays (:735-820)
-        if constexpr (S == 16) {
+        if constexpr (S == 16 && G == 4) {
             uint8_t *a0 = edges, *l0 = edges + kEdge, *a1 = edges + 2 * kEdge, *l1 = edges + 3 * kEdge;
             wave_sync();
             tpl_collect_edges(p, cur, x, y, a0, l0);
             wave_sync();
-            for (int mode = 0; mode <= p.mode_end; ++mode) {
-                uint32_t prd[1];
-                if (mode == 0) { // dc_pred[x > 0][y > 0] (:2705-2707)
-                    uint32_t sum = 0;
-                    if (lane < 16) sum = (y > 0 ? a0[4 + lane] : 0u) + (x > 0 ? l0[4 + lane] : 0u);
-                    sum              = wave_sum(sum);
-                    const uint32_t n = (y > 0 ? 16 : 0) + (x > 0 ? 16 : 0);
-                    prd[0]           = (n ? (sum + (n >> 1)) / n : 128u) * 0x01010101u;
-                } else if (mode >= 3 && mode <= 8) { // the directional modes read filtered copies of the edges (:743-760)
-                    const int angle = mode == 3 ? 45 : (mode == 4 ? 135 : (mode == 5 ? 113 : (mode == 6 ? 157 : (mode == 7 ? 203 : 67))));
-                    wave_sync();
-                    tpl_filter_edges(angle, x, y, a0, l0, a1, l1);
-                    wave_sync();
-                    prd[0] = tpl_intra_dword(mode, a1 + 4, l1 + 4);
-                } else {
-                    prd[0] = tpl_intra_dword(mode, a0 + 4, l0 + 4);
+            for (int mode0 = 0; mode0 <= p.mode_end; mode0 += 4) { // four modes' costs at a time
+                uint32_t  prd[4] = {0, 0, 0, 0};
+                const int n = min(4, p.mode_end + 1 - mode0);
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int mode = mode0 + q;
+                    if (q >= n) break;
+                    if (mode == 0) { // dc_pred[x > 0][y > 0] (:2705-2707)
+                        uint32_t sum = 0;
+                        if (lane < 16) sum = (y > 0 ? a0[4 + lane] : 0u) + (x > 0 ? l0[4 + lane] : 0u);
+                        sum               = wave_sum(sum);
+                        const uint32_t nn = (y > 0 ? 16 : 0) + (x > 0 ? 16 : 0);
+                        prd[q]            = (nn ? (sum + (nn >> 1)) / nn : 128u) * 0x01010101u;
+                    } else if (mode >= 3 && mode <= 8) { // the directional modes read filtered copies of the edges (:743-760)
+                        const int angle = mode == 3 ? 45 : (mode == 4 ? 135 : (mode == 5 ? 113 : (mode == 6 ? 157 : (mode == 7 ? 203 : 67))));
+                        wave_sync();
+                        tpl_filter_edges(angle, x, y, a0, l0, a1, l1);
+                        wave_sync();
+                        prd[q] = tpl_intra_dword(mode, a1 + 4, l1 + 4);
+                    } else {
+                        prd[q] = tpl_intra_dword(mode, a0 + 4, l0 + 4);
+                    }
                 }
-                long long cost, err;
-                tpl_transform<16, 16, 1>(p, src, prd, lds, false, cost, err);
-                if (cost < best_intra) {
-                    best_intra = cost;
-                    best_mode  = mode;
+                if (n == 1 && mode0 > 0) {
+                    late_prd  = prd[0];
+                    late_mode = mode0;
+                    break;
                 }
+                long long cost[4], err[4], rate[4];
+                tpl_transform_x4(p, src[0], prd, (1u << n) - 1, lds, false, false, cost, err, rate);
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+                    if (q < n && cost[q] < best_intra) { // in the order of the modes: the first of the cheapest stays
+                        best_intra = cost[q];
+                        best_mode  = mode0 + q;
+                    }
             }
         }
     } else if (!p.disable_intra_pred) {
@@ -455,47 +560,86 @@ __device__ __forceinline__ void tpl_block(ConstTplParams &p, int b64, int bi, in
     }
     const uint8_t *cand   = p.cand + ((size_t)b64 * p.n_pu + me_off) * p.max_cand;
     const uint32_t *mvs   = p.mv + ((size_t)b64 * p.n_pu + me_off) * p.max_refs;
-    for (int ci = 0; ci < n_cand; ++ci) { // :836-930
-        const uint32_t c = cand[ci];
-        if ((c & 3) > 1) continue; // single references only
-        const int list = c & 3, ref = list == 0 ? (c >> 2) & 3 : (c >> 4) & 3;
-        if (ref >= p.n_ref[list]) { // a candidate that names a reference the caller did not hand over
-            if (lane == 0) atomicOr(p.error, 1);
-            continue;
-        }
-        if (p.ref_skip[list][ref]) continue;
-        const uint32_t mv  = mvs[(list ? p.max_l0 : 0) + ref];
-        int16_t        mvx = (int16_t)((int16_t)(mv & 0xffff) << 1), mvy = (int16_t)((int16_t)(mv >> 16) << 1);
-        if (x + (mvx >> 3) < -kTplPad) mvx = (int16_t)((-kTplPad - x) << 3);
-        if (x + S + (mvx >> 3) > kTplPad + p.width - 1) mvx = (int16_t)(((kTplPad + p.width - 1) - (x + S)) << 3);
-        if (y + (mvy >> 3) < -kTplPad) mvy = (int16_t)((-kTplPad - y) << 3);
-        if (y + S + (mvy >> 3) > kTplPad + p.height - 1) mvy = (int16_t)(((kTplPad + p.height - 1) - (y + S)) << 3);
-        const DevPlane rp  = load_plane(p.ref[list][ref]);
-        const uint8_t *org = rp.pix + (ptrdiff_t)(y + (mvy >> 3)) * rp.stride + x + (mvx >> 3);
-        uint32_t       acc = 0;
+    // :836-930, G candidates at a time: their vectors and SADs one after the other, their transform-domain costs together
+    for (int ci = 0; ci < n_cand;) {
+        int       n = 0, c_rf[G], c_mvx[G], c_mvy[G];
+        long long c_cost[G], c_err[G] = {}, c_rate[G] = {};
+        uint32_t  c_f[G] = {};
 #pragma unroll
-        for (int k = 0; k < N; ++k) {
-            const int idx = lane + 64 * k, r = idx / DW, d = idx % DW;
-            uint32_t  f;
-            __builtin_memcpy(&f, org + (ptrdiff_t)r * rp.stride + 4 * d, 4);
-            acc = __builtin_amdgcn_sad_u8(src[k], f, acc);
+        for (int q = 0; q < G; ++q) {
+            if (G == 4 && q == 3 && late_mode >= 0) break; // that quarter is taken
+            int list = 0, ref = 0;
+            bool found = false;
+            while (ci < n_cand && !found) { // the next candidate that takes part
+                const uint32_t c = cand[ci++];
+                if ((c & 3) > 1) continue; // single references only
+                list = c & 3;
+                ref  = list == 0 ? (c >> 2) & 3 : (c >> 4) & 3;
+                if (ref >= p.n_ref[list]) { // a candidate that names a reference the caller did not hand over
+                    if (lane == 0) atomicOr(p.error, 1);
+                    continue;
+                }
+                found = !p.ref_skip[list][ref];
+            }
+            if (!found) break;
+            n                  = q + 1;
+            const uint32_t mv  = mvs[(list ? p.max_l0 : 0) + ref];
+            int16_t        mvx = (int16_t)((int16_t)(mv & 0xffff) << 1), mvy = (int16_t)((int16_t)(mv >> 16) << 1);
+            if (x + (mvx >> 3) < -kTplPad) mvx = (int16_t)((-kTplPad - x) << 3);
+            if (x + S + (mvx >> 3) > kTplPad + p.width - 1) mvx = (int16_t)(((kTplPad + p.width - 1) - (x + S)) << 3);
+            if (y + (mvy >> 3) < -kTplPad) mvy = (int16_t)((-kTplPad - y) << 3);
+            if (y + S + (mvy >> 3) > kTplPad + p.height - 1) mvy = (int16_t)(((kTplPad + p.height - 1) - (y + S)) << 3);
+            const DevPlane rp  = load_plane(p.ref[list][ref]);
+            const uint8_t *org = rp.pix + (ptrdiff_t)(y + (mvy >> 3)) * rp.stride + x + (mvx >> 3);
+            uint32_t       acc = 0;
+#pragma unroll
+            for (int k = 0; k < N; ++k) {
+                const int idx = lane + 64 * k, r = idx / DW, d = idx % DW;
+                uint32_t  f;
+                __builtin_memcpy(&f, org + (ptrdiff_t)r * rp.stride + 4 * d, 4);
+                acc = __builtin_amdgcn_sad_u8(src[k], f, acc);
+                if (k == 0) c_f[q] = f; // (a 16x16 block is this one dword per lane)
+            }
+            c_cost[q] = wave_sum(acc);
+            c_rf[q]   = list == 0 ? ref : 4 + ref; // svt_get_ref_frame_type(list, ref) - 1
+            c_mvx[q]  = mvx;
+            c_mvy[q]  = mvy;
         }
-        long long sad = wave_sum(acc), err = 0;
         if constexpr (S == 16) {
-            if (!p.sad_inter) { // :894-917
-                uint32_t f[1];
-                __builtin_memcpy(&f[0], org + (ptrdiff_t)(lane >> 2) * rp.stride + 4 * (lane & 3), 4);
-                long long rate = 0;
-                tpl_transform<16, 16, 1>(p, src, f, lds, p.src_dist != 0, sad, err, p.rate != 0, &rate);
-                if (sad < best_inter) best_rate = rate;
+            if (!p.sad_inter && n) { // :894-917
+                if constexpr (G == 4) {
+                    const bool late = late_mode >= 0;
+                    if (late) c_f[3] = late_prd;
+                    tpl_transform_x4(p, src[0], c_f, ((1u << n) - 1) | (late ? 8u : 0u), lds, p.src_dist != 0, p.rate != 0, c_cost, c_err, c_rate);
+                    if (late && c_cost[3] < best_intra) { // the last of the modes: after all the others
+                        best_intra = c_cost[3];
+                        best_mode  = late_mode;
+                    }
+                    late_mode = -1;
+                } else
+                    tpl_transform<16, 16, 1>(p, src, c_f, lds, p.src_dist != 0, c_cost[0], c_err[0], p.rate != 0, &c_rate[0]);
             }
         }
-        if (sad < best_inter) { // strictly smaller: the first of equal candidates stays
-            best_inter = sad;
-            best_err   = err;
-            best_rf    = list == 0 ? ref : 4 + ref; // svt_get_ref_frame_type(list, ref) - 1
-            best_mvx   = mvx;
-            best_mvy   = mvy;
+#pragma unroll
+        for (int q = 0; q < G; ++q)
+            if (q < n && c_cost[q] < best_inter) { // strictly smaller, in the candidates' order: the first of equal ones stays
+                best_inter = c_cost[q];
+                best_err   = c_err[q];
+                best_rate  = c_rate[q];
+                best_rf    = c_rf[q];
+                best_mvx   = c_mvx[q];
+                best_mvy   = c_mvy[q];
+            }
+    }
+    if constexpr (S == 16 && G == 4) {
+        if (late_mode >= 0) { // no round of candidates took it along
+            const uint32_t prd[4] = {late_prd, 0, 0, 0};
+            long long      cost[4], err[4], rate[4];
+            tpl_transform_x4(p, src[0], prd, 1, lds, false, false, cost, err, rate);
+            if (cost[0] < best_intra) {
+                best_intra = cost[0];
+                best_mode  = late_mode;
+            }
         }
     }
     const bool is_inter = best_inter < best_intra; // :932-933
@@ -537,8 +681,9 @@ __device__ __forceinline__ void tpl_block(ConstTplParams &p, int b64, int bi, in
 
 // grid (16, n_b64), one wave each: slot s of a 64x64 block is its s-th 16x16 block (level 0), its s-th 32x32 block
 // (level 1, s < 4) or the block itself (level 2, s == 0); blocks that are not complete run at level 0 (:2086-2088)
-__global__ void __launch_bounds__(64) tpl_search_kernel(const TplParams *pp) {
-    __shared__ int32_t lds[kTplLdsInts];
+template <int G>
+__global__ void __launch_bounds__(64, 4) tpl_search_kernel(const TplParams *pp) {
+    __shared__ int32_t lds[G == 4 ? kTplLdsIntsX4 : kTplLdsInts];
     __shared__ __align__(4) uint8_t edges[4 * kEdge];
     ConstTplParams    &p = *(ConstTplParams *)pp;
     const int b64 = blockIdx.y, slot = blockIdx.x;
@@ -548,20 +693,21 @@ __global__ void __launch_bounds__(64) tpl_search_kernel(const TplParams *pp) {
         const int q = slot >> 2, s = slot & 3; // z-order: 32x32 quadrant, 16x16 inside it
         const int x = sb_x + (q & 1) * 32 + (s & 1) * 16, y = sb_y + (q >> 1) * 32 + (s >> 1) * 16;
         if (x + 8 > p.width || y + 8 > p.height) return; // at least half of the block inside (:604-607)
-        tpl_block<16>(p, b64, 5 + slot, x, y, lds, edges);
+        tpl_block<16, G>(p, b64, 5 + slot, x, y, lds, edges);
     } else if (level == 1) {
         if (slot >= 4) return;
-        tpl_block<32>(p, b64, 1 + slot, sb_x + (slot & 1) * 32, sb_y + (slot >> 1) * 32, lds, edges);
+        tpl_block<32, G>(p, b64, 1 + slot, sb_x + (slot & 1) * 32, sb_y + (slot >> 1) * 32, lds, edges);
     } else {
         if (slot >= 1) return;
-        tpl_block<64>(p, b64, 0, sb_x, sb_y, lds, edges);
+        tpl_block<64, G>(p, b64, 0, sb_x, sb_y, lds, edges);
     }
 }
 
 } // namespace
 
-void launch_tpl_search(const TplParams *dev, int n_b64, hipStream_t s) {
-    hipLaunchKernelGGL(tpl_search_kernel, dim3(16, n_b64), dim3(64), 0, s, dev);
+void launch_tpl_search(const TplParams *dev, int n_b64, bool transform_costs, hipStream_t s) {
+    if (transform_costs) hipLaunchKernelGGL(tpl_search_kernel<4>, dim3(16, n_b64), dim3(64), 0, s, dev);
+    else hipLaunchKernelGGL(tpl_search_kernel<1>, dim3(16, n_b64), dim3(64), 0, s, dev);
 }
 
 } // namespace svtme
