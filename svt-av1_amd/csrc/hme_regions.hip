@@ -1,4 +1,157 @@
 // hme_regions.hip - the level-1/2 HME kernel that does the four regions of a reference in one work item
-// (hme_l12_regions_kernel): hme_items.hip's search functions and that kernel, compiled as a unit of their own.
-#define SVTME_HME_REGIONS_TU
-#include "hme_items.hip"
+// (hme_l12_regions_kernel), on hme_search.h's search functions.
+#include "hme_search.h"
+
+namespace svtme {
+
+// Levels 1 and 2 of all four regions of reference (l, r) in one wave, for the shapes quick_search covers: what l12_region
+// does per region, for windows of 8 x (1..3) positions (the pre-analysis ME's), with the four level-1 windows fetched in one
+// memory round trip and the four level-2 windows in two, and the reference's record, the source blocks and the work item's
+// set-up paid once instead of four times. A block or a window outside that shape (a picture's right / bottom edge) goes
+// through small_search region by region. (The first pass's 8 x 8 windows keep a work item per region: with two trips per
+// search the saving is smaller than what the larger item costs in resident waves.)
+template <class P>
+__device__ __forceinline__ void l12_regions(const P &p, const uint32_t *src1, const uint32_t *src2, uint32_t *win, int b64x, int b64y,
+                                            int block_w, int block_h, int l, int r, HmeRefOut *rec) {
+    const auto &k    = p.ctrl;
+    const int   lane = threadIdx.x & 63;
+    const bool  early = k.me_early_exit_th && rec->zz_sad < (k.me_early_exit_th >> 2);
+    // region q = sh * 2 + sw lives at index i = sw * 2 + sh of the record's arrays
+    int16_t  cx[4] = {0, 0, 0, 0}, cy[4] = {0, 0, 0, 0};
+    uint32_t csad[4] = {0, 0, 0, 0};
+    if (k.enable_hme_level0_flag && !early) {
+        // the worst region (strict '>', sr_h outer / sr_w inner) gives way to the better pre-HME result (:1967-1999)
+        uint32_t max_sad = 0;
+        int      mi      = 0;
+        for (int h_ = 0; h_ < 2; ++h_)
+            for (int w_ = 0; w_ < 2; ++w_)
+                if (rec->raw_sad[w_ * 2 + h_] > max_sad) {
+                    max_sad = rec->raw_sad[w_ * 2 + h_];
+                    mi      = w_ * 2 + h_;
+                }
+        const int s = rec->pre_sad[0] <= rec->pre_sad[1] ? 0 : 1;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int i = (q & 1) * 2 + (q >> 1);
+            cx[q]   = rec->raw_x[i];
+            cy[q]   = rec->raw_y[i];
+            csad[q] = rec->raw_sad[i];
+            if (k.prehme_enable && mi == i && rec->pre_sad[s] < csad[q]) {
+                csad[q] = rec->pre_sad[s];
+                cx[q]   = rec->pre_x[s];
+                cy[q]   = rec->pre_y[s];
+            }
+            if (lane == 0) {
+                rec->lx[0][i]   = cx[q];
+                rec->ly[0][i]   = cy[q];
+                rec->lsad[0][i] = csad[q];
+            }
+        }
+    }
+    for (int level = 1; level <= 2; ++level) {
+        // a level that does not run, or level 1 on the early exit (:2032-2040; level 2 has none), leaves zeros
+        if ((level == 1 ? !k.enable_hme_level1_flag : !k.enable_hme_level2_flag) || (level == 1 && early)) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) cx[q] = cy[q] = 0;
+            continue;
+        }
+        const DevPlane ref   = load_plane(p.ref[l][r].lvl[level]);
+        const int      shift = 2 - level;
+        const int      ox = b64x >> shift, oy = b64y >> shift;
+        const int      bw = block_w >> shift, bh = block_h >> shift;
+        const int      rows = bh >> 1;
+        const int      pad  = level == 2 ? 63 : ref.pad - 1;
+        const int      sa_width = level == 1 ? k.hme_l1_sa.width : k.hme_l2_sa.width, sa_height = level == 1 ? k.hme_l1_sa.height : k.hme_l2_sa.height;
+        int            wx[4], wy[4], hh[4];
+        int16_t        ww[4], orgx[4], orgy[4];
+        bool           quick = block_w == 64;
+        unsigned long long ops = 0;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            int16_t w = (int16_t)(((int16_t)sa_width + 7) & ~0x07), h = (int16_t)sa_height;
+            if (level == 1) {
+                cx[q] = (int16_t)(cx[q] >> 1);
+                cy[q] = (int16_t)(cy[q] >> 1);
+            }
+            int16_t org_x = (int16_t)(-(w >> 1) + cx[q]), org_y = (int16_t)(-(h >> 1) + cy[q]);
+            clip_axis(ox, org_x, w, -pad, ref.width);
+            w = (int16_t)(w < 8 ? w : (w & ~0x07));
+            clip_axis(oy, org_y, h, -pad, ref.height);
+            ops += (unsigned long long)max((int)h, 0) * max((int)w, 0) * rows * bw;
+            ww[q] = w, orgx[q] = org_x, orgy[q] = org_y, hh[q] = h;
+            wx[q] = ox + org_x, wy[q] = oy + org_y;
+            quick = quick && w == 8 && h >= 1 && h <= 3;
+        }
+        if (lane == 0) count_ops(p, 2 + level, ops);
+        const uint32_t *src = level == 1 ? src1 : src2;
+        u64             key[4];
+        if (quick && level == 1) {
+            wave_sync();
+            quick_stage<8, 3, 4>(win, ref, rows, wx, wy, hh);
+            wave_sync();
+#pragma unroll
+            for (int q = 0; q < 4; ++q) key[q] = quick_scan<8, 3>(src, win + q * QuickGeo<8, 3>::WIN, rows, hh[q]);
+            wave_sync();
+        } else if (quick) { // the 64-pixel block's windows: two at a time
+#pragma unroll
+            for (int half = 0; half < 2; ++half) {
+                const int wxp[2] = {wx[2 * half], wx[2 * half + 1]}, wyp[2] = {wy[2 * half], wy[2 * half + 1]};
+                const int hp[2]  = {hh[2 * half], hh[2 * half + 1]};
+                wave_sync();
+                quick_stage<16, 3, 2>(win, ref, rows, wxp, wyp, hp);
+                wave_sync();
+                key[2 * half]     = quick_scan<16, 3>(src, win, rows, hp[0]);
+                key[2 * half + 1] = quick_scan<16, 3>(src, win + QuickGeo<16, 3>::WIN, rows, hp[1]);
+            }
+            wave_sync();
+        } else {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) key[q] = small_search<false>(src, win, ref, bw, rows, wx[q], wy[q], ww[q], hh[q]);
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int i = (q & 1) * 2 + (q >> 1);
+            uint32_t  sad;
+            decode_key(key[q], orgx[q], orgy[q], level == 1 ? 2 : 1, cx[q], cy[q], sad, true);
+            if (lane == 0) {
+                rec->lx[level][i]   = cx[q];
+                rec->ly[level][i]   = cy[q];
+                rec->lsad[level][i] = sad;
+            }
+        }
+    }
+}
+
+constexpr int HI_WIN2_DWORDS_ALL = 2 * QuickGeo<16, 3>::WIN > 4 * QuickGeo<8, 3>::WIN ? 2 * QuickGeo<16, 3>::WIN : 4 * QuickGeo<8, 3>::WIN;
+static_assert(HI_WIN2_DWORDS_ALL * 4 >= HI_WIN2_BYTES, "small_search's window fits too");
+
+// One wave per (b64, reference): the 2 x 2 regions' levels 1 and 2 (sub-sampled searches only).
+template <class PICS>
+__global__ void __launch_bounds__(HI_THREADS) hme_l12_regions_kernel(PICS pp) {
+    __shared__ L12Shared<false>       S;
+    __shared__ __align__(16) uint32_t win[HI_WIN2_DWORDS_ALL + 64];
+    const auto &p = pp[blockIdx.y];
+    const auto &k = p.ctrl;
+    const int   n_refs = p.n_ref[0] + (p.n_list == 2 ? p.n_ref[1] : 0);
+    int         b64, item;
+    if (!b64_band_item(blockIdx.x, p.b64_w * p.b64_h, n_refs, b64, item) || b64_left_out(p, b64)) return;
+    int       b64x, b64y;
+    b64_origin(p, b64, b64x, b64y);
+    const int block_w = min(p.width - b64x, 64), block_h = min(p.height - b64y, 64);
+    int       l = 0, r = item;
+    if (r >= p.n_ref[0]) {
+        r -= p.n_ref[0];
+        l = 1;
+    }
+    if (!ref_searched(p, l) || !k.enable_hme_flag) return;
+    stage_l12_blocks<false>(p, S, b64x, b64y, block_w, block_h);
+    wave_sync();
+    l12_regions(p, S.src1, S.src2, win, b64x, b64y, block_w, block_h, l, r, &p.hme_out[(b64 * SVTME_MAX_LISTS + l) * SVTME_MAX_REFS + r]);
+}
+
+void launch_hme_l12_regions(const Batch &b, hipStream_t s) {
+    const dim3 grid((b.n_b64() + 7) / 8 * 8 * b.max_refs(), b.n);
+    if (b.n == 1) hipLaunchKernelGGL((hme_l12_regions_kernel<OnePicture>), grid, dim3(HI_THREADS), 0, s, OnePicture{b.host[0]});
+    else hipLaunchKernelGGL((hme_l12_regions_kernel<ManyPictures>), grid, dim3(HI_THREADS), 0, s, ManyPictures{b.dev});
+}
+} // namespace svtme
