@@ -265,11 +265,13 @@ def main():
         """k steps back to back: at most --in-flight pictures outstanding, also across step boundaries (mini-GOPs follow
         each other without a pause, as they do in the encoder); everything has been waited for on return. owners: the
         rank of every picture of the k steps (this rank runs its own ones only). sample = (stats, stride): the kernel
-        durations of every stride-th submission are added to stats (one svtme_picture_timing call for the submission: its
-        pictures share their launches and report equal shares). keep: a list that receives every picture's results."""
+        durations of every submission of every stride-th step are added to stats (whole steps, because the submissions of
+        a step differ - the pictures of a mini-GOP have different reference counts and distances - while the operation
+        counts the durations are set against are averages over whole steps; one svtme_picture_timing call for a
+        submission: its pictures share their launches and report equal shares). keep: a list that receives every picture's results."""
         e, ds = e or eng, ds or descs
         tickets, group, new_sources = [], [], []
-        sampled, n_flush = set(), [0]
+        sampled, cur_step = set(), [0]
 
         def finish(e, t, collect):
             if keep is not None:
@@ -293,14 +295,14 @@ def main():
                 put_sources(e, new_sources, flush.ks)
                 new_sources.clear()
             new = e.submit_batch(group) if len(group) > 1 else [e.submit(group[0])]
-            if sample is not None and n_flush[0] % sample[1] == 0:
+            if sample is not None and cur_step[0] % sample[1] == 0:
                 sampled.add(new[0])
-            n_flush[0] += 1
             tickets.extend(new)
             group.clear()
 
         for step in range(k):
             ks = step % KEY_SETS
+            cur_step[0] = step
             seen = set()  # sources this rank has put for this step
             for i, d in enumerate(descs_alt[ks] if upload else ds):
                 if owners is not None and owners[step * len(ds) + i] != rank:
@@ -393,14 +395,14 @@ def main():
     g0 = grp.stats() if grp is not None else None
     t0 = time.perf_counter()
     # nothing but (put,) submit / wait / done per picture inside the timed region - and, with one search stream, one
-    # svtme_picture_timing call for every few submissions (at most ~64 over the region): the kernels' HIP events
+    # svtme_picture_timing call per submission of every few steps (~64 calls over the region): the kernels' HIP events
     timed = new_stats()
-    n_submits = max(1, args.steps * ((per_rank[rank] // args.steps + args.batch - 1) // args.batch))
+    submits_per_step = max(1, (per_rank[rank] // args.steps + args.batch - 1) // args.batch)
     if grp is not None:
         run_group_steps(args.steps, count=True)
     elif not args.group:
         run_steps(args.steps, None, upload=args.with_upload, owners=owners_timed,
-                  sample=(timed, max(1, n_submits // 64)) if streams == 1 else None)
+                  sample=(timed, max(1, args.steps * submits_per_step // 64)) if streams == 1 else None)
     if grp is not None and not rehearsal:
         for d in range(args.gpus):
             torch.cuda.synchronize(d)

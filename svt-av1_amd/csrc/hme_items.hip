@@ -39,7 +39,7 @@ __global__ void __launch_bounds__(HI_THREADS) hme_zz_kernel(PICS pp) {
 // the record of list 0 / reference r: both are only read when the picture's controls make references depend on each
 // other (p.dep_l0, p.dep_pre), and are complete by then. zz: the zero-MV SAD of the reference (~0 when not computed).
 template <bool FS, class PICS>
-__global__ void __launch_bounds__(HI_THREADS, 3) hme_l0_kernel(PICS pp, int grid_refs, uint32_t grid_refs_magic, int hme_phase, int all_regions) {
+__global__ void __launch_bounds__(HI_THREADS, 6) hme_l0_kernel(PICS pp, int grid_refs, uint32_t grid_refs_magic, int hme_phase, int all_regions) {
     __shared__ __align__(16) uint32_t win[HI_WIN_BYTES / 4 + 64];
     // grid: x = 64x64 block, y = search of the reference, z = (picture, reference): the work items of one picture are
     // dispatched together; the picture's index by a multiplication (grid_refs_magic = ceil(2^32 / grid_refs))

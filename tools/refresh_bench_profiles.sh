@@ -1,9 +1,11 @@
 #!/bin/bash
 # Re-runs bench.py for every workload and writes the JSON lines under profiles/ (run on the GPU box from the repository root).
 set -e
-R=${1:-r02}
+R=${1:-r03}
+ONLY=${2:-} # optional: a regular expression, only the runs whose name matches it
 run() { # name, args...
     local name=$1; shift
+    if [ -n "$ONLY" ] && ! [[ "$name" =~ $ONLY ]]; then return 0; fi
     timeout -k 10 600 python3 bench.py "$@" > "profiles/${R}_bench_${name}.json.tmp" 2> "gpurun_out/refresh_${name}.err"
     tail -1 "profiles/${R}_bench_${name}.json.tmp" > "profiles/${R}_bench_${name}.json"
     rm "profiles/${R}_bench_${name}.json.tmp"
@@ -27,4 +29,7 @@ run 1080p_ra_m3_with_upload --with-upload --no-cpu-baseline
 run 1080p_ra_m8_with_upload --workload 1080p_ra_m8 --with-upload --no-cpu-baseline
 run 4k_ra_m8_with_upload --workload 4k_ra_m8 --with-upload --no-cpu-baseline
 run 720p_ld_m12_with_upload --workload 720p_ld_m12 --with-upload --no-cpu-baseline
+# one process, two engines on this GPU behind svtme_group (a rehearsal of the N-GPU group mode: batched submits, uploads
+# and peer copies inside the timed region)
+SVTME_BENCH_REHEARSAL=1 run 1080p_ra_m8_group2_one_gpu --workload 1080p_ra_m8 --group --gpus 2 --no-cpu-baseline
 mkdir -p gpurun_out/profiles && cp profiles/${R}_bench_*.json gpurun_out/profiles/
