@@ -3,7 +3,8 @@
  * (tools/run_sanitized.sh: AddressSanitizer + UndefinedBehaviorSanitizer on the host code only) sees them: engines of
  * several sizes, pictures in flight on a small store, slot overwrite and release with readers in flight, every
  * me_type, the device tail in both forms, batches of pictures that share their launches, zero-copy puts from
- * page-locked buffers, the allocation-free search, a group of two engines, argument errors, and destroy with work
+ * page-locked buffers, batched puts and copies between engines, the allocation-free search, a group of two engines (single and
+ * batched submits, with and without copies between its engines), the global-motion refinement, argument errors, and destroy with work
  * outstanding.
  * Prints "ok <checksum>"; the sanitizers abort on their own findings.
  */
@@ -385,6 +386,25 @@ static uint64_t run_extras(uint32_t w, uint32_t h, uint32_t seed, uint64_t hsh) 
             hsh = fnv(hsh, &e_frame, sizeof(e_frame));
             hsh = fnv(hsh, &e_stop, sizeof(e_stop));
         }
+        /* the refinement loop as one call: with the stand-in tables any model comes back valid, and a second run from the
+           refined model cannot find a smaller error than the first one returned */
+        {
+            svtme_gm_model m = {{3 << 13, -(2 << 13), (1 << 16) + 40, 12, -12, (1 << 16) + 40}, 0, 0, 0, 0, 2};
+            int64_t        e1 = 0, e2 = 0;
+            uint32_t       n1 = 0, n2 = 0;
+            CHECK(svtme_gm_refine(eng, 102, 100, 1, &m, 2, 3, INT64_MAX, &e1, &n1));
+            if (n1 < 1 + 2 * 4 * 3 || m.wmtype < 0 || m.wmtype > 3 || e1 <= 0) EXPECT(-113, SVTME_OK);
+            CHECK(svtme_gm_refine(eng, 102, 100, 1, &m, m.wmtype, 3, e1, &e2, &n2));
+            if (e2 > e1) EXPECT(-114, SVTME_OK);
+            CHECK(svtme_gm_refine(eng, 102, 100, 0, &m, 0, 1, INT64_MAX, &e2, NULL)); /* identity forced: one evaluation */
+            if (m.wmtype != 0 || m.wmmat[0] || m.wmmat[2] != 1 << 16) EXPECT(-115, SVTME_OK);
+            hsh = fnv(hsh, &e1, sizeof(e1));
+            hsh = fnv(hsh, &n1, sizeof(n1));
+            EXPECT(svtme_gm_refine(eng, 102, 100, 1, &m, 4, 3, INT64_MAX, &e1, NULL), SVTME_ERR_BAD_ARG);
+            EXPECT(svtme_gm_refine(eng, 102, 100, 1, &m, 2, 0, INT64_MAX, &e1, NULL), SVTME_ERR_BAD_ARG);
+            EXPECT(svtme_gm_refine(eng, 102, 999, 1, &m, 2, 3, INT64_MAX, &e1, NULL), SVTME_ERR_NOT_FOUND);
+            EXPECT(svtme_gm_refine(eng, 102, 100, 1, NULL, 2, 3, INT64_MAX, &e1, NULL), SVTME_ERR_BAD_ARG);
+        }
         EXPECT(svtme_gm_corners(eng, 999, 0, pts, 8, &n_pts), SVTME_ERR_NOT_FOUND);
         EXPECT(svtme_gm_corners(eng, 102, 3, pts, 8, &n_pts), SVTME_ERR_BAD_ARG);
         EXPECT(svtme_gm_warp_error(eng, 102, 100, 0, NULL, 0, &e_warp), SVTME_ERR_BAD_ARG);
@@ -470,6 +490,46 @@ static uint64_t run_extras(uint32_t w, uint32_t h, uint32_t seed, uint64_t hsh) 
         EXPECT(svtme_tpl_search(eng, &tp, NULL), SVTME_ERR_BAD_ARG);
         free(cnt); free(cand); free(mv); free(blk);
     }
+    /* the same sources once more as ONE batched put under other keys, and from there device to device into a second engine:
+       the three pictures searched on either give the bytes they gave above */
+    {
+        uint64_t       keys[N], pocs[N];
+        const uint8_t *lumas[N];
+        for (int k = 0; k < N; ++k) keys[k] = 200 + (uint64_t)k, pocs[k] = (uint64_t)k, lumas[k] = pool + (size_t)k * stride * h;
+        svtme_config cfg2 = cfg;
+        cfg2.store_slots  = 2 * N + 1;
+        svtme_engine *big = NULL, *peer = NULL;
+        CHECK(svtme_create(&cfg2, &big));
+        CHECK(svtme_create(&cfg, &peer));
+        CHECK(svtme_store_put_many(big, N, keys, pocs, lumas, stride, w, h, 1));
+        EXPECT(svtme_store_put_many(big, 0, keys, pocs, lumas, stride, w, h, 1), SVTME_ERR_BAD_ARG);
+        EXPECT(svtme_store_put_many(big, SVTME_MAX_PUT_BATCH + 1, keys, pocs, lumas, stride, w, h, 1), SVTME_ERR_BAD_ARG);
+        EXPECT(svtme_store_put_many(big, N, keys, pocs, NULL, stride, w, h, 1), SVTME_ERR_BAD_ARG);
+        for (int k = 0; k < N; ++k) CHECK(svtme_store_copy_peer(peer, big, keys[k]));
+        EXPECT(svtme_store_copy_peer(peer, big, 999), SVTME_ERR_NOT_FOUND);
+        EXPECT(svtme_store_copy_peer(peer, NULL, keys[0]), SVTME_ERR_BAD_ARG);
+        svtme_engine *both[2] = {big, peer};
+        for (int e = 0; e < 2; ++e) {
+            uint64_t again = 0;
+            for (int i = 0; i < 3; ++i) {
+                svtme_picture q = pic[i];
+                q.cur_key += 100;
+                for (int l = 0; l < SVTME_MAX_LISTS; ++l)
+                    for (int r = 0; r < SVTME_MAX_REFS; ++r)
+                        if (q.ref_key[l][r]) q.ref_key[l][r] += 100;
+                CHECK(svtme_picture_submit(both[e], &q, &t[0]));
+                CHECK(svtme_picture_wait(both[e], t[0], &res));
+                again = hash_results(&res, &pic[i], again);
+                CHECK(svtme_picture_done(both[e], t[0]));
+            }
+            if (again != one) {
+                fprintf(stderr, "a batched put (engine %d) and single puts differ\n", e);
+                exit(1);
+            }
+        }
+        svtme_destroy(peer);
+        svtme_destroy(big);
+    }
     svtme_destroy(eng);
     /* two engines on this device behind one handle: pictures round robin, sources where they are read */
     {
@@ -496,6 +556,29 @@ static uint64_t run_extras(uint32_t w, uint32_t h, uint32_t seed, uint64_t hsh) 
         uint64_t np = 0, ns = 0, nu = 0;
         CHECK(svtme_group_stats(grp, &np, &ns, &nu));
         if (np != 3 || ns != N || nu < 4 || nu > 2 * N) EXPECT(-102, SVTME_OK);
+        /* the three pictures as one submit (the group splits them over its engines), with copies between the engines
+           and, after the sources have been announced afresh, without */
+        for (int round = 0; round < 2; ++round) {
+            uint64_t copies = 0, links = 0;
+            CHECK(svtme_group_set_peer_copies(grp, round == 0));
+            if (round)
+                for (int k = 0; k < N; ++k)
+                    CHECK(svtme_group_store_put(grp, 100 + (uint64_t)k, (uint64_t)k, pool + (size_t)k * stride * h, stride, w, h, k != 1));
+            CHECK(svtme_group_pictures_submit(grp, pic, 3, gt));
+            g = 0;
+            for (int i = 0; i < 3; ++i) {
+                if (svtme_group_ticket_engine(gt[i]) > 1) EXPECT(-103, SVTME_OK);
+                CHECK(svtme_group_picture_wait(grp, gt[i], &res));
+                g = hash_results(&res, &pic[i], g);
+                CHECK(svtme_group_picture_done(grp, gt[i]));
+            }
+            if (g != one) {
+                fprintf(stderr, "the group's batched submit (round %d) and a single engine differ\n", round);
+                exit(1);
+            }
+            CHECK(svtme_group_peer_stats(grp, &copies, &links));
+        }
+        EXPECT(svtme_group_pictures_submit(grp, pic, 0, gt), SVTME_ERR_BAD_ARG);
         EXPECT(svtme_group_picture_wait(grp, (svtme_ticket)7 << 56, &res), SVTME_ERR_NOT_FOUND);
         CHECK(svtme_group_store_release(grp, 100));
         EXPECT(svtme_group_store_release(grp, 100), SVTME_ERR_NOT_FOUND);
