@@ -526,8 +526,9 @@ typedef struct svtme_gm_model { /* EbWarpedMotionParams (EbDefinitions.h:1969-19
     int32_t wmtype; /* TransformationType: IDENTITY 0, TRANSLATION 1, ROTZOOM 2, AFFINE 3 */
 } svtme_gm_model;
 /* wmtype: the type to force (the reference passes the model's own, EbGlobalMotionEstimation.c:231-246); n_refinements:
- * gm_ctrls.params_refinement_steps, at least 1; best_frame_error: the best error of the models tried before (INT64_MAX for
- * the first) */
+ * gm_ctrls.params_refinement_steps, 1 .. 13 (the first step is 1 << (n_refinements - 1) units of a parameter whose range is
+ * 1 << 12; the encoder uses 1 and 5; SVTME_ERR_BAD_ARG outside that, as for a wmtype outside 0 .. 3); best_frame_error:
+ * the best error of the models tried before (INT64_MAX for the first) */
 int svtme_gm_refine(svtme_engine *e, uint64_t cur_key, uint64_t ref_key, int downsample_level, svtme_gm_model *wm, int wmtype,
                     int n_refinements, int64_t best_frame_error, int64_t *error, uint32_t *evaluations);
 
