@@ -31,5 +31,14 @@ for mode in ("copy", "pinned"):
         t2 = time.perf_counter()
         print(mode, "rep", rep, "put calls us", ["%.0f" % t for t in ts[:6]], "all calls %.0f us, drained after %.0f us -> %.0f puts/s, %.1f GB/s" %
               ((t1 - t0) * 1e6, (t2 - t0) * 1e6, n / (t2 - t0), n * w * h / (t2 - t0) / 1e9), flush=True)
+# a mini-GOP's sources in one call (svtme_store_put_many)
+for rep in range(3):
+    t0 = time.perf_counter()
+    eng.store_put_many(list(range(n)), list(range(n)), [pool[i, 72:72 + h, 72:72 + w] for i in range(n)], pinned=True)
+    t1 = time.perf_counter()
+    eng.store_wait(n - 1)
+    t2 = time.perf_counter()
+    print("put_many pinned rep", rep, "call %.0f us, drained after %.0f us -> %.0f puts/s, %.1f GB/s" %
+          ((t1 - t0) * 1e6, (t2 - t0) * 1e6, n / (t2 - t0), n * w * h / (t2 - t0) / 1e9), flush=True)
 eng.host_free(pool)
 eng.close()
