@@ -40,18 +40,18 @@ import numpy as np  # noqa: E402
 # BASELINE.json configs -> shapes. "1080p_ra_m3" is configs[2]: 1080p random access, mini-GOP 16, HME L0/L1/L2 + full-pel
 # search, up to 4+3 references (preset 3 = MRP level 3), the single-GPU 1080p configuration the metric is quoted on.
 WORKLOADS = {
-    "1080p_ra_m3": dict(width=1920, height=1080, enc_mode=3, structure="ra", n_frames=17, bit_depth=8, batch=8),
+    "1080p_ra_m3": dict(width=1920, height=1080, enc_mode=3, structure="ra", n_frames=17, bit_depth=8, batch=16),
     # "batch": pictures per svtme_pictures_submit call (the pictures of a mini-GOP are posted back to back,
     # EbPictureDecisionProcess.c:6842-6874). The fast presets are bound by per-launch costs, which a mini-GOP submitted at
     # once pays once; the slow ones gain the shorter kernel tails (measured: profiles/r02_batch_sweep.txt)
     "1080p_ra_m8": dict(width=1920, height=1080, enc_mode=8, structure="ra", n_frames=17, bit_depth=8, batch=16),
     "720p_ld_m12": dict(width=1280, height=720, enc_mode=12, structure="ldp", n_frames=17, bit_depth=8, batch=16),
-    "4k_ra_m8": dict(width=3840, height=2160, enc_mode=8, structure="ra", n_frames=17, bit_depth=10, batch=8),
+    "4k_ra_m8": dict(width=3840, height=2160, enc_mode=8, structure="ra", n_frames=17, bit_depth=10, batch=16),
     "8k_ra_m2": dict(width=7680, height=4320, enc_mode=2, structure="ra", n_frames=17, bit_depth=8, batch=2),
     # temporal-filter searches (ME_MCTF): a 7-frame window, the centre frame searched in each of its 6 neighbours; one
     # "picture" = one (centre, neighbour) pair. tf = (tf_ctrls.hme_me_level, tf_ctrls.me_exit_th): level 0 is what presets
     # up to M5 use, level 2 with the 16x16 exit threshold what the fast presets use (EbEncHandle.c:2556-2876).
-    "1080p_tf_l0": dict(width=1920, height=1080, enc_mode=0, structure="tf", n_frames=7, bit_depth=8, tf=(0, 0), batch=4),
+    "1080p_tf_l0": dict(width=1920, height=1080, enc_mode=0, structure="tf", n_frames=7, bit_depth=8, tf=(0, 0), batch=6),
     "1080p_tf_l2": dict(width=1920, height=1080, enc_mode=8, structure="tf", n_frames=7, bit_depth=8, tf=(2, 256), batch=6),
     # first-pass ME of a two-pass encode (ME_FIRST_PASS): every frame searches the previous and the first frame;
     # fp = (ipp_pass_ctrls.bypass_zz_check, ipp_pass_ctrls.reduce_me_search)
@@ -198,7 +198,7 @@ def main():
     if args.batch <= 0:
         args.batch = wl.get("batch", 1)
         if args.with_upload:  # a batch waits for the puts of all its pictures: shorter batches overlap better with the uploads
-            args.batch = min(args.batch, 4)
+            args.batch = min(args.batch, 8)
     args.batch = min(args.batch, svtme.MAX_BATCH)
     if args.in_flight <= 0:
         args.in_flight = max(6, 3 * args.batch)

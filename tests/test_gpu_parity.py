@@ -273,7 +273,7 @@ def test_scheduler_runs_a_sequence_on_the_engine_with_store_reuse():
 
 # the batch sizes the benchmark submits these shapes with (bench.py WORKLOADS): their launch shapes - pictures as a grid
 # dimension, parameter records read from device memory, 16-row work items at the fast presets - differ from a single picture's
-BENCH_BATCH = {"m3_ra_1920x1080": 8, "m8_ra_3840x2160": 8, "m2_ra_7680x4320": 2, "m12_ldp_1280x720": 16, "m8_ra_1920x1080": 16,
+BENCH_BATCH = {"m3_ra_1920x1080": 16, "m8_ra_3840x2160": 16, "m2_ra_7680x4320": 2, "m12_ldp_1280x720": 16, "m8_ra_1920x1080": 16,
                "m3_ra_640x360": 8}
 
 
