@@ -24,6 +24,9 @@
 //                   Running minima carry the row number in the low key bits, so the reference's tie rule (first
 //                   strictly smaller SAD in raster order) is reproduced exactly: keys order by (SAD, y, x).
 //  me_finish_kernel keys -> p_sb_best_sad / p_sb_best_mv.
+// Where the controls allow no window more than one work item (the fast presets' 16 x 9 positions and smaller, the temporal
+// filter's last level, the first pass), the three are one kernel: the item plans its own window, searches it and writes the
+// final SADs / vectors itself - no job records, no keys, no atomics, two launches less.
 #include "search_common.h"
 
 namespace svtme {
@@ -37,14 +40,11 @@ constexpr int ME_WIN_ROWS  = 8 * ME_ITEM_GROUPS + 62; // the item's search rows 
 constexpr int ME_WIN_BYTES = ME_WIN_ROWS * ME_PD * 4;
 
 struct MeShared {
-    __align__(16) uint32_t src[32 * 16]; // rows 0,2,..,62 of the source block, 16 dwords each
     u64                    hsad[8]; // per (list, ref): search centre, HME SAD, do_ref, search-range divisor
     uint32_t               div[8];
     int16_t                sc_x[8], sc_y[8];
     uint8_t                do_ref[8];
     uint8_t                cand[8]; // this entry has an HME result of its own
-    uint32_t               red;
-    int                    zero; // always 0, but only known at run time
 };
 
 // z-order index of the 16x16 block in raster (row, col): svt_ext_all_sad_calculation_8x8_16x16_c's `offsets` (:366)
@@ -85,21 +85,16 @@ __device__ __forceinline__ uint32_t units_inverse(int d) {
     return (d & (d - 1)) == 0 ? 65536u >> (31 - __clz(d)) : (d == 10 ? 6554u : (d == 12 ? 5462u : 4682u));
 }
 
-template <class PICS>
-__global__ void __launch_bounds__(ME_THREADS) me_plan_kernel(PICS pp, int me_ref0) {
-    __shared__ MeShared S;
-    const auto &p   = pp[blockIdx.z]; // grid: x = 64x64 block, y = reference, z = picture
+// The plan of reference my_idx (list-0 references first, then list 1; the caller has checked that the picture has it) of
+// block b64, whole wave: the window to search, w == 0 when the reference is not searched. KEYS: the job goes to p.me_jobs and
+// the reference's 85 keys are reset (the search runs as a kernel of its own); else the caller searches the window itself.
+template <bool KEYS, class P>
+__device__ __forceinline__ MeJob me_plan_item(const P &p, MeShared &S, int b64, int my_idx) {
     const auto &k   = p.ctrl;
     const int             tid = threadIdx.x;
-    const int             b64 = blockIdx.x;
     int                   b64x, b64y;
     b64_origin(p, b64, b64x, b64y);
     const int             block_w = min(p.width - b64x, 64), block_h = min(p.height - b64y, 64);
-
-    // me_ref0: first reference (list-0 references first, then list 1) this launch covers; the grid covers the batch's
-    // longest reference list
-    const int my_idx = me_ref0 + (int)blockIdx.y;
-    if (my_idx >= p.n_ref[0] + (p.n_list == 2 ? p.n_ref[1] : 0)) return;
     int       my_l = 0, my_r = my_idx;
     if (my_r >= p.n_ref[0]) {
         my_r -= p.n_ref[0];
@@ -211,10 +206,11 @@ __global__ void __launch_bounds__(ME_THREADS) me_plan_kernel(PICS pp, int me_ref
     }
     const int my = my_l * 4 + my_r;
     MeJob    *job = &p.me_jobs[b64 * 8 + my];
-    for (int pu = tid; pu < SVTME_PU_COUNT; pu += ME_THREADS) p.me_keys[(size_t)(b64 * 8 + my) * SVTME_PU_COUNT + pu] = ~0ull;
+    if (KEYS)
+        for (int pu = tid; pu < SVTME_PU_COUNT; pu += ME_THREADS) p.me_keys[(size_t)(b64 * 8 + my) * SVTME_PU_COUNT + pu] = ~0ull;
     if (!S.do_ref[my] || (p.me_type == SVTME_ME_MCTF && S.hsad[0] < p.tf_me_exit_th) || b64_left_out(p, b64)) {
-        if (tid == 0) *job = MeJob{0, 0, 0, 0};
-        return;
+        if (KEYS && tid == 0) *job = MeJob{0, 0, 0, 0};
+        return MeJob{0, 0, 0, 0};
     }
 
     // ---- integer_search_b64 for (my_l, my_r)
@@ -305,15 +301,30 @@ __global__ void __launch_bounds__(ME_THREADS) me_plan_kernel(PICS pp, int me_ref
     clip_axis(b64y, org_y, h, lo_y, hi_y);
 
     if (tid == 0) {
-        *job = MeJob{org_x, org_y, w, h};
+        if (KEYS) *job = MeJob{org_x, org_y, w, h};
         count_ops(p, 5, (unsigned long long)w * h * 2048ull);
         if (me_item_count(w, h) > p.me_max_items) count_ops(p, 7, 1); // cannot happen: the host sized the grid from sa_max
     }
+    return MeJob{org_x, org_y, w, h};
 }
 
 template <class PICS>
+__global__ void __launch_bounds__(ME_THREADS) me_plan_kernel(PICS pp, int me_ref0) {
+    __shared__ MeShared S;
+    const auto &p = pp[blockIdx.z]; // grid: x = 64x64 block, y = reference, z = picture
+    // me_ref0: first reference (list-0 references first, then list 1) this launch covers; the grid covers the batch's
+    // longest reference list
+    const int my_idx = me_ref0 + (int)blockIdx.y;
+    if (my_idx >= p.n_ref[0] + (p.n_list == 2 ? p.n_ref[1] : 0)) return;
+    (void)me_plan_item<true>(p, S, (int)blockIdx.x, my_idx);
+}
+
+// FUSED: every window of the batch is one work item (me_max_items == 1), which plans it, searches it and writes the final
+// results; me_plan_kernel has not run and me_finish_kernel<false> only tidies up.
+template <class PICS, bool FUSED>
 __global__ void __launch_bounds__(ME_THREADS, 2) me_search_kernel(PICS pp, int grid_refs, uint32_t grid_refs_magic, int ref_first, int ref_last) {
     constexpr int ROW_BITS = ME_ROW_BITS;
+    __shared__ MeShared               S; // (FUSED only)
     __shared__ __align__(16) uint32_t src_rows[32 * 16]; // rows 0,2,..,62 of the source block, 16 dwords each
     __shared__ __align__(16) uint32_t win[ME_WIN_BYTES / 4];
     // the grid's slowest dimension is (picture, reference): the work items of one picture are dispatched together, so that
@@ -330,14 +341,24 @@ __global__ void __launch_bounds__(ME_THREADS, 2) me_search_kernel(PICS pp, int g
     // ref_first .. ref_last (list-0 references first, then list 1).
     int       my_l = 0, my_r = p.n_ref[0] + (p.n_list == 2 ? p.n_ref[1] : 0) - 1 - ((int)blockIdx.z - pic_i * grid_refs);
     if (my_r < ref_first || my_r > ref_last) return;
+    const int my_idx = my_r;
     if (my_r >= p.n_ref[0]) {
         my_r -= p.n_ref[0];
         my_l = 1;
     }
     const int   my  = my_l * 4 + my_r;
-    const MeJob job = p.me_jobs[b64 * 8 + my];
+    MeJob       job;
+    if constexpr (FUSED) job = me_plan_item<false>(p, S, b64, my_idx);
+    else job = p.me_jobs[b64 * 8 + my];
     const int   w = job.w, h = job.h, org_x = job.org_x, org_y = job.org_y;
-    if (w <= 0) return;
+    // where this reference's results go: output plane = reference, list-0 references first
+    uint32_t *const out_sad = FUSED ? p.best_sad + (size_t)(my_idx * p.b64_w * p.b64_h + b64) * SVTME_PU_COUNT : nullptr;
+    uint32_t *const out_mv  = FUSED ? p.best_mv + (size_t)(my_idx * p.b64_w * p.b64_h + b64) * SVTME_PU_COUNT : nullptr;
+    if (w <= 0) {
+        if constexpr (FUSED) // not searched (pruned, the temporal filter's exit, a block the first pass leaves out): zeros
+            for (int pu = tid; pu < SVTME_PU_COUNT; pu += ME_THREADS) out_sad[pu] = out_mv[pu] = 0;
+        return;
+    }
     // ---- this item (me_item_units in svtme_device.h): a 64-position column chunk of the window is cut into units - the
     // 4 positions x 8 rows of a position quad and a group of 8 rows, or one row parity of them where the chunk has few
     // quads - numbered group by group; an item takes the next 16 of them, one per quad of lanes, from up to two groups of
@@ -621,16 +642,28 @@ __global__ void __launch_bounds__(ME_THREADS, 2) me_search_kernel(PICS pp, int g
         const int      sh = pu >= 5 && pu < 21 ? 16 : 6 + ROW_BITS;
         const uint32_t sad = k >> sh;
         // a key that no position produced (cannot happen for an item the plan made): all-ones fields exceed the largest SAD
-        if (sad > (pu >= 21 ? 8u * 4u : pu >= 5 ? 16u * 8u : pu >= 1 ? 32u * 16u : 64u * 32u) * 255u) continue;
-        const u64 key = ((u64)sad << 32) | ((uint32_t)(ty0 + (int)((k >> 6) & ((1 << ROW_BITS) - 1))) << 16) | (uint32_t)(tx0 + (int)(k & 63));
-        u64      *g   = &p.me_keys[(size_t)(b64 * 8 + my) * SVTME_PU_COUNT + pu];
-        if (key < *g) atomicMin(g, key);
+        const bool none = sad > (pu >= 21 ? 8u * 4u : pu >= 5 ? 16u * 8u : pu >= 1 ? 32u * 16u : 64u * 32u) * 255u;
+        const int  y = ty0 + (int)((k >> 6) & ((1 << ROW_BITS) - 1)), x = tx0 + (int)(k & 63);
+        if constexpr (FUSED) {
+            // the window's only item: these are the window's minima (me_finish_kernel's conversion: SADs were taken on every
+            // other row, x2 :248-305; the vector in quarter pels, y in the high half :474-476; a key nobody set reads as
+            // all ones there)
+            const int py = (none ? 0xFFFF : y) + org_y, px = (none ? 0xFFFF : x) + org_x;
+            out_sad[pu] = none ? 0xFFFFFFFEu : sad << 1;
+            out_mv[pu]  = ((uint32_t)(uint16_t)py << 18) | (uint16_t)((uint16_t)px << 2);
+        } else {
+            if (none) continue;
+            const u64 key = ((u64)sad << 32) | ((uint32_t)y << 16) | (uint32_t)x;
+            u64      *g   = &p.me_keys[(size_t)(b64 * 8 + my) * SVTME_PU_COUNT + pu];
+            if (key < *g) atomicMin(g, key);
+        }
     }
 }
 
 // ---- results: p_sb_best_sad / p_sb_best_mv, one plane per reference of the picture. SADs were taken on every other
 // row: x2 (:248-305). References that were not searched (pruned) read as zero.
-template <class PICS>
+// KEYS == false: the search items have written the results themselves (me_search_kernel<.., true>); only the tidying up.
+template <class PICS, bool KEYS>
 __global__ void __launch_bounds__(256) me_finish_kernel(PICS pp) {
     const auto &p = pp[blockIdx.y];
     const int n_b64 = p.b64_w * p.b64_h, per_plane = n_b64 * SVTME_PU_COUNT;
@@ -654,7 +687,7 @@ __global__ void __launch_bounds__(256) me_finish_kernel(PICS pp) {
         const int nz = n_b64 * SVTME_MAX_LISTS * SVTME_MAX_REFS * (int)(sizeof(HmeRefOut) / 4);
         for (int z = i; z < nz; z += (int)gridDim.x * 256) hz[z] = 0;
     }
-    if (i >= n) return;
+    if (!KEYS || i >= n) return;
     // output plane q = reference (l, r), list-0 references first
     const int   q = i / per_plane, rest = i - q * per_plane, b64 = rest / SVTME_PU_COUNT, pu = rest - b64 * SVTME_PU_COUNT;
     const int   l = q >= p.n_ref[0] ? 1 : 0, r = l ? q - p.n_ref[0] : q;
@@ -696,10 +729,21 @@ static void launch_me_as(const Batch &b, PICS pics, hipStream_t s, hipEvent_t ma
     // that use the rule.)
     const bool two_phase = p.ctrl.enable_me_sr_adjustment == 2 && p.ctrl.me_early_exit_th == 0 && n_refs > 1;
     int        me_ref0 = 0;
+    const dim3     grid(n_b64, p.me_max_items, n_refs * b.n);
+    const uint32_t refs_magic = (uint32_t)((0x100000000ull + (uint32_t)n_refs - 1) / (uint32_t)n_refs);
+    // no window of these controls is more than one work item: the item plans, searches and finishes its window
+    static const bool no_fusion = getenv("SVTME_ME_UNFUSED") != nullptr; // diagnostic: the three kernels in every case
+    if (p.me_max_items == 1 && !two_phase && !no_fusion) {
+        if (marks[0]) (void)hipEventRecord(marks[0], s);
+        hipLaunchKernelGGL((me_search_kernel<PICS, true>), grid, dim3(ME_THREADS), 0, s, pics, n_refs, refs_magic, 0, 1 << 30);
+        if (marks[1]) (void)hipEventRecord(marks[1], s);
+        // (the tidying up needs few workgroups: a grid-stride loop over the HME records)
+        hipLaunchKernelGGL((me_finish_kernel<PICS, false>), dim3(std::min((n_b64 * n_refs * SVTME_PU_COUNT + 255) / 256, 64), b.n), dim3(256), 0, s, pics);
+        if (marks[2]) (void)hipEventRecord(marks[2], s);
+        return;
+    }
     auto       search = [&](int ref_first, int ref_last) {
-        const dim3 grid(n_b64, p.me_max_items, n_refs * b.n);
-        const uint32_t refs_magic = (uint32_t)((0x100000000ull + (uint32_t)n_refs - 1) / (uint32_t)n_refs);
-        hipLaunchKernelGGL((me_search_kernel<PICS>), grid, dim3(ME_THREADS), 0, s, pics, n_refs, refs_magic, ref_first, ref_last);
+        hipLaunchKernelGGL((me_search_kernel<PICS, false>), grid, dim3(ME_THREADS), 0, s, pics, n_refs, refs_magic, ref_first, ref_last);
     };
     if (two_phase) {
         hipLaunchKernelGGL(me_plan_kernel<PICS>, dim3(n_b64, 1, b.n), dim3(ME_THREADS), 0, s, pics, 0);
@@ -711,7 +755,7 @@ static void launch_me_as(const Batch &b, PICS pics, hipStream_t s, hipEvent_t ma
     if (marks[0]) (void)hipEventRecord(marks[0], s);
     search(me_ref0, 1 << 30);
     if (marks[1]) (void)hipEventRecord(marks[1], s);
-    hipLaunchKernelGGL(me_finish_kernel<PICS>, dim3((n_b64 * n_refs * SVTME_PU_COUNT + 255) / 256, b.n), dim3(256), 0, s, pics);
+    hipLaunchKernelGGL((me_finish_kernel<PICS, true>), dim3((n_b64 * n_refs * SVTME_PU_COUNT + 255) / 256, b.n), dim3(256), 0, s, pics);
     if (marks[2]) (void)hipEventRecord(marks[2], s);
 }
 
@@ -723,7 +767,7 @@ void launch_me(const Batch &b, hipStream_t s, hipEvent_t marks[3]) {
 // resident workgroups per CU the runtime expects for the search kernel (diagnostic)
 int occupancy_me_search() {
     int n = 0;
-    (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, me_search_kernel<OnePicture>, ME_THREADS, 0);
+    (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, me_search_kernel<OnePicture, false>, ME_THREADS, 0);
     return n;
 }
 
