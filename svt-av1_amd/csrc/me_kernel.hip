@@ -319,6 +319,191 @@ __global__ void __launch_bounds__(ME_THREADS) me_plan_kernel(PICS pp, int me_ref
     (void)me_plan_item<true>(p, S, (int)blockIdx.x, my_idx);
 }
 
+// The walk and the merge of a work item of at most 16 / NS units (the small windows of the fast presets: 8 x 3, 8 x 6, 16 x 3
+// positions: split units, one row parity of a position quad each). With one unit per quad of lanes most of the wave would
+// idle, so the block's 32 sampled rows are cut into NS slices of R = 32 / NS rows and every unit is walked by NS quads of
+// lanes, a slice each: R + 3 steps instead of 35. A slice holds whole 8x8 and 16x16 partitions (R = 8: one row of 16x16
+// blocks; R = 16: two); the 16-row column sums of the slices meet through lane exchanges for the 32x32 and 64x64 sums, which
+// every slice then ranks (the same keys in each). Leaves the item's minima in win[4][85] as me_search_kernel's own walk does.
+template <int NS>
+__device__ __forceinline__ void me_walk_sliced(uint32_t *win, const uint32_t *src_rows, int u0, int u_end, uint32_t u_inv, int U, int g0, int rows,
+                                               int w, int tx0) {
+    constexpr int ROW_BITS = ME_ROW_BITS;
+    constexpr int R = 32 / NS, UQ = 16 / NS; // sampled rows per slice, units (quads of lanes) per slice
+    const int     tid = threadIdx.x, quad = tid >> 2, col = tid & 3;
+    const int     sl = quad / UQ, uq = quad & (UQ - 1);
+    const int     u     = u0 + uq;
+    const bool    valid = u < u_end;
+    const int     ug    = valid ? (int)(((uint32_t)u * u_inv) >> 16) : g0, uv = valid ? u - ug * U : 0;
+    const int     grp   = ug - g0;
+    const int     xg = uv >> 1, par = uv & 1;
+    const int     ya = 8 * grp, yb = min(rows, ya + 8);
+    const int     yfirst = ya + par;
+    const int     n_pos  = valid ? min(4, max(0, (yb - yfirst + 1) >> 1)) : 0; // same in the lanes of a unit
+    const bool    odd = (col & 1) != 0;
+    uint32_t      b8[R / 4][2][2], b16[R / 8][4], b32[2][2], b64k[2];
+#pragma unroll
+    for (int a = 0; a < R / 4; ++a)
+#pragma unroll
+        for (int c = 0; c < 2; ++c) b8[a][c][0] = b8[a][c][1] = 0xFFFFFFFFu;
+#pragma unroll
+    for (int a = 0; a < R / 8; ++a)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) b16[a][i] = 0xFFFFFFFFu;
+    b32[0][0] = b32[0][1] = b32[1][0] = b32[1][1] = b64k[0] = b64k[1] = 0xFFFFFFFFu;
+    uint32_t ypk[4], yrk[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+        const uint32_t yr = (uint32_t)(par + 2 * t);
+        ypk[t]            = t < n_pos ? yr * 0x10001u : 0xFFFFFFFFu;
+        yrk[t]            = t < n_pos ? (yr + 8 * grp) << 6 : 0xFFFFFFFFu;
+    }
+    u64      acc0[4], acc1[4];
+    uint32_t t16[4][2], half[4][2], sw[4][4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+        acc0[t] = acc1[t] = 0;
+        t16[t][0] = t16[t][1] = half[t][0] = half[t][1] = 0;
+    }
+    // position t meets the slice's sampled row m at step s = t + m; the slice's first window row lies 2 R sl rows under
+    // the unit's first
+    const uint32_t *sbase = &src_rows[col * 4 + R * sl * 16];
+    int             ie = (yfirst + 2 * R * sl) * ME_PD + xg + col * 4, io = ie + 1;
+    uint32_t        n01[2], n12[2], n23[2], n34[2], nsw[4];
+    auto            fetch = [&](auto s_c) {
+        constexpr int s = decltype(s_c)::value;
+        if constexpr ((s & 3) == 0) {
+            if constexpr (s > 0) {
+                ie += 8 * ME_PD;
+                io += 8 * ME_PD;
+            }
+            asm volatile("" : "+v"(ie));
+            asm volatile("" : "+v"(io));
+        }
+        constexpr int c = (s & 3) * 2 * ME_PD;
+        n01[0] = win[ie + c], n01[1] = win[ie + c + 1];
+        n12[0] = win[io + c], n12[1] = win[io + c + 1];
+        n23[0] = win[ie + c + 2], n23[1] = win[ie + c + 3];
+        n34[0] = win[io + c + 2], n34[1] = win[io + c + 3];
+        if constexpr (s < R) {
+            const uint4 v = *reinterpret_cast<const uint4 *>(sbase + s * 16);
+            nsw[0] = v.x, nsw[1] = v.y, nsw[2] = v.z, nsw[3] = v.w;
+        }
+    };
+    fetch(std::integral_constant<int, 0>{});
+    static_for<0, R + 3>([&](auto s_c) {
+        constexpr int s = decltype(s_c)::value;
+        const u64 p01 = ((u64)n01[1] << 32) | n01[0], p12 = ((u64)n12[1] << 32) | n12[0];
+        const u64 p23 = ((u64)n23[1] << 32) | n23[0], p34 = ((u64)n34[1] << 32) | n34[0];
+        if constexpr (s < R) sw[s & 3][0] = nsw[0], sw[s & 3][1] = nsw[1], sw[s & 3][2] = nsw[2], sw[s & 3][3] = nsw[3];
+        if constexpr (s + 1 < R + 3) fetch(std::integral_constant<int, s + 1>{});
+        __builtin_amdgcn_sched_barrier(0);
+        static_for<0, 4>([&](auto t_c) {
+            constexpr int t = decltype(t_c)::value;
+            constexpr int m = s - t; // the slice's sampled row of position t at this step
+            if constexpr (m >= 0 && m < R) {
+                acc0[t] = __builtin_amdgcn_qsad_pk_u16_u8(p01, sw[m & 3][0], (m & 3) == 0 ? (u64)0 : acc0[t]);
+                acc0[t] = __builtin_amdgcn_qsad_pk_u16_u8(p12, sw[m & 3][1], acc0[t]);
+                acc1[t] = __builtin_amdgcn_qsad_pk_u16_u8(p23, sw[m & 3][2], (m & 3) == 0 ? (u64)0 : acc1[t]);
+                acc1[t] = __builtin_amdgcn_qsad_pk_u16_u8(p34, sw[m & 3][3], acc1[t]);
+                if constexpr ((m & 3) == 3) {
+                    constexpr int  by = m >> 2, a = by >> 1; // 8x8 block row / 16x16 block row within the slice
+                    const uint32_t l0 = (uint32_t)acc0[t], h0 = (uint32_t)(acc0[t] >> 32);
+                    const uint32_t l1 = (uint32_t)acc1[t], h1 = (uint32_t)(acc1[t] >> 32);
+                    b8[by][0][0] = pk_min_u16(b8[by][0][0], (l0 << 3) | ypk[t]);
+                    b8[by][0][1] = pk_min_u16(b8[by][0][1], (h0 << 3) | ypk[t]);
+                    b8[by][1][0] = pk_min_u16(b8[by][1][0], (l1 << 3) | ypk[t]);
+                    b8[by][1][1] = pk_min_u16(b8[by][1][1], (h1 << 3) | ypk[t]);
+                    if constexpr ((by & 1) == 0) {
+                        t16[t][0] = pk_add_u16(l0, l1);
+                        t16[t][1] = pk_add_u16(h0, h1);
+                    } else {
+                        const uint32_t d0 = pk_add_u16(t16[t][0], pk_add_u16(l0, l1));
+                        const uint32_t d1 = pk_add_u16(t16[t][1], pk_add_u16(h0, h1));
+                        b16[a][0] = min(b16[a][0], (d0 << 16) | yrk[t]);
+                        b16[a][1] = min(b16[a][1], (d0 & 0xFFFF0000u) | yrk[t]);
+                        b16[a][2] = min(b16[a][2], (d1 << 16) | yrk[t]);
+                        b16[a][3] = min(b16[a][3], (d1 & 0xFFFF0000u) | yrk[t]);
+                        if constexpr ((a & 1) == 0) {
+                            half[t][0] = d0;
+                            half[t][1] = d1;
+                        } else {
+                            half[t][0] = pk_add_u16(half[t][0], d0);
+                            half[t][1] = pk_add_u16(half[t][1], d1);
+                        }
+                        if constexpr (a == R / 8 - 1) {
+                            // the slice's column sums of position t are complete: 32-row sums (<= 65280) of the block's top
+                            // and bottom half from the slices, the same in every slice of the unit
+                            uint32_t q0 = half[t][0], q1 = half[t][1];
+                            if constexpr (NS == 4) {
+                                q0 = pk_add_u16(q0, (uint32_t)__shfl_xor((int)q0, 16));
+                                q1 = pk_add_u16(q1, (uint32_t)__shfl_xor((int)q1, 16));
+                            }
+                            const uint32_t o0 = (uint32_t)__shfl_xor((int)q0, 32), o1 = (uint32_t)__shfl_xor((int)q1, 32);
+                            const bool     low = tid >= 32; // this slice lies in the block's bottom half
+                            const uint32_t top0 = low ? o0 : q0, top1 = low ? o1 : q1, bot0 = low ? q0 : o0, bot1 = low ? q1 : o1;
+                            const uint32_t tk = odd ? top1 : top0, tr = quad_xor1(odd ? top0 : top1);
+                            const uint32_t bk = odd ? bot1 : bot0, br = quad_xor1(odd ? bot0 : bot1);
+#pragma unroll
+                            for (int j = 0; j < 2; ++j) {
+                                const uint32_t tp = j ? (tk >> 16) + (tr >> 16) : (tk & 0xFFFFu) + (tr & 0xFFFFu);
+                                const uint32_t bt = j ? (bk >> 16) + (br >> 16) : (bk & 0xFFFFu) + (br & 0xFFFFu);
+                                uint32_t       all = tp + bt;
+                                all += quad_xor2(all);
+                                b32[0][j] = min(b32[0][j], (tp << (6 + ROW_BITS)) | yrk[t]);
+                                b32[1][j] = min(b32[1][j], (bt << (6 + ROW_BITS)) | yrk[t]);
+                                b64k[j]   = min(b64k[j], (all << (6 + ROW_BITS)) | yrk[t]);
+                            }
+                        }
+                    }
+                }
+            }
+        });
+    });
+    // ---- merge, as in me_search_kernel: a row of 16 lanes holds four units of one slice; the rows' results meet in
+    // win[4][85], where a row fills in the partitions of its slice and leaves the others all ones
+    const uint32_t xbase = (uint32_t)(xg * 4);
+    const bool     narrow = w < 8;
+    uint32_t       xlab[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) xlab[i] = (narrow && (int)(tx0 + xbase + i) >= w) ? 0xFFFFFFFFu : xbase + i;
+    const bool writer = (tid & 12) == 12;
+    wave_sync();
+    for (int i = tid; i < 4 * SVTME_PU_COUNT; i += ME_THREADS) win[i] = 0xFFFFFFFFu;
+    wave_sync();
+    uint32_t *part = win + (tid >> 4) * SVTME_PU_COUNT;
+#pragma unroll
+    for (int byl = 0; byl < R / 4; ++byl)
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+            const uint32_t d0 = b8[byl][c][0], d1 = b8[byl][c][1];
+            const uint32_t k0 = ((d0 & 0xFFFFu) << 6) | xlab[0], k1 = ((d0 >> 16) << 6) | xlab[1];
+            const uint32_t k2 = ((d1 & 0xFFFFu) << 6) | xlab[2], k3 = ((d1 >> 16) << 6) | xlab[3];
+            const uint32_t km = min(min(k0, k1), min(k2, k3));
+            const uint32_t k  = row_quads_min(((km & 0xFFFFFE00u) << (ROW_BITS - 3)) | ((km & 0x1FFu) | ((uint32_t)grp << 9)));
+            const int      by = byl + (R / 4) * sl, bx8 = col * 2 + c;
+            const int      pu = 21 + z16(by >> 1, bx8 >> 1) * 4 + ((by & 1) << 1) + (bx8 & 1);
+            if (writer) part[pu] = k;
+        }
+#pragma unroll
+    for (int al = 0; al < R / 8; ++al) {
+        const uint32_t k = row_quads_min(min(min(b16[al][0] | xlab[0], b16[al][1] | xlab[1]), min(b16[al][2] | xlab[2], b16[al][3] | xlab[3])));
+        if (writer) part[5 + z16(al + (R / 8) * sl, col)] = k;
+    }
+    const uint32_t xl0 = odd ? xlab[2] : xlab[0], xl1 = odd ? xlab[3] : xlab[1];
+#pragma unroll
+    for (int a = 0; a < 2; ++a) {
+        uint32_t k = min(b32[a][0] | xl0, b32[a][1] | xl1);
+        k          = row_quads_min(min(k, quad_xor1(k)));
+        if (writer && !odd) part[1 + a * 2 + (col >> 1)] = k;
+    }
+    {
+        uint32_t k = min(b64k[0] | xl0, b64k[1] | xl1);
+        k          = row_quads_min(min(k, quad_xor1(k)));
+        if (writer && col == 0) part[0] = k;
+    }
+}
+
 // FUSED: every window of the batch is one work item (me_max_items == 1), which plans it, searches it and writes the final
 // results; me_plan_kernel has not run and me_finish_kernel<false> only tidies up.
 template <class PICS, bool FUSED>
@@ -432,7 +617,10 @@ __global__ void __launch_bounds__(ME_THREADS, 2) me_search_kernel(PICS pp, int g
             }
             __syncthreads();
             const int  n_it   = split ? 1 : 2;
-            {
+            // the small windows of the fast presets: every unit walked by two or four quads of lanes (me_walk_sliced)
+            if (FUSED && u_end - u0 <= 4) me_walk_sliced<4>(win, src_rows, u0, u_end, u_inv, U, g0, rows, w, tx0);
+            else if (FUSED && u_end - u0 <= 8) me_walk_sliced<2>(win, src_rows, u0, u_end, u_inv, U, g0, rows, w, tx0);
+            else {
                 // this quad's unit: group of rows `grp` (counted from the item's first), position quad xg, row parity
                 const int  u     = u0 + quad;
                 const bool valid = quad < UPI && u < u_end;
