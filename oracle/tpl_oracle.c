@@ -549,3 +549,182 @@ int orc_tpl_search(const uint8_t *cur_pix, int stride, const uint8_t *const ref_
     }
     return SVTME_OK;
 }
+
+
+/* ---- the reconstruction path (:1004-1197): prediction of the chosen mode from the reconstructed picture (intra) or the
+ * reference picture (inter), residual, forward transform, quantisation, inverse transform into the reconstructed picture,
+ * and the statistics result_model_store (:211-288) keeps.
+ *
+ * The inverse DCT: svt_av1_inv_txfm2d_add_WxH_c (inv_txfm2d_add_c, EbInvTransforms.c:2455-2533) - every row of coefficients
+ * (x 1/sqrt(2) where W : H is 2 : 1), clamped to 16 bits, through a W-point transform, rounded >> -shift[0]; every column,
+ * clamped to 16 bits, through an H-point transform, rounded >> 4, added to the prediction and clipped to a byte. The 1-D
+ * transforms are the networks of svt_av1_idct4_new .. svt_av1_idct16_new (:75-355) at 12 cosine bits: rotations rounded as
+ * in the forward transform, every sum and difference clamped to 16 bits (stage range 16 at 8 bits, :23-65). The N-point
+ * network is the N/2-point network of the even inputs and an "odd half" of the odd ones, joined by N clamped sums and
+ * differences; written that way here (the same values at every node). */
+static int32_t clamp16(int32_t v) { return v > 32767 ? 32767 : (v < -32768 ? -32768 : v); }
+
+static void idct4(const int32_t *x, int32_t *X, const int32_t *c) {
+    const int32_t a0 = rot(x[0], c[32], x[2], c[32], 12), a1 = rot(x[0], c[32], x[2], -c[32], 12);
+    const int32_t a2 = rot(x[1], c[48], x[3], -c[16], 12), a3 = rot(x[1], c[16], x[3], c[48], 12);
+    X[0] = clamp16(a0 + a3), X[1] = clamp16(a1 + a2), X[2] = clamp16(a1 - a2), X[3] = clamp16(a0 - a3);
+}
+
+static void idct8(const int32_t *x, int32_t *X, const int32_t *c) {
+    const int32_t ev[4] = {x[0], x[2], x[4], x[6]};
+    int32_t       E[4];
+    idct4(ev, E, c);
+    const int32_t b4 = rot(x[1], c[56], x[7], -c[8], 12), b5 = rot(x[5], c[24], x[3], -c[40], 12);
+    const int32_t b6 = rot(x[5], c[40], x[3], c[24], 12), b7 = rot(x[1], c[8], x[7], c[56], 12);
+    const int32_t c4 = clamp16(b4 + b5), c5 = clamp16(b4 - b5), c6 = clamp16(-b6 + b7), c7 = clamp16(b6 + b7);
+    const int32_t d[4] = {c4, rot(c5, -c[32], c6, c[32], 12), rot(c5, c[32], c6, c[32], 12), c7}; /* nodes 4 .. 7 */
+    for (int i = 0; i < 4; ++i) {
+        X[i]     = clamp16(E[i] + d[3 - i]);
+        X[7 - i] = clamp16(E[i] - d[3 - i]);
+    }
+}
+
+static void idct16(const int32_t *x, int32_t *X, const int32_t *c) {
+    int32_t ev[8], E[8];
+    for (int i = 0; i < 8; ++i) ev[i] = x[2 * i];
+    idct8(ev, E, c);
+    const int32_t b8 = rot(x[1], c[60], x[15], -c[4], 12), b9 = rot(x[9], c[28], x[7], -c[36], 12);
+    const int32_t b10 = rot(x[5], c[44], x[11], -c[20], 12), b11 = rot(x[13], c[12], x[3], -c[52], 12);
+    const int32_t b12 = rot(x[13], c[52], x[3], c[12], 12), b13 = rot(x[5], c[20], x[11], c[44], 12);
+    const int32_t b14 = rot(x[9], c[36], x[7], c[28], 12), b15 = rot(x[1], c[4], x[15], c[60], 12);
+    const int32_t c8 = clamp16(b8 + b9), c9 = clamp16(b8 - b9), c10 = clamp16(-b10 + b11), c11 = clamp16(b10 + b11);
+    const int32_t c12 = clamp16(b12 + b13), c13 = clamp16(b12 - b13), c14 = clamp16(-b14 + b15), c15 = clamp16(b14 + b15);
+    const int32_t d9 = rot(c9, -c[16], c14, c[48], 12), d10 = rot(c10, -c[48], c13, -c[16], 12);
+    const int32_t d13 = rot(c10, -c[16], c13, c[48], 12), d14 = rot(c9, c[48], c14, c[16], 12);
+    const int32_t e8 = clamp16(c8 + c11), e9 = clamp16(d9 + d10), e10 = clamp16(d9 - d10), e11 = clamp16(c8 - c11);
+    const int32_t e12 = clamp16(-c12 + c15), e13 = clamp16(-d13 + d14), e14 = clamp16(d13 + d14), e15 = clamp16(c12 + c15);
+    const int32_t f[8] = {e8, e9, rot(e10, -c[32], e13, c[32], 12), rot(e11, -c[32], e12, c[32], 12),
+                          rot(e11, c[32], e12, c[32], 12), rot(e10, c[32], e13, c[32], 12), e14, e15}; /* nodes 8 .. 15 */
+    for (int i = 0; i < 8; ++i) {
+        X[i]      = clamp16(E[i] + f[7 - i]);
+        X[15 - i] = clamp16(E[i] - f[7 - i]);
+    }
+}
+
+static void idct(int n, const int32_t *x, int32_t *X, const int32_t *c) {
+    if (n == 4) idct4(x, X, c);
+    else if (n == 8) idct8(x, X, c);
+    else idct16(x, X, c);
+}
+
+/* dq [h][w] (w = 16, h = 16 / 8 / 4) added to the h rows at dst, dst_stride apart */
+void orc_tpl_inv_dct_add(const int32_t *dq, int w, int h, uint8_t *dst, int dst_stride) {
+    int32_t c[64], buf[16 * 16], in[16], out[16];
+    cos_table(c, 12);
+    const int shift0 = (w == 16 && h == 16) ? 2 : 1; /* inv_shift_16x16 / 16x8 / 16x4, EbInvTransforms.h:53-65 */
+    for (int r = 0; r < h; ++r) {
+        for (int i = 0; i < w; ++i) {
+            int32_t v = dq[r * w + i];
+            if (w == 2 * h) v = (int32_t)(((int64_t)v * 2896 + 2048) >> 12); /* new_inv_sqrt2, 12 bits */
+            in[i] = clamp16(v);
+        }
+        idct(w, in, out, c);
+        for (int i = 0; i < w; ++i) buf[r * w + i] = (out[i] + (1 << (shift0 - 1))) >> shift0;
+    }
+    for (int col = 0; col < w; ++col) {
+        for (int r = 0; r < h; ++r) in[r] = clamp16(buf[r * w + col]);
+        idct(h, in, out, c);
+        for (int r = 0; r < h; ++r) {
+            const int v = dst[r * dst_stride + col] + ((out[r] + 8) >> 4);
+            dst[r * dst_stride + col] = (uint8_t)(v < 0 ? 0 : (v > 255 ? 255 : v));
+        }
+    }
+}
+
+/* get_quantize_error's dqcoeff and whether any level is left (eob != 0): svt_av1_quantize_fp_c as in orc_tpl_quantize_error */
+static int tpl_dequantised(const int32_t *coeff, int n, const int16_t round_fp[2], const int16_t quant_fp[2], const int16_t dequant[2],
+                           int32_t *dq) {
+    int any = 0;
+    for (int i = 0; i < n; ++i) {
+        const int ac = i != 0, v = coeff[i], neg = v < 0;
+        int64_t   a = neg ? -(int64_t)v : v;
+        dq[i]       = 0;
+        if ((a << 1) >= dequant[ac]) {
+            a += round_fp[ac];
+            a = a > INT16_MAX ? INT16_MAX : a;
+            const int32_t level = (int32_t)((a * quant_fp[ac]) >> 16);
+            if (level) {
+                dq[i] = neg ? -(level * dequant[ac]) : level * dequant[ac];
+                any   = 1;
+            }
+        }
+    }
+    return any;
+}
+
+int orc_tpl_recon(const uint8_t *cur_pix, int stride, const uint8_t *const ref_pix[SVTME_MAX_LISTS * SVTME_MAX_REFS],
+                  const svtme_tpl_picture *p, const svtme_tpl_block *blocks, uint8_t *recon, orc_tpl_stats *stats) {
+    if (p->pf_shape > 2 || p->subsample_tx > 2) return SVTME_ERR_UNSUPPORTED;
+    if (p->dispenser_search_level != 0) return SVTME_ERR_UNSUPPORTED; /* 16x16 blocks: tpl levels 1 .. 6 */
+    const int   w = (int)p->width, h = (int)p->height, b64_w = (w + 63) / 64, b64_h = (h + 63) / 64;
+    const plane cur = {cur_pix, stride, w, h}, rec = {recon, stride, w, h};
+    const int   all_modes = !p->tpl_opt_flag, shape = all_modes ? 0 : p->pf_shape; /* :1131-1133 */
+    const int   dc_path = p->tpl_opt_flag && p->use_pred_sad_in_intra_search; /* intra_dc_sad_path :594-595 */
+    const int   sub = p->subsample_tx, step = 1 << sub, tx_h = 16 >> sub;
+    memset(stats, 0, sizeof(*stats) * (size_t)b64_w * b64_h * SVTME_TPL_BLOCKS);
+    for (int b64 = 0; b64 < b64_w * b64_h; ++b64) {
+        const int sb_x = (b64 % b64_w) * 64, sb_y = (b64 / b64_w) * 64;
+        for (int bi = 5; bi <= 20; ++bi) {
+            int bx, by, size;
+            blk_geometry(bi, &bx, &by, &size);
+            const int x = sb_x + bx, y = sb_y + by;
+            if (x + 8 > w || y + 8 > h) continue; /* :604-607 */
+            const svtme_tpl_block *b = &blocks[(size_t)b64 * SVTME_TPL_BLOCKS + bi];
+            uint8_t                prd[256];
+            if (b->best_is_inter) { /* :1005-1030: the block the vector points at in the reference picture */
+                const int list = b->best_rf_idx < 4 ? 0 : 1, ref = b->best_rf_idx & 3;
+                if (!ref_pix[list * SVTME_MAX_REFS + ref]) return SVTME_ERR_BAD_ARG;
+                const plane rp = {ref_pix[list * SVTME_MAX_REFS + ref], stride, w, h};
+                for (int r = 0; r < 16; ++r)
+                    for (int c = 0; c < 16; ++c) prd[r * 16 + c] = (uint8_t)pel(&rp, x + (b->mv_x >> 3) + c, y + (b->mv_y >> 3) + r);
+            } else if (dc_path) { /* :1044-1078 */
+                memset(prd, dc_value(&rec, x, y, 16), 256);
+            } else { /* :1080-1119: the neighbours in the reconstructed picture */
+                uint8_t   above[40], left[40];
+                const int mode = b->best_intra_mode;
+                tpl_neighbours(&rec, x, y, above + 4, left + 4);
+                if (mode >= 1 && mode <= 8) tpl_filter_edges(k_mode_angle[mode], x, y, above + 4, left + 4);
+                tpl_intra_predict(mode, x, y, above + 4, left + 4, prd);
+            }
+            int16_t res[256];
+            int32_t coeff[256], dq[256];
+            for (int r = 0; r < tx_h; ++r) /* svt_aom_subtract_block over every step-th row, :1123-1130 */
+                for (int c = 0; c < 16; ++c) res[r * 16 + c] = (int16_t)(pel(&cur, x + c, y + r * step) - prd[r * step * 16 + c]);
+            orc_tpl_fwd_dct(res, 16, tx_h, coeff, shape);
+            const int64_t recon_error = orc_tpl_quantize_error(coeff, 16 * tx_h, p->y_round_fp, p->y_quant_fp, p->y_dequant);
+            const int     eob = tpl_dequantised(coeff, 16 * tx_h, p->y_round_fp, p->y_quant_fp, p->y_dequant, dq);
+            const int64_t rate_cost = p->tpl_opt_flag ? 0 : orc_tpl_rate16(coeff, p->y_round_fp, p->y_quant_fp, p->y_dequant);
+            if (!p->disable_intra_pred && eob) { /* :1143-1177 (disable_intra_pred implies a picture that is not a reference) */
+                orc_tpl_inv_dct_add(dq, 16, tx_h, prd, 16 * step);
+                for (int r = 0; r < 16; ++r) /* the rows between take the row above them */
+                    if (r % step) memcpy(prd + r * 16, prd + (r - r % step) * 16, 16);
+            }
+            for (int r = 0; r < 16 && y + r < h; ++r)
+                for (int c = 0; c < 16 && x + c < w; ++c) recon[(size_t)(y + r) * stride + x + c] = prd[r * 16 + c];
+            orc_tpl_stats *o = &stats[(size_t)b64 * SVTME_TPL_BLOCKS + bi];
+            o->recrf_dist = (recon_error << 4) << sub; /* TPL_DEP_COST_SCALE_LOG2, :1179-1181 */
+            o->recrf_rate = (rate_cost << 4) << sub;
+            if (b->best_is_inter) { /* :980-981 */
+                o->srcrf_dist = (b->src_recon_error << 4) << sub;
+                o->srcrf_rate = (b->src_rate << 4) << sub;
+            } else { /* :1182-1187 */
+                o->srcrf_dist = o->recrf_dist;
+                o->srcrf_rate = o->recrf_rate;
+            }
+            if (o->recrf_dist < o->srcrf_dist) o->recrf_dist = o->srcrf_dist; /* :1189-1190 */
+            if (o->recrf_rate < o->srcrf_rate) o->recrf_rate = o->srcrf_rate;
+            /* result_model_store :214-222 */
+            o->srcrf_dist /= 16, o->recrf_dist /= 16, o->srcrf_rate /= 16, o->recrf_rate /= 16;
+            if (o->srcrf_dist < 1) o->srcrf_dist = 1;
+            if (o->recrf_dist < 1) o->recrf_dist = 1;
+            if (o->srcrf_rate < 1) o->srcrf_rate = 1;
+            if (o->recrf_rate < 1) o->recrf_rate = 1;
+        }
+    }
+    return SVTME_OK;
+}

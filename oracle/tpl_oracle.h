@@ -17,4 +17,13 @@ int64_t orc_tpl_quantize_error(const int32_t *coeff, int n, const int16_t round_
 int64_t orc_tpl_rate16(const int32_t *coeff, const int16_t round_fp[2], const int16_t quant_fp[2], const int16_t dequant[2]);
 /* the transform-domain costs of intra modes DC_PRED .. PAETH_PRED of the 16x16 block at (x, y) (tpl_opt_flag = 0) */
 void orc_tpl_intra_costs(const uint8_t *cur_pix, int stride, int w, int h, int x, int y, int64_t costs[13]);
+/* The reconstruction path of the dispenser (:1004-1197) for 16x16 blocks (dispenser_search_level 0): `blocks` is what
+ * orc_tpl_search found with src_dist set; recon: width x height bytes of `stride`, written block by block in the dispenser's
+ * order; stats [n_b64][SVTME_TPL_BLOCKS]: TplStats as result_model_store leaves them, zero for blocks that do not exist. */
+typedef struct orc_tpl_stats {
+    int64_t srcrf_dist, recrf_dist, srcrf_rate, recrf_rate;
+} orc_tpl_stats;
+int  orc_tpl_recon(const uint8_t *cur_pix, int stride, const uint8_t *const ref_pix[SVTME_MAX_LISTS * SVTME_MAX_REFS],
+                   const svtme_tpl_picture *p, const svtme_tpl_block *blocks, uint8_t *recon, orc_tpl_stats *stats);
+void orc_tpl_inv_dct_add(const int32_t *dq, int w, int h, uint8_t *dst, int dst_stride);
 #endif

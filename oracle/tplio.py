@@ -98,6 +98,46 @@ def oracle_search(cur, refs, pic):
     return out
 
 
+TPL_STATS = np.dtype([("srcrf_dist", "<i8"), ("recrf_dist", "<i8"), ("srcrf_rate", "<i8"), ("recrf_rate", "<i8")])
+
+
+def recon_available(ctrl):
+    """The reconstruction path is restated for 16x16 blocks (tpl levels 1 to 6)."""
+    return ctrl["dispenser_search_level"] == 0
+
+
+def oracle_recon(cur, refs, pic, blocks):
+    """The dispenser's reconstruction path on what oracle_search found (pic with src_dist): returns (reconstructed picture
+    uint8 [h, w], TPL_STATS records [n_b64, 21])."""
+    global _lib
+    if _lib is None:
+        _lib = ctypes.CDLL(ORACLE_LIB)
+    h, w = cur.shape
+    cur = np.ascontiguousarray(cur, np.uint8)
+    keep = {k: np.ascontiguousarray(v, np.uint8) for k, v in refs.items()}
+    ptrs = (ctypes.POINTER(ctypes.c_uint8) * 8)()
+    for (l, r), a in keep.items():
+        ptrs[l * 4 + r] = a.ctypes.data_as(ctypes.POINTER(ctypes.c_uint8))
+    blocks = np.ascontiguousarray(blocks, TPL_BLOCK)
+    recon = np.zeros((h, w), np.uint8)
+    stats = np.zeros(blocks.shape, TPL_STATS)
+    _lib.orc_tpl_recon.restype = ctypes.c_int
+    rc = _lib.orc_tpl_recon(cur.ctypes.data_as(ctypes.POINTER(ctypes.c_uint8)), w, ptrs, ctypes.byref(pic),
+                            blocks.ctypes.data_as(ctypes.c_void_p), recon.ctypes.data_as(ctypes.c_void_p),
+                            stats.ctypes.data_as(ctypes.c_void_p))
+    if rc != 0:
+        raise RuntimeError("orc_tpl_recon: %d" % rc)
+    return recon, stats
+
+
+def recon_hash(recon):
+    """The 64-bit FNV-1a hash the reference driver records of the reconstructed picture (oracle/ref_driver.c, tpl_dump)."""
+    h = 0xcbf29ce484222325
+    for v in np.ascontiguousarray(recon, np.uint8).tobytes():
+        h = ((h ^ v) * 0x100000001b3) & 0xFFFFFFFFFFFFFFFF
+    return h
+
+
 def me_inputs_of(pd, bd):
     """The ME results a reference dump holds (refio.PIC_DUMP record, refio.B64_DUMP records) in the shape make_picture takes."""
     return dict(total_me_candidate_index=bd["total_me_candidate_index"].copy(),

@@ -76,6 +76,27 @@ def test_oracle_reproduces_reference_tpl_search(name):
     assert (n_src > 0) == (tplio.src_dist_available(per[0][0]) and n_intra < n_blocks)
 
 
+@pytest.mark.parametrize("name", sorted(CASES))
+def test_oracle_reproduces_reference_tpl_reconstruction(name):
+    """The dispenser's reconstruction path (prediction from the reconstructed / the reference picture, transform,
+    quantisation, inverse transform) on the search's results: the reconstructed picture's hash and the four statistics of
+    every block as the real reference left them."""
+    frames, pics, per = load_case(name, CASES[name])
+    if not tplio.recon_available(per[0][0]):
+        pytest.skip("32x32 blocks: not restated")
+    for pic, (ctrl, me, tb, quant) in zip(pics, per):
+        p, keep, refs = picture_of(frames, pic, ctrl, me, quant=quant)
+        blocks = tplio.oracle_search(frames[pic.poc], refs, p)
+        recon, stats = tplio.oracle_recon(frames[pic.poc], refs, p, blocks)
+        g = np.load(os.path.join(GOLDEN, name + ".npz"))
+        v = tb["valid"] == 1
+        for f in ("srcrf_dist", "recrf_dist", "srcrf_rate", "recrf_rate"):
+            bad = np.argwhere(v & (stats[f] != tb[f]))
+            assert not len(bad), "%s poc %d: %s differs at (b64, block) %s: %d != %d (%d places)" % (
+                name, pic.poc, f, tuple(bad[0]), stats[f][tuple(bad[0])], tb[f][tuple(bad[0])], len(bad))
+        assert tplio.recon_hash(recon) == int(g["pic%d_tpl" % pics.index(pic)]["recon_hash"]), (name, pic.poc)
+
+
 @pytest.mark.parametrize("name", sorted(n for n in CASES if n.startswith("tpl1_")))
 def test_oracle_reproduces_every_intra_mode_cost_the_reference_recorded(name):
     """tpl_opt_flag = 0: the reference's record holds the cost of each of the thirteen intra modes of every block, in mode
