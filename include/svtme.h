@@ -617,6 +617,31 @@ typedef struct svtme_tpl_block {
 } svtme_tpl_block;
 int svtme_tpl_search(svtme_engine *e, const svtme_tpl_picture *pic, svtme_tpl_block *out /* [n_b64][SVTME_TPL_BLOCKS] */);
 
+/*
+ * The dispenser's reconstruction path, the second half of tpl_mc_flow_dispenser_sb_generic
+ * (EbSourceBasedOperationsProcess.c:1004-1197), for the 16x16 blocks of dispenser_search_level 0 (tpl levels 1 to 6;
+ * SVTME_ERR_UNSUPPORTED otherwise). `blocks` is what svtme_tpl_search returned for the picture with src_dist set - or what the
+ * encoder kept of it between TPL groups (tpl_src_stats_buffer, :983-1002). Per block: the prediction - the reference
+ * picture's block at the full-pel vector for NEWMV (:1005-1030), else DC from the reconstructed neighbours
+ * (intra_dc_sad_path, :1044-1078) or best_intra_mode with update_neighbor_samples_array_open_loop_mb_recon,
+ * filter_intra_edge and intra_prediction_open_loop_mb (:1080-1119) -, the residual over every (1 << subsample_tx)-th row,
+ * svt_av1_wht_fwd_txfm with pf_shape, get_quantize_error, rate_estimator (:1123-1141), and, unless disable_intra_pred is
+ * set, av1_inv_transform_recon8bit of the dequantised coefficients into the reconstructed picture with the rows between
+ * copied from the row above (:1143-1177). ref_key names the pictures the predictions are copied from: source pictures, or
+ * pictures reconstructed by earlier calls that the caller has put into the store under keys of their own
+ * (encode_context_ptr->mc_flow_rec_picture_buffer for references inside the TPL group, :1011-1021).
+ * stats: [n_b64][SVTME_TPL_BLOCKS], TplStats as result_model_store leaves them (:211-222, :1179-1197): srcrf / recrf
+ * distortion and rate, divided by the block size, at least 1; zero for blocks outside the grid. recon: NULL, or width x
+ * height bytes of recon_stride that receive the reconstructed picture. The blocks that depend on reconstructed neighbours
+ * (the intra ones) run as a wavefront over the picture; the others all at once. Synchronous; shares its stream with the
+ * other svtme_tpl_* / svtme_gm_* calls.
+ */
+typedef struct svtme_tpl_stats {
+    int64_t srcrf_dist, recrf_dist, srcrf_rate, recrf_rate;
+} svtme_tpl_stats;
+int svtme_tpl_recon(svtme_engine *e, const svtme_tpl_picture *pic, const svtme_tpl_block *blocks /* [n_b64][SVTME_TPL_BLOCKS] */,
+                    svtme_tpl_stats *stats /* [n_b64][SVTME_TPL_BLOCKS] */, uint8_t *recon, uint32_t recon_stride);
+
 const char *svtme_version(void);
 
 #ifdef __cplusplus

@@ -138,6 +138,9 @@ struct GmState {
     // svtme_tpl_search: the caller's ME results and the block records, device and pinned host copies (first call allocates)
     uint8_t *d_tpl = nullptr, *h_tpl = nullptr;
     size_t   tpl_bytes = 0;
+    // svtme_tpl_recon: block records, statistics, the picture's record and the reconstructed picture (first call allocates)
+    uint8_t *d_rec = nullptr, *h_rec = nullptr;
+    size_t   rec_bytes = 0;
 };
 constexpr size_t kGmCornerInts = 2 + 2 * (size_t)SVTME_GM_MAX_CORNERS, kGmMatchInts = 5 * (size_t)SVTME_GM_MAX_CORNERS;
 
@@ -387,11 +390,12 @@ extern "C" void svtme_destroy(svtme_engine *e) {
     if (e->d_tiles) (void)hipFree(e->d_tiles);
     {
         GmState &g = e->gm;
-        void    *dev[] = {g.d_score, g.d_keep, g.d_rows, g.d_corners[0], g.d_corners[1], g.d_match, g.d_block_err, g.d_result, g.d_filter, g.d_lut, g.d_tpl};
+        void    *dev[] = {g.d_score, g.d_keep, g.d_rows, g.d_corners[0], g.d_corners[1], g.d_match, g.d_block_err, g.d_result, g.d_filter, g.d_lut, g.d_tpl, g.d_rec};
         for (void *d : dev)
             if (d) (void)hipFree(d);
         if (g.h_buf) (void)hipHostFree(g.h_buf);
         if (g.h_tpl) (void)hipHostFree(g.h_tpl);
+        if (g.h_rec) (void)hipHostFree(g.h_rec);
     }
     for (auto sm : e->s_me)
         if (sm) (void)hipStreamDestroy(sm);
@@ -1742,6 +1746,103 @@ extern "C" int svtme_tpl_search(svtme_engine *e, const svtme_tpl_picture *pic, s
     memcpy(&err, g.h_tpl + err_off, sizeof(err));
     if (err) return SVTME_ERR_BAD_ARG;
     memcpy(out, g.h_tpl + out_off, out_bytes);
+    return SVTME_OK;
+}
+
+// ---- TPL dispenser: reconstruction path
+extern "C" int svtme_tpl_recon(svtme_engine *e, const svtme_tpl_picture *pic, const svtme_tpl_block *blocks, svtme_tpl_stats *stats, uint8_t *recon,
+                               uint32_t recon_stride) {
+    if (!e || !pic || !blocks || !stats) return SVTME_ERR_BAD_ARG;
+    if (pic->width < 64 || pic->height < 64 || pic->width > e->cfg.max_width || pic->height > e->cfg.max_height || pic->width % 8 ||
+        pic->height % 8 || pic->n_ref[0] > SVTME_MAX_REFS || pic->n_ref[1] > SVTME_MAX_REFS || (recon && recon_stride < pic->width))
+        return SVTME_ERR_BAD_ARG;
+    // 16x16 blocks with the 16x16, 16x8 and 16x4 transforms: tpl levels 1 to 6
+    if (pic->dispenser_search_level != 0 || pic->subsample_tx > 2 || pic->pf_shape > 2) return SVTME_ERR_UNSUPPORTED;
+    const bool all_modes = !pic->tpl_opt_flag;
+    if (all_modes && pic->subsample_tx != 0) return SVTME_ERR_UNSUPPORTED; // rate_estimator is there for the 16x16 transform
+    const int b64_w = (int)(pic->width + 63) / 64, n_b64 = b64_w * ((int)(pic->height + 63) / 64);
+    const size_t n_blk = (size_t)n_b64 * SVTME_TPL_BLOCKS;
+    for (size_t i = 0; i < n_blk; ++i) { // what the kernels index with
+        const svtme_tpl_block &b = blocks[i];
+        if (!b.valid || !b.best_is_inter) {
+            if (b.valid && b.best_intra_mode > 12) return SVTME_ERR_BAD_ARG;
+            continue;
+        }
+        if (b.best_rf_idx < 0 || b.best_rf_idx > 7 || (b.best_rf_idx & 3) >= pic->n_ref[b.best_rf_idx >> 2]) return SVTME_ERR_BAD_ARG;
+    }
+    DEVICE_OR_FAIL(e->cfg.device);
+    std::lock_guard<std::mutex> gm_lock(e->gm.mu);
+    GmState  &g = e->gm;
+    const size_t blk_bytes = n_blk * sizeof(svtme_tpl_block), stat_bytes = n_blk * sizeof(svtme_tpl_stats);
+    const size_t stat_off = (blk_bytes + 63) / 64 * 64, par_off = (stat_off + stat_bytes + 63) / 64 * 64;
+    const size_t rec_stride = ((size_t)pic->width + 63) / 64 * 64, rec_off = par_off + (sizeof(TplParams) + 63) / 64 * 64;
+    const size_t total = rec_off + rec_stride * pic->height;
+    if (g.rec_bytes < total) {
+        if (g.d_rec) (void)hipFree(g.d_rec);
+        if (g.h_rec) (void)hipHostFree(g.h_rec);
+        g.d_rec = g.h_rec = nullptr;
+        g.rec_bytes = 0;
+        if (hipMalloc((void **)&g.d_rec, total) != hipSuccess || hipHostMalloc((void **)&g.h_rec, total, hipHostMallocDefault) != hipSuccess) {
+            (void)hipGetLastError();
+            return SVTME_ERR_NO_RESOURCES;
+        }
+        g.rec_bytes = total;
+    }
+    GmPlanes pl(e);
+    uint64_t keys[GmPlanes::kMax];
+    int      n_keys = 0;
+    keys[n_keys++]  = pic->cur_key;
+    for (int l = 0; l < SVTME_MAX_LISTS; ++l)
+        for (int r = 0; r < pic->n_ref[l]; ++r) keys[n_keys++] = pic->ref_key[l][r];
+    if (const int rc = pl.take(keys, n_keys, 0)) return rc;
+    TplParams p;
+    memset(&p, 0, sizeof(p));
+    p.cur = pl.plane[0];
+    if (p.cur.width != (int)pic->width || p.cur.height != (int)pic->height) return SVTME_ERR_BAD_ARG;
+    for (int l = 0, k = 1; l < SVTME_MAX_LISTS; ++l)
+        for (int r = 0; r < pic->n_ref[l]; ++r, ++k) {
+            if (pl.plane[k].width != p.cur.width || pl.plane[k].height != p.cur.height) return SVTME_ERR_BAD_ARG;
+            p.ref[l][r] = pl.plane[k];
+        }
+    p.n_ref[0] = pic->n_ref[0];
+    p.n_ref[1] = pic->n_ref[1];
+    p.width  = (int)pic->width;
+    p.height = (int)pic->height;
+    p.b64_w  = b64_w;
+    p.n_b64  = n_b64;
+    p.disable_intra_pred = pic->disable_intra_pred;
+    p.pf_shape     = all_modes ? 0 : pic->pf_shape; // DEFAULT_SHAPE without tpl_opt_flag (:1131-1133)
+    p.rate         = all_modes; // rate_estimator, else 0 (:1141)
+    p.subsample_tx = pic->subsample_tx;
+    p.dc_path      = pic->tpl_opt_flag && pic->use_pred_sad_in_intra_search; // intra_dc_sad_path :594-595
+    for (int k = 0; k < 2; ++k) {
+        p.round_fp[k] = pic->y_round_fp[k];
+        p.quant_fp[k] = pic->y_quant_fp[k];
+        p.dequant[k]  = pic->y_dequant[k];
+    }
+    for (int k = 0; k < 32; ++k) {
+        p.cos13[k] = (int32_t)lround(cos(2 * k * 3.14159265358979323846 / 128.0) * 8192.0);
+        p.cos12[k] = (int32_t)lround(cos(2 * k * 3.14159265358979323846 / 128.0) * 4096.0);
+    }
+    p.out          = reinterpret_cast<svtme_tpl_block *>(g.d_rec);
+    p.stats        = reinterpret_cast<svtme_tpl_stats *>(g.d_rec + stat_off);
+    p.recon        = g.d_rec + rec_off;
+    p.recon_stride = (int32_t)rec_stride;
+    memcpy(g.h_rec, blocks, blk_bytes);
+    memcpy(g.h_rec + par_off, &p, sizeof(p));
+    const hipStream_t st = e->s_me[3];
+    for (int k = 0; k < n_keys; ++k) GM_TRY(hipStreamWaitEvent(st, pl.ready[k], 0));
+    GM_TRY(hipMemcpyAsync(g.d_rec, g.h_rec, blk_bytes, hipMemcpyHostToDevice, st));
+    GM_TRY(hipMemcpyAsync(g.d_rec + par_off, g.h_rec + par_off, sizeof(p), hipMemcpyHostToDevice, st));
+    GM_TRY(hipMemsetAsync(g.d_rec + stat_off, 0, stat_bytes, st));
+    launch_tpl_recon(reinterpret_cast<const TplParams *>(g.d_rec + par_off), p.width, p.height, st);
+    GM_TRY(hipGetLastError());
+    GM_TRY(hipMemcpyAsync(g.h_rec + stat_off, g.d_rec + stat_off, stat_bytes, hipMemcpyDeviceToHost, st));
+    if (recon) GM_TRY(hipMemcpyAsync(g.h_rec + rec_off, g.d_rec + rec_off, rec_stride * pic->height, hipMemcpyDeviceToHost, st));
+    GM_TRY(hipStreamSynchronize(st));
+    memcpy(stats, g.h_rec + stat_off, stat_bytes);
+    if (recon)
+        for (uint32_t y = 0; y < pic->height; ++y) memcpy(recon + (size_t)y * recon_stride, g.h_rec + rec_off + (size_t)y * rec_stride, pic->width);
     return SVTME_OK;
 }
 

@@ -229,10 +229,16 @@ struct TplParams {
     const uint32_t *mv; // [n_b64][n_pu * max_refs]
     svtme_tpl_block *out; // [n_b64][SVTME_TPL_BLOCKS], zeroed
     int             *error; // bit 0: a candidate named a reference beyond n_ref
+    // svtme_tpl_recon: `out` holds the caller's block records; the reconstructed picture and the statistics
+    uint8_t         *recon;
+    int32_t          recon_stride, dc_path; // dc_path: intra blocks are predicted from the DC of their neighbours (intra_dc_sad_path)
+    svtme_tpl_stats *stats; // [n_b64][SVTME_TPL_BLOCKS], zeroed
 };
 // dev: the record in device memory; transform_costs: it asks for costs in the transform domain (every intra mode, or
 // sad_intra / sad_inter not set): the kernel that takes them four at a time
 void launch_tpl_search(const TplParams *dev, int n_b64, bool transform_costs, hipStream_t s);
+// the reconstruction path of a picture of width x height: the inter blocks in one launch, the intra blocks diagonal by diagonal
+void launch_tpl_recon(const TplParams *dev, int width, int height, hipStream_t s);
 
 int  occupancy_me_search();
 void occupancy_hme_items(int out[2]);

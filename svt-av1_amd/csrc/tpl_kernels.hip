@@ -7,6 +7,7 @@
 // 64x64 block 16. A 16x16 transform takes 16 lanes - a lane per column, then a lane per row, through LDS - so the costs of
 // up to four predictions of a block (four intra modes, four candidates, or three candidates and the intra mode the rounds of
 // four left over) are taken together, one in each quarter of the wave.
+#include <algorithm>
 #include "search_common.h"
 
 namespace svtme {
@@ -703,11 +704,292 @@ __global__ void __launch_bounds__(64, 4) tpl_search_kernel(const TplParams *pp) 
     }
 }
 
+
+// ---- the reconstruction path (:1004-1197) of a 16x16 block: prediction, residual, forward transform, quantisation, inverse
+// transform into the reconstructed picture, statistics.
+//
+// The inverse DCT of svt_av1_inv_txfm2d_add_16xH_c (inv_txfm2d_add_c, EbInvTransforms.c:2455-2533): every row of coefficients
+// (x 1/sqrt(2) for 16x8), clamped to 16 bits, through the 16-point network, rounded >> 2 (16x16) or >> 1; every column, clamped
+// to 16 bits, through the H-point network, rounded >> 4, added to the prediction, clipped. The networks are
+// svt_av1_idct4_new .. svt_av1_idct16_new (:75-355) with 12-bit cosines and every sum / difference clamped to 16 bits (the
+// stage range at 8 bits, :23-65), written as the N/2-point network of the even inputs plus the odd half. Inputs are clamped
+// to 16 bits and cosines are below 2^13, so the 24-bit multiplications of rot<> are exact.
+#define TPL_C(k) c[(k) >> 1]
+__device__ __forceinline__ int32_t clamp16(int32_t v) { return min(max(v, -32768), 32767); }
+
+__device__ __forceinline__ void idct_n(const int32_t (&x)[4], int32_t (&X)[4], CosTable c) {
+    const int32_t a0 = rot<12>(x[0], TPL_C(32), x[2], TPL_C(32)), a1 = rot<12>(x[0], TPL_C(32), x[2], -TPL_C(32));
+    const int32_t a2 = rot<12>(x[1], TPL_C(48), x[3], -TPL_C(16)), a3 = rot<12>(x[1], TPL_C(16), x[3], TPL_C(48));
+    X[0] = clamp16(a0 + a3), X[1] = clamp16(a1 + a2), X[2] = clamp16(a1 - a2), X[3] = clamp16(a0 - a3);
+}
+
+__device__ __forceinline__ void idct_n(const int32_t (&x)[8], int32_t (&X)[8], CosTable c) {
+    const int32_t ev[4] = {x[0], x[2], x[4], x[6]};
+    int32_t       E[4];
+    idct_n(ev, E, c);
+    const int32_t b4 = rot<12>(x[1], TPL_C(56), x[7], -TPL_C(8)), b5 = rot<12>(x[5], TPL_C(24), x[3], -TPL_C(40));
+    const int32_t b6 = rot<12>(x[5], TPL_C(40), x[3], TPL_C(24)), b7 = rot<12>(x[1], TPL_C(8), x[7], TPL_C(56));
+    const int32_t c4 = clamp16(b4 + b5), c5 = clamp16(b4 - b5), c6 = clamp16(-b6 + b7), c7 = clamp16(b6 + b7);
+    const int32_t d[4] = {c4, rot<12>(c5, -TPL_C(32), c6, TPL_C(32)), rot<12>(c5, TPL_C(32), c6, TPL_C(32)), c7};
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        X[i]     = clamp16(E[i] + d[3 - i]);
+        X[7 - i] = clamp16(E[i] - d[3 - i]);
+    }
+}
+
+__device__ __forceinline__ void idct_n(const int32_t (&x)[16], int32_t (&X)[16], CosTable c) {
+    int32_t ev[8], E[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) ev[i] = x[2 * i];
+    idct_n(ev, E, c);
+    const int32_t b8 = rot<12>(x[1], TPL_C(60), x[15], -TPL_C(4)), b9 = rot<12>(x[9], TPL_C(28), x[7], -TPL_C(36));
+    const int32_t b10 = rot<12>(x[5], TPL_C(44), x[11], -TPL_C(20)), b11 = rot<12>(x[13], TPL_C(12), x[3], -TPL_C(52));
+    const int32_t b12 = rot<12>(x[13], TPL_C(52), x[3], TPL_C(12)), b13 = rot<12>(x[5], TPL_C(20), x[11], TPL_C(44));
+    const int32_t b14 = rot<12>(x[9], TPL_C(36), x[7], TPL_C(28)), b15 = rot<12>(x[1], TPL_C(4), x[15], TPL_C(60));
+    const int32_t c8 = clamp16(b8 + b9), c9 = clamp16(b8 - b9), c10 = clamp16(-b10 + b11), c11 = clamp16(b10 + b11);
+    const int32_t c12 = clamp16(b12 + b13), c13 = clamp16(b12 - b13), c14 = clamp16(-b14 + b15), c15 = clamp16(b14 + b15);
+    const int32_t d9 = rot<12>(c9, -TPL_C(16), c14, TPL_C(48)), d10 = rot<12>(c10, -TPL_C(48), c13, -TPL_C(16));
+    const int32_t d13 = rot<12>(c10, -TPL_C(16), c13, TPL_C(48)), d14 = rot<12>(c9, TPL_C(48), c14, TPL_C(16));
+    const int32_t e8 = clamp16(c8 + c11), e9 = clamp16(d9 + d10), e10 = clamp16(d9 - d10), e11 = clamp16(c8 - c11);
+    const int32_t e12 = clamp16(-c12 + c15), e13 = clamp16(-d13 + d14), e14 = clamp16(d13 + d14), e15 = clamp16(c12 + c15);
+    const int32_t f[8] = {e8, e9, rot<12>(e10, -TPL_C(32), e13, TPL_C(32)), rot<12>(e11, -TPL_C(32), e12, TPL_C(32)),
+                          rot<12>(e11, TPL_C(32), e12, TPL_C(32)), rot<12>(e10, TPL_C(32), e13, TPL_C(32)), e14, e15};
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        X[i]      = clamp16(E[i] + f[7 - i]);
+        X[15 - i] = clamp16(E[i] - f[7 - i]);
+    }
+}
+
+#undef TPL_C
+
+// The transforms of a 16x16 block whose lanes hold its source and predicted pixels (lane = row lane / 4, columns 4 (lane % 4)
+// ..): the 16 x H forward DCT of every (16 / H)-th row's residual and its quantisation as in tpl_transform; then, when
+// `inverse` and a level is left, the inverse DCT of the dequantised coefficients added to the prediction of those rows, the
+// rows between taking the row above them (:1145-1176). Returns the lane's four reconstructed pixels; recon_error and rate in
+// every lane.
+template <int H>
+__device__ __forceinline__ uint32_t tpl_recon_transform(ConstTplParams &p, uint32_t src, uint32_t prd, int32_t *lds, bool inverse, bool want_rate,
+                                                        long long &recon_error, long long &rate) {
+    constexpr int PITCH = 17, STEP = 16 / H, SHIFT1 = H == 4 ? 1 : 2, BIT_ROW = H == 16 ? 12 : 13, SHIFT_INV = H == 16 ? 2 : 1;
+    const int     lane = threadIdx.x & 63, r = lane >> 2, d = lane & 3;
+    wave_sync();
+    if (r % STEP == 0) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) lds[(r / STEP) * PITCH + 4 * d + j] = (int32_t)((src >> (8 * j)) & 0xff) - (int32_t)((prd >> (8 * j)) & 0xff);
+    }
+    wave_sync();
+    {
+        int32_t in[H], out[H];
+        if (lane < 16) {
+#pragma unroll
+            for (int i = 0; i < H; ++i) in[i] = lds[i * PITCH + lane] * 4;
+            fdct_n<13>(in, out, p.cos13);
+        }
+        wave_sync();
+        if (lane < 16) {
+#pragma unroll
+            for (int i = 0; i < H; ++i) lds[i * PITCH + lane] = (out[i] + (1 << (SHIFT1 - 1))) >> SHIFT1;
+        }
+    }
+    wave_sync();
+    long long e_sum = 0;
+    int       eob = 0, logs = 0, any = 0;
+    const int kw = 16 >> p.pf_shape, kh = H >> p.pf_shape;
+    if (lane < H) {
+        int32_t in[16], out[16];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) in[i] = lds[lane * PITCH + i];
+        if (lane < kh) fdct_n<BIT_ROW>(in, out, BIT_ROW == 12 ? p.cos12 : p.cos13);
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            int32_t v = (lane < kh && i < kw) ? out[i] : 0;
+            if (H == 8) v = (int32_t)(((long long)v * 5793 + 2048) >> 12); // NewSqrt2, 12 fractional bits
+            const int32_t a  = v < 0 ? -v : v;
+            const int     ac = (lane | i) != 0;
+            int32_t       dq = 0;
+            if ((a << 1) >= p.dequant[ac]) {
+                const int32_t t     = min(a + p.round_fp[ac], 32767);
+                const int32_t level = (int32_t)(((long long)t * p.quant_fp[ac]) >> 16);
+                dq                  = level * p.dequant[ac];
+                if (level) {
+                    any = 1;
+                    if (H == 16 && want_rate) {
+                        eob = max(eob, tpl_scan_pos16(lane, i) + 1);
+                        logs += 31 - __clz(level + 1);
+                    }
+                }
+            }
+            const long long diff = (long long)a - dq;
+            e_sum += diff * diff;
+            lds[lane * PITCH + i] = v < 0 ? -dq : dq; // dqcoeff
+        }
+    }
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) {
+        e_sum += __shfl_xor(e_sum, m);
+        any |= __shfl_xor(any, m);
+        eob = max(eob, __shfl_xor(eob, m));
+        logs += __shfl_xor(logs, m);
+    }
+    e_sum >>= 2;
+    recon_error = e_sum < 1 ? 1 : e_sum;
+    rate        = want_rate ? (long long)(eob + 1 + logs) << 9 : 0;
+    if (!inverse || !any) return prd;
+    wave_sync();
+    {
+        int32_t in[16], out[16];
+        if (lane < H) {
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                int32_t v = lds[lane * PITCH + i];
+                if (H == 8) v = (int32_t)(((long long)v * 2896 + 2048) >> 12); // new_inv_sqrt2, 12 fractional bits
+                in[i] = clamp16(v);
+            }
+            idct_n(in, out, p.cos12);
+#pragma unroll
+            for (int i = 0; i < 16; ++i) lds[lane * PITCH + i] = (out[i] + (1 << (SHIFT_INV - 1))) >> SHIFT_INV;
+        }
+    }
+    wave_sync();
+    {
+        int32_t in[H], out[H];
+        if (lane < 16) {
+#pragma unroll
+            for (int i = 0; i < H; ++i) in[i] = clamp16(lds[i * PITCH + lane]);
+            idct_n(in, out, p.cos12);
+        }
+        wave_sync();
+        if (lane < 16) {
+#pragma unroll
+            for (int i = 0; i < H; ++i) lds[i * PITCH + lane] = (out[i] + 8) >> 4;
+        }
+    }
+    wave_sync();
+    // the transformed row of this lane's row: itself, or the one above it that was
+    const int      rt = r - r % STEP;
+    const uint32_t pt = (uint32_t)__shfl((int)prd, rt * 4 + d);
+    uint32_t       o  = 0;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int v = (int)((pt >> (8 * j)) & 0xff) + lds[(rt / STEP) * PITCH + 4 * d + j];
+        o |= (uint32_t)min(max(v, 0), 255) << (8 * j);
+    }
+    return o;
+}
+
+// One block of the reconstruction path, whole wave; `b` is the search's record of the block.
+__device__ __forceinline__ void tpl_recon_block(ConstTplParams &p, int b64, int bi, int x, int y, const svtme_tpl_block &b, int32_t *lds, uint8_t *edges) {
+    const int      lane = threadIdx.x & 63, r = lane >> 2, d = lane & 3;
+    const DevPlane cur = load_plane(p.cur);
+    DevPlane       rec = cur; // the reconstructed picture: the picture's size, no border
+    rec.pix            = p.recon;
+    rec.stride         = p.recon_stride;
+    const uint32_t src = *reinterpret_cast<const uint32_t *>(cur.pix + (ptrdiff_t)(y + r) * cur.stride + x + 4 * d);
+    uint32_t       prd;
+    if (b.best_is_inter) { // :1005-1030
+        const DevPlane rp = load_plane(p.ref[b.best_rf_idx >> 2][b.best_rf_idx & 3]);
+        __builtin_memcpy(&prd, rp.pix + (ptrdiff_t)(y + (b.mv_y >> 3) + r) * rp.stride + x + (b.mv_x >> 3) + 4 * d, 4);
+    } else if (p.dc_path || b.best_intra_mode == 0) { // :1044-1078; DC_PRED of :1080-1119 sees the same neighbours
+        uint32_t sum = 0;
+        if (lane < 16) {
+            if (y > 0) sum += x + lane < p.width ? rec.pix[(ptrdiff_t)(y - 1) * rec.stride + x + lane] : 127u;
+            if (x > 0) sum += y + lane < p.height ? rec.pix[(ptrdiff_t)(y + lane) * rec.stride + x - 1] : 129u;
+        }
+        sum              = wave_sum(sum);
+        const uint32_t n = (y > 0 ? 16 : 0) + (x > 0 ? 16 : 0);
+        prd              = (n ? (sum + (n >> 1)) / n : 128u) * 0x01010101u;
+    } else { // :1080-1119
+        uint8_t  *a0 = edges, *l0 = edges + kEdge, *a1 = edges + 2 * kEdge, *l1 = edges + 3 * kEdge;
+        const int mode = b.best_intra_mode;
+        wave_sync();
+        tpl_collect_edges(p, rec, x, y, a0, l0);
+        wave_sync();
+        if (mode >= 3 && mode <= 8) {
+            const int angle = mode == 3 ? 45 : (mode == 4 ? 135 : (mode == 5 ? 113 : (mode == 6 ? 157 : (mode == 7 ? 203 : 67))));
+            tpl_filter_edges(angle, x, y, a0, l0, a1, l1);
+            wave_sync();
+            prd = tpl_intra_dword(mode, a1 + 4, l1 + 4);
+        } else
+            prd = tpl_intra_dword(mode, a0 + 4, l0 + 4);
+    }
+    long long      recon_error, rate;
+    const bool     inverse = !p.disable_intra_pred, want_rate = p.rate != 0;
+    uint32_t       out;
+    if (p.subsample_tx == 0) out = tpl_recon_transform<16>(p, src, prd, lds, inverse, want_rate, recon_error, rate);
+    else if (p.subsample_tx == 1) out = tpl_recon_transform<8>(p, src, prd, lds, inverse, false, recon_error, rate);
+    else out = tpl_recon_transform<4>(p, src, prd, lds, inverse, false, recon_error, rate);
+    if (y + r < p.height) {
+        uint8_t *dst = p.recon + (ptrdiff_t)(y + r) * p.recon_stride + x + 4 * d;
+        if (x + 4 * d + 4 <= p.width) *reinterpret_cast<uint32_t *>(dst) = out;
+        else
+            for (int j = 0; j < 4 && x + 4 * d + j < p.width; ++j) dst[j] = (uint8_t)(out >> (8 * j));
+    }
+    if (lane == 0) { // :1179-1197, result_model_store :214-222
+        const int       sub = p.subsample_tx;
+        svtme_tpl_stats o;
+        o.recrf_dist = (recon_error << 4) << sub;
+        o.recrf_rate = (rate << 4) << sub;
+        if (b.best_is_inter) {
+            o.srcrf_dist = (b.src_recon_error << 4) << sub;
+            o.srcrf_rate = (b.src_rate << 4) << sub;
+        } else {
+            o.srcrf_dist = o.recrf_dist;
+            o.srcrf_rate = o.recrf_rate;
+        }
+        o.recrf_dist = max(o.recrf_dist, o.srcrf_dist);
+        o.recrf_rate = max(o.recrf_rate, o.srcrf_rate);
+        o.srcrf_dist = max(o.srcrf_dist / 16, 1ll);
+        o.recrf_dist = max(o.recrf_dist / 16, 1ll);
+        o.srcrf_rate = max(o.srcrf_rate / 16, 1ll);
+        o.recrf_rate = max(o.recrf_rate / 16, 1ll);
+        p.stats[(size_t)b64 * SVTME_TPL_BLOCKS + bi] = o;
+    }
+}
+
+// INTRA false: grid (16, n_b64) as the search, the blocks predicted from reference pictures, which depend on nothing.
+// INTRA true: the blocks predicted from their reconstructed neighbours - the blocks left of, above and above-left of them,
+// and for the picture's first column the block above-right (update_neighbor_samples_array_open_loop_mb_recon replaces the
+// upper-right and lower-left extensions by repeats everywhere else) -, which all lie on earlier anti-diagonals
+// bx + 2 by of the picture's 16x16 grid: grid (blocks of the diagonal `diag`), block row by0 + blockIdx.x.
+template <bool INTRA>
+__global__ void __launch_bounds__(64) tpl_recon_kernel(const TplParams *pp, int diag, int by0) {
+    __shared__ int32_t lds[16 * 17];
+    __shared__ __align__(4) uint8_t edges[4 * kEdge];
+    ConstTplParams    &p = *(ConstTplParams *)pp;
+    int bx, by;
+    if (INTRA) {
+        by = by0 + (int)blockIdx.x;
+        bx = diag - 2 * by;
+    } else {
+        const int b64 = blockIdx.y, slot = blockIdx.x, q = slot >> 2, s = slot & 3;
+        bx = (b64 % p.b64_w) * 4 + (q & 1) * 2 + (s & 1);
+        by = (b64 / p.b64_w) * 4 + (q >> 1) * 2 + (s >> 1);
+    }
+    const int x = bx * 16, y = by * 16;
+    if (bx < 0 || x + 8 > p.width || y + 8 > p.height) return; // at least half of the block inside (:604-607)
+    const int b64 = (by >> 2) * p.b64_w + (bx >> 2);
+    const int bi  = 5 + (((by >> 1) & 1) * 2 + ((bx >> 1) & 1)) * 4 + (by & 1) * 2 + (bx & 1); // z-order inside the 64x64 block
+    const svtme_tpl_block b = p.out[(size_t)b64 * SVTME_TPL_BLOCKS + bi];
+    if (!b.valid || (b.best_is_inter != 0) == INTRA) return;
+    tpl_recon_block(p, b64, bi, x, y, b, lds, edges);
+}
+
 } // namespace
 
 void launch_tpl_search(const TplParams *dev, int n_b64, bool transform_costs, hipStream_t s) {
     if (transform_costs) hipLaunchKernelGGL(tpl_search_kernel<4>, dim3(16, n_b64), dim3(64), 0, s, dev);
     else hipLaunchKernelGGL(tpl_search_kernel<1>, dim3(16, n_b64), dim3(64), 0, s, dev);
+}
+
+void launch_tpl_recon(const TplParams *dev, int width, int height, hipStream_t s) {
+    const int bw = (width + 15) / 16, bh = (height + 15) / 16, n_b64 = ((width + 63) / 64) * ((height + 63) / 64);
+    hipLaunchKernelGGL(tpl_recon_kernel<false>, dim3(16, n_b64), dim3(64), 0, s, dev, 0, 0);
+    for (int d = 0; d <= (bw - 1) + 2 * (bh - 1); ++d) {
+        const int by0 = std::max(0, (d - (bw - 1) + 1) / 2), by1 = std::min(bh - 1, d / 2);
+        if (by1 >= by0) hipLaunchKernelGGL(tpl_recon_kernel<true>, dim3(by1 - by0 + 1), dim3(64), 0, s, dev, d, by0);
+    }
 }
 
 } // namespace svtme

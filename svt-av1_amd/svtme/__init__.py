@@ -122,7 +122,7 @@ EXPORTS = ("svtme_version", "svtme_derive_controls", "svtme_derive_tf_controls",
            "svtme_group_engine_for", "svtme_group_gm_set_tables",
            "svtme_gm_set_tables", "svtme_gm_corners", "svtme_gm_correspondences", "svtme_gm_warp_error", "svtme_gm_frame_error",
            "svtme_gm_refine",
-           "svtme_tpl_search", "svtme_set_tile_rects", "svtme_group_set_tile_rects",
+           "svtme_tpl_search", "svtme_tpl_recon", "svtme_set_tile_rects", "svtme_group_set_tile_rects",
            "svtme_store_put_many", "svtme_store_copy_peer", "svtme_group_pictures_submit", "svtme_group_ticket_engine",
            "svtme_group_set_peer_copies", "svtme_group_peer_stats")
 MAX_BATCH = 32
@@ -134,6 +134,9 @@ TPL_BLOCKS = 21
 TPL_BLOCK = np.dtype([("best_intra_cost", "<i8"), ("best_inter_cost", "<i8"), ("mv_x", "<i2"), ("mv_y", "<i2"),
                       ("best_rf_idx", "i1"), ("best_is_inter", "u1"), ("best_intra_mode", "u1"), ("valid", "u1"),
                       ("src_recon_error", "<i8"), ("src_rate", "<i8")])
+
+
+TPL_STATS = np.dtype([("srcrf_dist", "<i8"), ("recrf_dist", "<i8"), ("srcrf_rate", "<i8"), ("recrf_rate", "<i8")])  # svtme_tpl_stats
 
 
 class TplPicture(C.Structure):
@@ -232,6 +235,7 @@ def load_library():
     lib.svtme_gm_refine.argtypes = [C.c_void_p, C.c_uint64, C.c_uint64, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int64, C.POINTER(C.c_int64),
                                     C.POINTER(C.c_uint32)]
     lib.svtme_tpl_search.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+    lib.svtme_tpl_recon.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32]
     lib.svtme_set_tile_rects.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p, C.c_uint32]
     lib.svtme_group_set_tile_rects.argtypes = lib.svtme_set_tile_rects.argtypes
     _lib = lib
@@ -692,6 +696,18 @@ class Engine:
         if rc:
             raise SvtmeError(rc, "svtme_tpl_search")
         return out
+
+    def tpl_recon(self, pic, blocks, want_picture=True):
+        """svtme_tpl_recon: pic as for tpl_search, blocks what tpl_search returned (TPL_BLOCK records [n_b64, 21]). Returns
+        (TPL_STATS records [n_b64, 21], the reconstructed picture uint8 [height, width] or None)."""
+        blocks = np.ascontiguousarray(blocks, TPL_BLOCK)
+        stats = np.zeros(blocks.shape, TPL_STATS)
+        recon = np.zeros((pic.height, pic.width), np.uint8) if want_picture else None
+        rc = self.lib.svtme_tpl_recon(self.h, C.addressof(pic), blocks.ctypes.data, stats.ctypes.data,
+                                      recon.ctypes.data if want_picture else None, pic.width)
+        if rc:
+            raise SvtmeError(rc, "svtme_tpl_recon")
+        return stats, recon
 
     def timing(self, ticket):
         ms = (C.c_float * 8)()

@@ -46,6 +46,97 @@ def test_engine_reproduces_reference_tpl_search(name):
         eng.close()
 
 
+STAT_FIELDS = ("srcrf_dist", "recrf_dist", "srcrf_rate", "recrf_rate")
+
+
+@pytest.mark.parametrize("name", sorted(n for n in tpl_cases.CASES if not n.startswith("tpl7")))
+def test_engine_reproduces_reference_tpl_reconstruction(name):
+    """svtme_tpl_recon on the engine's own search results: the reconstructed picture's hash and every block's statistics as
+    the real reference's dispenser left them (16x16 blocks: 16x16 and 16x8 transforms, DC and all thirteen intra modes)."""
+    frames, pics, per = load_case(name, tpl_cases.CASES[name])
+    g = np.load(os.path.join(GOLDEN, name + ".npz"))
+    eng = _engine(frames)
+    try:
+        for i, (pic, (ctrl, me, tb, quant)) in enumerate(zip(pics, per)):
+            p, keep, refs = picture_of(frames, pic, ctrl, me, quant=quant)
+            blocks = eng.tpl_search(p)
+            stats, recon = eng.tpl_recon(p, blocks)
+            v = tb["valid"] == 1
+            for f in STAT_FIELDS:
+                bad = np.argwhere(v & (stats[f] != tb[f]))
+                assert not len(bad), "%s poc %d: %s differs at (b64, block) %s: %d != %d (%d places)" % (
+                    name, pic.poc, f, tuple(bad[0]), stats[f][tuple(bad[0])], tb[f][tuple(bad[0])], len(bad))
+                assert not stats[f][~v].any()
+            assert tplio.recon_hash(recon) == int(g["pic%d_tpl" % i]["recon_hash"]), (name, pic.poc)
+            stats2, none = eng.tpl_recon(p, blocks, want_picture=False)  # the same without the picture
+            assert none is None and np.array_equal(stats2, stats)
+    finally:
+        eng.close()
+
+
+@pytest.mark.parametrize("seed", range(int(os.environ.get("SVTME_FUZZ_N", "12"))))
+def test_random_reconstructions_match_the_restatement(seed):
+    """Random sizes, contents, quantisers and ME results; every subsample_tx / pf_shape; with and without tpl_opt_flag; pictures
+    of intra blocks only (i_slice) and with intra prediction disabled: statistics and the reconstructed picture byte for byte."""
+    rng = np.random.default_rng(4000 + seed)
+    w, h = int(rng.integers(8, 50)) * 8, int(rng.integers(8, 36)) * 8
+    n_ref = (int(rng.integers(1, 5)), int(rng.integers(0, 4)))
+    kind = ["synth", "noise", "flat"][int(rng.integers(0, 3))]
+    frames = support.make_job(w, h, 1 + n_ref[0] + n_ref[1], 8, seed=seed + 11, kind=kind)[0]
+    n_b64 = ((w + 63) // 64) * ((h + 63) // 64)
+    me = _random_me(rng, n_b64, [85, 21][int(rng.integers(0, 2))], n_ref, int(rng.choice([8, 64, 400])))
+    all_modes = seed % 3 == 0
+    ctrl = dict(dispenser_search_level=0, disable_intra_pred=int(rng.integers(0, 4) == 0), tpl_opt_flag=0 if all_modes else 1,
+                use_pred_sad_in_intra_search=int(rng.integers(0, 2)), use_pred_sad_in_inter_search=int(rng.integers(0, 2)),
+                subsample_tx=0, pf_shape=int(rng.integers(0, 3)))
+    if not all_modes and ctrl["use_pred_sad_in_intra_search"] and ctrl["use_pred_sad_in_inter_search"]:
+        ctrl["subsample_tx"] = int(rng.integers(0, 3))
+    dq = [int(rng.integers(4, 1400)), int(rng.integers(4, 1900))]
+    quant = ([int(rng.integers(0, 1 + d)) for d in dq], [min(32767, int(rng.integers(1, 3)) * 32768 // d) for d in dq], dq)
+    import svtme
+    eng = svtme.Engine(w, h, store_slots=len(frames) + 1, max_in_flight=2)
+    try:
+        for i in range(len(frames)):
+            eng.store_put(i + 1, i, frames[i])
+        refs = {(l, r): frames[1 + (l * n_ref[0]) + r] for l in range(2) for r in range(n_ref[l])}
+        keys = ([2 + r for r in range(n_ref[0])], [2 + n_ref[0] + r for r in range(n_ref[1])])
+        p, keep = tplio.make_picture(w, h, ctrl, me, cur_key=1, ref_keys=keys, quant=quant, i_slice=int(seed % 5 == 4))
+        blocks = eng.tpl_search(p)
+        want_blocks = tplio.oracle_search(frames[0], refs, p)
+        assert_blocks_equal(blocks, want_blocks, "seed %d search" % seed)
+        stats, recon = eng.tpl_recon(p, blocks)
+        want_recon, want_stats = tplio.oracle_recon(frames[0], refs, p, blocks)
+        for f in STAT_FIELDS:
+            assert np.array_equal(stats[f], want_stats[f]), (seed, ctrl, f, np.argwhere(stats[f] != want_stats[f])[:4])
+        assert np.array_equal(recon, want_recon), (seed, ctrl, np.argwhere(recon != want_recon)[:4])
+    finally:
+        eng.close()
+
+
+def test_reconstruction_refuses_what_it_does_not_do():
+    import svtme
+    frames, pics, per = load_case("tpl4_m8_200x136", tpl_cases.CASES["tpl4_m8_200x136"])
+    eng = _engine(frames)
+    try:
+        ctrl, me, tb, quant = per[1]
+        p, keep, refs = picture_of(frames, pics[1], ctrl, me, quant=quant)
+        blocks = eng.tpl_search(p)
+        for change in (dict(dispenser_search_level=1), dict(dispenser_search_level=2), dict(pf_shape=3), dict(subsample_tx=3),
+                       dict(tpl_opt_flag=0, subsample_tx=1)):
+            q, keep2, _ = picture_of(frames, pics[1], dict(ctrl, **change), me, quant=quant)
+            with pytest.raises(svtme.SvtmeError) as ei:
+                eng.tpl_recon(q, blocks)
+            assert ei.value.code == svtme.ERR_UNSUPPORTED, change
+        bad = blocks.copy()
+        inter = np.argwhere((bad["valid"] == 1) & (bad["best_is_inter"] == 1))[0]
+        bad["best_rf_idx"][tuple(inter)] = 7  # a reference the picture does not have
+        with pytest.raises(svtme.SvtmeError) as ei:
+            eng.tpl_recon(p, bad)
+        assert ei.value.code == svtme.ERR_BAD_ARG
+    finally:
+        eng.close()
+
+
 def _random_me(rng, n_b64, n_pu, n_ref, max_mv):
     """ME results no encoder would produce but the interface allows: any count, any mix of directions and references,
     vectors far outside the picture."""
