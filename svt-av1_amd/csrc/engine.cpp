@@ -1775,8 +1775,34 @@ extern "C" int svtme_tpl_recon(svtme_engine *e, const svtme_tpl_picture *pic, co
     GmState  &g = e->gm;
     const size_t blk_bytes = n_blk * sizeof(svtme_tpl_block), stat_bytes = n_blk * sizeof(svtme_tpl_stats);
     const size_t stat_off = (blk_bytes + 63) / 64 * 64, par_off = (stat_off + stat_bytes + 63) / 64 * 64;
-    const size_t rec_stride = ((size_t)pic->width + 63) / 64 * 64, rec_off = par_off + (sizeof(TplParams) + 63) / 64 * 64;
-    const size_t total = rec_off + rec_stride * pic->height;
+    // The intra blocks in levels: a block reads the reconstruction of the blocks left of, above and above-left of it, and on the
+    // picture's first column of the one above-right (EbEncIntraPrediction.c:1237-1319); those predicted from reference pictures
+    // are all done first, so a block's level is one more than the highest level among its intra neighbours.
+    const int bw16 = (int)(pic->width + 15) / 16, bh16 = (int)(pic->height + 15) / 16;
+    std::vector<int> level((size_t)bw16 * bh16, -1), level_count;
+    for (int by = 0; by < bh16; ++by)
+        for (int bx = 0; bx < bw16; ++bx) {
+            if (bx * 16 + 8 > (int)pic->width || by * 16 + 8 > (int)pic->height) continue;
+            const int b64 = (by >> 2) * b64_w + (bx >> 2), bi = 5 + (((by >> 1) & 1) * 2 + ((bx >> 1) & 1)) * 4 + (by & 1) * 2 + (bx & 1);
+            const svtme_tpl_block &b = blocks[(size_t)b64 * SVTME_TPL_BLOCKS + bi];
+            if (!b.valid || b.best_is_inter) continue;
+            auto at = [&](int x, int y) { return x >= 0 && y >= 0 && x < bw16 ? level[(size_t)y * bw16 + x] : -1; };
+            const int l = 1 + std::max(std::max(at(bx - 1, by), at(bx, by - 1)), std::max(at(bx - 1, by - 1), bx == 0 ? at(1, by - 1) : -1));
+            level[(size_t)by * bw16 + bx] = l;
+            if ((int)level_count.size() <= l) level_count.resize(l + 1, 0);
+            ++level_count[l];
+        }
+    std::vector<uint32_t> order;
+    {
+        std::vector<int> next(level_count.size() + 1, 0);
+        for (size_t l = 0; l < level_count.size(); ++l) next[l + 1] = next[l] + level_count[l];
+        order.resize(next.back());
+        for (int by = 0; by < bh16; ++by)
+            for (int bx = 0; bx < bw16; ++bx)
+                if (level[(size_t)by * bw16 + bx] >= 0) order[next[level[(size_t)by * bw16 + bx]]++] = (uint32_t)bx | ((uint32_t)by << 16);
+    }
+    const size_t rec_stride = ((size_t)pic->width + 63) / 64 * 64, list_off = par_off + (sizeof(TplParams) + 63) / 64 * 64;
+    const size_t rec_off = (list_off + (size_t)bw16 * bh16 * 4 + 63) / 64 * 64, total = rec_off + rec_stride * pic->height;
     if (g.rec_bytes < total) {
         if (g.d_rec) (void)hipFree(g.d_rec);
         if (g.h_rec) (void)hipHostFree(g.h_rec);
@@ -1830,12 +1856,14 @@ extern "C" int svtme_tpl_recon(svtme_engine *e, const svtme_tpl_picture *pic, co
     p.recon_stride = (int32_t)rec_stride;
     memcpy(g.h_rec, blocks, blk_bytes);
     memcpy(g.h_rec + par_off, &p, sizeof(p));
+    if (!order.empty()) memcpy(g.h_rec + list_off, order.data(), order.size() * 4);
     const hipStream_t st = e->s_me[3];
     for (int k = 0; k < n_keys; ++k) GM_TRY(hipStreamWaitEvent(st, pl.ready[k], 0));
     GM_TRY(hipMemcpyAsync(g.d_rec, g.h_rec, blk_bytes, hipMemcpyHostToDevice, st));
-    GM_TRY(hipMemcpyAsync(g.d_rec + par_off, g.h_rec + par_off, sizeof(p), hipMemcpyHostToDevice, st));
+    GM_TRY(hipMemcpyAsync(g.d_rec + par_off, g.h_rec + par_off, list_off - par_off + order.size() * 4, hipMemcpyHostToDevice, st)); // record and list
     GM_TRY(hipMemsetAsync(g.d_rec + stat_off, 0, stat_bytes, st));
-    launch_tpl_recon(reinterpret_cast<const TplParams *>(g.d_rec + par_off), p.width, p.height, st);
+    launch_tpl_recon(reinterpret_cast<const TplParams *>(g.d_rec + par_off), n_b64, reinterpret_cast<const uint32_t *>(g.d_rec + list_off),
+                     level_count.data(), (int)level_count.size(), st);
     GM_TRY(hipGetLastError());
     GM_TRY(hipMemcpyAsync(g.h_rec + stat_off, g.d_rec + stat_off, stat_bytes, hipMemcpyDeviceToHost, st));
     if (recon) GM_TRY(hipMemcpyAsync(g.h_rec + rec_off, g.d_rec + rec_off, rec_stride * pic->height, hipMemcpyDeviceToHost, st));

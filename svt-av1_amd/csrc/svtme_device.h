@@ -237,8 +237,9 @@ struct TplParams {
 // dev: the record in device memory; transform_costs: it asks for costs in the transform domain (every intra mode, or
 // sad_intra / sad_inter not set): the kernel that takes them four at a time
 void launch_tpl_search(const TplParams *dev, int n_b64, bool transform_costs, hipStream_t s);
-// the reconstruction path of a picture of width x height: the inter blocks in one launch, the intra blocks diagonal by diagonal
-void launch_tpl_recon(const TplParams *dev, int width, int height, hipStream_t s);
+// the reconstruction path of a picture: the inter blocks in one launch, then the intra blocks level by level (list: the
+// blocks, bx | by << 16, sorted by level; level_count[l]: how many level l has)
+void launch_tpl_recon(const TplParams *dev, int n_b64, const uint32_t *list, const int *level_count, int n_levels, hipStream_t s);
 
 int  occupancy_me_search();
 void occupancy_hme_items(int out[2]);

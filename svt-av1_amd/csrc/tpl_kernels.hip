@@ -949,19 +949,20 @@ __device__ __forceinline__ void tpl_recon_block(ConstTplParams &p, int b64, int 
 }
 
 // INTRA false: grid (16, n_b64) as the search, the blocks predicted from reference pictures, which depend on nothing.
-// INTRA true: the blocks predicted from their reconstructed neighbours - the blocks left of, above and above-left of them,
-// and for the picture's first column the block above-right (update_neighbor_samples_array_open_loop_mb_recon replaces the
-// upper-right and lower-left extensions by repeats everywhere else) -, which all lie on earlier anti-diagonals
-// bx + 2 by of the picture's 16x16 grid: grid (blocks of the diagonal `diag`), block row by0 + blockIdx.x.
+// INTRA true: blocks predicted from their reconstructed neighbours - the blocks left of, above and above-left of them, and
+// for the picture's first column the block above-right (update_neighbor_samples_array_open_loop_mb_recon replaces the
+// upper-right and lower-left extensions by repeats everywhere else). The host has sorted them into levels, a block's level
+// one more than the highest of its intra neighbours'; a launch runs one level: blocks list[first + blockIdx.x] (bx | by << 16).
 template <bool INTRA>
-__global__ void __launch_bounds__(64) tpl_recon_kernel(const TplParams *pp, int diag, int by0) {
+__global__ void __launch_bounds__(64) tpl_recon_kernel(const TplParams *pp, const uint32_t *list, int first) {
     __shared__ int32_t lds[16 * 17];
     __shared__ __align__(4) uint8_t edges[4 * kEdge];
     ConstTplParams    &p = *(ConstTplParams *)pp;
     int bx, by;
     if (INTRA) {
-        by = by0 + (int)blockIdx.x;
-        bx = diag - 2 * by;
+        const uint32_t at = list[first + (int)blockIdx.x];
+        bx = (int)(at & 0xFFFFu);
+        by = (int)(at >> 16);
     } else {
         const int b64 = blockIdx.y, slot = blockIdx.x, q = slot >> 2, s = slot & 3;
         bx = (b64 % p.b64_w) * 4 + (q & 1) * 2 + (s & 1);
@@ -983,13 +984,10 @@ void launch_tpl_search(const TplParams *dev, int n_b64, bool transform_costs, hi
     else hipLaunchKernelGGL(tpl_search_kernel<1>, dim3(16, n_b64), dim3(64), 0, s, dev);
 }
 
-void launch_tpl_recon(const TplParams *dev, int width, int height, hipStream_t s) {
-    const int bw = (width + 15) / 16, bh = (height + 15) / 16, n_b64 = ((width + 63) / 64) * ((height + 63) / 64);
-    hipLaunchKernelGGL(tpl_recon_kernel<false>, dim3(16, n_b64), dim3(64), 0, s, dev, 0, 0);
-    for (int d = 0; d <= (bw - 1) + 2 * (bh - 1); ++d) {
-        const int by0 = std::max(0, (d - (bw - 1) + 1) / 2), by1 = std::min(bh - 1, d / 2);
-        if (by1 >= by0) hipLaunchKernelGGL(tpl_recon_kernel<true>, dim3(by1 - by0 + 1), dim3(64), 0, s, dev, d, by0);
-    }
+void launch_tpl_recon(const TplParams *dev, int n_b64, const uint32_t *list, const int *level_count, int n_levels, hipStream_t s) {
+    hipLaunchKernelGGL(tpl_recon_kernel<false>, dim3(16, n_b64), dim3(64), 0, s, dev, (const uint32_t *)nullptr, 0);
+    for (int l = 0, first = 0; l < n_levels; first += level_count[l++])
+        hipLaunchKernelGGL(tpl_recon_kernel<true>, dim3(level_count[l]), dim3(64), 0, s, dev, list, first);
 }
 
 } // namespace svtme

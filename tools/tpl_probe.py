@@ -68,6 +68,22 @@ def main():
             dt = (time.perf_counter() - t0) / (reps * len(js))
             print("svtme_tpl_search, 1080p, %d blocks, %s: %.3f ms per call (ME results in: %.2f MB, block records out: %.2f MB)"
                   % (8160, what, 1e3 * dt, 510 * 85 * (1 + shape["max_cand"] + 4 * shape["max_refs"]) / 1e6, 510 * 21 * 40 / 1e6))
+        # the reconstruction path on the engine's own search results (the reference's own, one host core: the dispenser's time
+        # with the search on the engine, above)
+        for what, js in (("tpl level 4 (DC from the reconstructed neighbours)", jobs), ("tpl level 1 (the chosen one of thirteen intra modes, rate)", jobs_all)):
+            found = [eng.tpl_search(p) for p, keep, refs in js]
+            n_intra = sum(int(((b["valid"] == 1) & (b["best_is_inter"] == 0)).sum()) for b in found)
+            for (p, keep, refs), b in zip(js, found):
+                eng.tpl_recon(p, b)
+            for want_picture in (True, False):
+                reps = 10
+                t0 = time.perf_counter()
+                for _ in range(reps):
+                    for (p, keep, refs), b in zip(js, found):
+                        eng.tpl_recon(p, b, want_picture=want_picture)
+                dt = (time.perf_counter() - t0) / (reps * len(js))
+                print("svtme_tpl_recon, 1080p, 8160 blocks (%.0f intra per picture), %s, %s: %.3f ms per call"
+                      % (n_intra / len(js), what, "statistics and the reconstructed picture back" if want_picture else "statistics back", 1e3 * dt))
     finally:
         eng.close()
 
