@@ -606,17 +606,70 @@ static void idct16(const int32_t *x, int32_t *X, const int32_t *c) {
     }
 }
 
+/* svt_av1_idct32_new (:356-706): the odd half takes inputs 1, 17, 9, 25, 5, 21, 13, 29, 3, 19, 11, 27, 7, 23, 15, 31 as nodes
+ * 16 .. 31 (arrays below are indexed node - 16) */
+static void idct32(const int32_t *x, int32_t *X, const int32_t *c) {
+    static const uint8_t in_of[16] = {1, 17, 9, 25, 5, 21, 13, 29, 3, 19, 11, 27, 7, 23, 15, 31};
+    static const uint8_t k2[8] = {62, 30, 46, 14, 54, 22, 38, 6}; /* stage 2: node 16 + i with node 31 - i */
+    int32_t ev[16], E[16], o[16], b[16], d[16], e[16], f[16], g[16], h[16];
+    for (int i = 0; i < 16; ++i) ev[i] = x[2 * i], o[i] = x[in_of[i]];
+    idct16(ev, E, c);
+    for (int i = 0; i < 8; ++i) {
+        b[i]      = rot(o[i], c[k2[i]], o[15 - i], -c[64 - k2[i]], 12);
+        b[15 - i] = rot(o[i], c[64 - k2[i]], o[15 - i], c[k2[i]], 12);
+    }
+    for (int i = 0; i < 16; i += 4) { /* stage 3 */
+        d[i] = clamp16(b[i] + b[i + 1]), d[i + 1] = clamp16(b[i] - b[i + 1]);
+        d[i + 2] = clamp16(-b[i + 2] + b[i + 3]), d[i + 3] = clamp16(b[i + 2] + b[i + 3]);
+    }
+    /* stage 4 */
+    b[0] = d[0], b[3] = d[3], b[4] = d[4], b[7] = d[7], b[8] = d[8], b[11] = d[11], b[12] = d[12], b[15] = d[15];
+    b[1]  = rot(d[1], -c[8], d[14], c[56], 12), b[14] = rot(d[1], c[56], d[14], c[8], 12);
+    b[2]  = rot(d[2], -c[56], d[13], -c[8], 12), b[13] = rot(d[2], -c[8], d[13], c[56], 12);
+    b[5]  = rot(d[5], -c[40], d[10], c[24], 12), b[10] = rot(d[5], c[24], d[10], c[40], 12);
+    b[6]  = rot(d[6], -c[24], d[9], -c[40], 12), b[9] = rot(d[6], -c[40], d[9], c[24], 12);
+    /* stage 5 */
+    e[0] = clamp16(b[0] + b[3]), e[1] = clamp16(b[1] + b[2]), e[2] = clamp16(b[1] - b[2]), e[3] = clamp16(b[0] - b[3]);
+    e[4] = clamp16(-b[4] + b[7]), e[5] = clamp16(-b[5] + b[6]), e[6] = clamp16(b[5] + b[6]), e[7] = clamp16(b[4] + b[7]);
+    e[8] = clamp16(b[8] + b[11]), e[9] = clamp16(b[9] + b[10]), e[10] = clamp16(b[9] - b[10]), e[11] = clamp16(b[8] - b[11]);
+    e[12] = clamp16(-b[12] + b[15]), e[13] = clamp16(-b[13] + b[14]), e[14] = clamp16(b[13] + b[14]), e[15] = clamp16(b[12] + b[15]);
+    /* stage 6 */
+    f[0] = e[0], f[1] = e[1], f[6] = e[6], f[7] = e[7], f[8] = e[8], f[9] = e[9], f[14] = e[14], f[15] = e[15];
+    f[2]  = rot(e[2], -c[16], e[13], c[48], 12), f[13] = rot(e[2], c[48], e[13], c[16], 12);
+    f[3]  = rot(e[3], -c[16], e[12], c[48], 12), f[12] = rot(e[3], c[48], e[12], c[16], 12);
+    f[4]  = rot(e[4], -c[48], e[11], -c[16], 12), f[11] = rot(e[4], -c[16], e[11], c[48], 12);
+    f[5]  = rot(e[5], -c[48], e[10], -c[16], 12), f[10] = rot(e[5], -c[16], e[10], c[48], 12);
+    /* stage 7 */
+    for (int i = 0; i < 4; ++i) {
+        g[i]      = clamp16(f[i] + f[7 - i]);
+        g[7 - i]  = clamp16(f[i] - f[7 - i]);
+        g[8 + i]  = clamp16(-f[8 + i] + f[15 - i]);
+        g[15 - i] = clamp16(f[8 + i] + f[15 - i]);
+    }
+    /* stage 8 */
+    for (int i = 0; i < 4; ++i) h[i] = g[i], h[12 + i] = g[12 + i];
+    for (int i = 4; i < 8; ++i) {
+        h[i]      = rot(g[i], -c[32], g[15 - i], c[32], 12);
+        h[15 - i] = rot(g[i], c[32], g[15 - i], c[32], 12);
+    }
+    for (int i = 0; i < 16; ++i) { /* stage 9 */
+        X[i]      = clamp16(E[i] + h[15 - i]);
+        X[31 - i] = clamp16(E[i] - h[15 - i]);
+    }
+}
+
 static void idct(int n, const int32_t *x, int32_t *X, const int32_t *c) {
     if (n == 4) idct4(x, X, c);
     else if (n == 8) idct8(x, X, c);
-    else idct16(x, X, c);
+    else if (n == 16) idct16(x, X, c);
+    else idct32(x, X, c);
 }
 
-/* dq [h][w] (w = 16, h = 16 / 8 / 4) added to the h rows at dst, dst_stride apart */
+/* dq [h][w] ((w, h) = (16, 16), (16, 8), (16, 4) or (32, 8)) added to the h rows at dst, dst_stride apart */
 void orc_tpl_inv_dct_add(const int32_t *dq, int w, int h, uint8_t *dst, int dst_stride) {
-    int32_t c[64], buf[16 * 16], in[16], out[16];
+    int32_t c[64], buf[32 * 16], in[32], out[32];
     cos_table(c, 12);
-    const int shift0 = (w == 16 && h == 16) ? 2 : 1; /* inv_shift_16x16 / 16x8 / 16x4, EbInvTransforms.h:53-65 */
+    const int shift0 = (w == 16 && h < 16) ? 1 : 2; /* inv_shift_16x16 / 32x8: 2; 16x8 / 16x4: 1, EbInvTransforms.h:53-67 */
     for (int r = 0; r < h; ++r) {
         for (int i = 0; i < w; ++i) {
             int32_t v = dq[r * w + i];
@@ -660,30 +713,33 @@ static int tpl_dequantised(const int32_t *coeff, int n, const int16_t round_fp[2
 int orc_tpl_recon(const uint8_t *cur_pix, int stride, const uint8_t *const ref_pix[SVTME_MAX_LISTS * SVTME_MAX_REFS],
                   const svtme_tpl_picture *p, const svtme_tpl_block *blocks, uint8_t *recon, orc_tpl_stats *stats) {
     if (p->pf_shape > 2 || p->subsample_tx > 2) return SVTME_ERR_UNSUPPORTED;
-    if (p->dispenser_search_level != 0) return SVTME_ERR_UNSUPPORTED; /* 16x16 blocks: tpl levels 1 .. 6 */
+    /* 16x16 blocks with 16x16 / 16x8 / 16x4 transforms (tpl levels 1 .. 6), or 32x32 blocks with the 32x8 transform, whose
+     * incomplete 64x64 blocks take 16x16 blocks with 16x4 (tpl level 7) */
+    if (p->dispenser_search_level > 1 || (p->dispenser_search_level == 1 && (p->subsample_tx != 2 || !p->tpl_opt_flag))) return SVTME_ERR_UNSUPPORTED;
     const int   w = (int)p->width, h = (int)p->height, b64_w = (w + 63) / 64, b64_h = (h + 63) / 64;
     const plane cur = {cur_pix, stride, w, h}, rec = {recon, stride, w, h};
     const int   all_modes = !p->tpl_opt_flag, shape = all_modes ? 0 : p->pf_shape; /* :1131-1133 */
     const int   dc_path = p->tpl_opt_flag && p->use_pred_sad_in_intra_search; /* intra_dc_sad_path :594-595 */
-    const int   sub = p->subsample_tx, step = 1 << sub, tx_h = 16 >> sub;
+    const int   sub = p->subsample_tx, step = 1 << sub;
     memset(stats, 0, sizeof(*stats) * (size_t)b64_w * b64_h * SVTME_TPL_BLOCKS);
     for (int b64 = 0; b64 < b64_w * b64_h; ++b64) {
         const int sb_x = (b64 % b64_w) * 64, sb_y = (b64 / b64_w) * 64;
-        for (int bi = 5; bi <= 20; ++bi) {
-            int bx, by, size;
-            blk_geometry(bi, &bx, &by, &size);
-            const int x = sb_x + bx, y = sb_y + by;
-            if (x + 8 > w || y + 8 > h) continue; /* :604-607 */
+        const int level = (sb_x + 64 <= w && sb_y + 64 <= h) ? p->dispenser_search_level : 0; /* :2086-2088 */
+        for (int bi = level ? 1 : 5; bi <= (level ? 4 : 20); ++bi) {
+            int bx, by, S;
+            blk_geometry(bi, &bx, &by, &S);
+            const int x = sb_x + bx, y = sb_y + by, tx_h = S >> sub;
+            if (x + (S >> 1) > w || y + (S >> 1) > h) continue; /* :604-607 */
             const svtme_tpl_block *b = &blocks[(size_t)b64 * SVTME_TPL_BLOCKS + bi];
-            uint8_t                prd[256];
+            uint8_t                prd[32 * 32];
             if (b->best_is_inter) { /* :1005-1030: the block the vector points at in the reference picture */
                 const int list = b->best_rf_idx < 4 ? 0 : 1, ref = b->best_rf_idx & 3;
                 if (!ref_pix[list * SVTME_MAX_REFS + ref]) return SVTME_ERR_BAD_ARG;
                 const plane rp = {ref_pix[list * SVTME_MAX_REFS + ref], stride, w, h};
-                for (int r = 0; r < 16; ++r)
-                    for (int c = 0; c < 16; ++c) prd[r * 16 + c] = (uint8_t)pel(&rp, x + (b->mv_x >> 3) + c, y + (b->mv_y >> 3) + r);
-            } else if (dc_path) { /* :1044-1078 */
-                memset(prd, dc_value(&rec, x, y, 16), 256);
+                for (int r = 0; r < S; ++r)
+                    for (int c = 0; c < S; ++c) prd[r * S + c] = (uint8_t)pel(&rp, x + (b->mv_x >> 3) + c, y + (b->mv_y >> 3) + r);
+            } else if (dc_path || S == 32) { /* :1044-1078 (a 32x32 block's mode is DC_PRED, over the same neighbours) */
+                memset(prd, dc_value(&rec, x, y, S), (size_t)S * S);
             } else { /* :1080-1119: the neighbours in the reconstructed picture */
                 uint8_t   above[40], left[40];
                 const int mode = b->best_intra_mode;
@@ -694,18 +750,18 @@ int orc_tpl_recon(const uint8_t *cur_pix, int stride, const uint8_t *const ref_p
             int16_t res[256];
             int32_t coeff[256], dq[256];
             for (int r = 0; r < tx_h; ++r) /* svt_aom_subtract_block over every step-th row, :1123-1130 */
-                for (int c = 0; c < 16; ++c) res[r * 16 + c] = (int16_t)(pel(&cur, x + c, y + r * step) - prd[r * step * 16 + c]);
-            orc_tpl_fwd_dct(res, 16, tx_h, coeff, shape);
-            const int64_t recon_error = orc_tpl_quantize_error(coeff, 16 * tx_h, p->y_round_fp, p->y_quant_fp, p->y_dequant);
-            const int     eob = tpl_dequantised(coeff, 16 * tx_h, p->y_round_fp, p->y_quant_fp, p->y_dequant, dq);
+                for (int c = 0; c < S; ++c) res[r * S + c] = (int16_t)(pel(&cur, x + c, y + r * step) - prd[r * step * S + c]);
+            if (orc_tpl_fwd_dct(res, S, tx_h, coeff, shape)) return SVTME_ERR_UNSUPPORTED;
+            const int64_t recon_error = orc_tpl_quantize_error(coeff, S * tx_h, p->y_round_fp, p->y_quant_fp, p->y_dequant);
+            const int     eob = tpl_dequantised(coeff, S * tx_h, p->y_round_fp, p->y_quant_fp, p->y_dequant, dq);
             const int64_t rate_cost = p->tpl_opt_flag ? 0 : orc_tpl_rate16(coeff, p->y_round_fp, p->y_quant_fp, p->y_dequant);
             if (!p->disable_intra_pred && eob) { /* :1143-1177 (disable_intra_pred implies a picture that is not a reference) */
-                orc_tpl_inv_dct_add(dq, 16, tx_h, prd, 16 * step);
-                for (int r = 0; r < 16; ++r) /* the rows between take the row above them */
-                    if (r % step) memcpy(prd + r * 16, prd + (r - r % step) * 16, 16);
+                orc_tpl_inv_dct_add(dq, S, tx_h, prd, S * step);
+                for (int r = 0; r < S; ++r) /* the rows between take the row above them */
+                    if (r % step) memcpy(prd + r * S, prd + (r - r % step) * S, (size_t)S);
             }
-            for (int r = 0; r < 16 && y + r < h; ++r)
-                for (int c = 0; c < 16 && x + c < w; ++c) recon[(size_t)(y + r) * stride + x + c] = prd[r * 16 + c];
+            for (int r = 0; r < S && y + r < h; ++r)
+                for (int c = 0; c < S && x + c < w; ++c) recon[(size_t)(y + r) * stride + x + c] = prd[r * S + c];
             orc_tpl_stats *o = &stats[(size_t)b64 * SVTME_TPL_BLOCKS + bi];
             o->recrf_dist = (recon_error << 4) << sub; /* TPL_DEP_COST_SCALE_LOG2, :1179-1181 */
             o->recrf_rate = (rate_cost << 4) << sub;
@@ -719,7 +775,7 @@ int orc_tpl_recon(const uint8_t *cur_pix, int stride, const uint8_t *const ref_p
             if (o->recrf_dist < o->srcrf_dist) o->recrf_dist = o->srcrf_dist; /* :1189-1190 */
             if (o->recrf_rate < o->srcrf_rate) o->recrf_rate = o->srcrf_rate;
             /* result_model_store :214-222 */
-            o->srcrf_dist /= 16, o->recrf_dist /= 16, o->srcrf_rate /= 16, o->recrf_rate /= 16;
+            o->srcrf_dist /= S, o->recrf_dist /= S, o->srcrf_rate /= S, o->recrf_rate /= S;
             if (o->srcrf_dist < 1) o->srcrf_dist = 1;
             if (o->recrf_dist < 1) o->recrf_dist = 1;
             if (o->srcrf_rate < 1) o->srcrf_rate = 1;

@@ -102,8 +102,9 @@ TPL_STATS = np.dtype([("srcrf_dist", "<i8"), ("recrf_dist", "<i8"), ("srcrf_rate
 
 
 def recon_available(ctrl):
-    """The reconstruction path is restated for 16x16 blocks (tpl levels 1 to 6)."""
-    return ctrl["dispenser_search_level"] == 0
+    """The reconstruction path is restated for 16x16 blocks (tpl levels 1 to 6) and for 32x32 blocks with the 32x8 transform
+    (tpl level 7)."""
+    return ctrl["dispenser_search_level"] == 0 or (ctrl["dispenser_search_level"] == 1 and ctrl["subsample_tx"] == 2 and ctrl["tpl_opt_flag"] == 1)
 
 
 def oracle_recon(cur, refs, pic, blocks):

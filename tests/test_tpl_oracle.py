@@ -83,7 +83,7 @@ def test_oracle_reproduces_reference_tpl_reconstruction(name):
     every block as the real reference left them."""
     frames, pics, per = load_case(name, CASES[name])
     if not tplio.recon_available(per[0][0]):
-        pytest.skip("32x32 blocks: not restated")
+        pytest.skip("not restated")
     for pic, (ctrl, me, tb, quant) in zip(pics, per):
         p, keep, refs = picture_of(frames, pic, ctrl, me, quant=quant)
         blocks = tplio.oracle_search(frames[pic.poc], refs, p)
