@@ -1756,10 +1756,12 @@ extern "C" int svtme_tpl_recon(svtme_engine *e, const svtme_tpl_picture *pic, co
     if (pic->width < 64 || pic->height < 64 || pic->width > e->cfg.max_width || pic->height > e->cfg.max_height || pic->width % 8 ||
         pic->height % 8 || pic->n_ref[0] > SVTME_MAX_REFS || pic->n_ref[1] > SVTME_MAX_REFS || (recon && recon_stride < pic->width))
         return SVTME_ERR_BAD_ARG;
-    // 16x16 blocks with the 16x16, 16x8 and 16x4 transforms: tpl levels 1 to 6
-    if (pic->dispenser_search_level != 0 || pic->subsample_tx > 2 || pic->pf_shape > 2) return SVTME_ERR_UNSUPPORTED;
+    // 16x16 blocks with the 16x16, 16x8 and 16x4 transforms (tpl levels 1 to 6); 32x32 blocks with the 32x8 transform, whose
+    // incomplete 64x64 blocks take 16x16 blocks with 16x4 (tpl level 7)
+    if (pic->dispenser_search_level > 1 || pic->subsample_tx > 2 || pic->pf_shape > 2) return SVTME_ERR_UNSUPPORTED;
     const bool all_modes = !pic->tpl_opt_flag;
     if (all_modes && pic->subsample_tx != 0) return SVTME_ERR_UNSUPPORTED; // rate_estimator is there for the 16x16 transform
+    if (pic->dispenser_search_level == 1 && (pic->subsample_tx != 2 || all_modes)) return SVTME_ERR_UNSUPPORTED;
     const int b64_w = (int)(pic->width + 63) / 64, n_b64 = b64_w * ((int)(pic->height + 63) / 64);
     const size_t n_blk = (size_t)n_b64 * SVTME_TPL_BLOCKS;
     for (size_t i = 0; i < n_blk; ++i) { // what the kernels index with
@@ -1778,28 +1780,39 @@ extern "C" int svtme_tpl_recon(svtme_engine *e, const svtme_tpl_picture *pic, co
     // The intra blocks in levels: a block reads the reconstruction of the blocks left of, above and above-left of it, and on the
     // picture's first column of the one above-right (EbEncIntraPrediction.c:1237-1319); those predicted from reference pictures
     // are all done first, so a block's level is one more than the highest level among its intra neighbours.
+    // (Kept per 16x16 cell of the picture; a 32x32 block fills its four cells. The 64x64 blocks in raster order and the blocks
+    // inside them in the dispenser's order: whatever a block reads comes earlier.)
     const int bw16 = (int)(pic->width + 15) / 16, bh16 = (int)(pic->height + 15) / 16;
     std::vector<int> level((size_t)bw16 * bh16, -1), level_count;
-    for (int by = 0; by < bh16; ++by)
-        for (int bx = 0; bx < bw16; ++bx) {
-            if (bx * 16 + 8 > (int)pic->width || by * 16 + 8 > (int)pic->height) continue;
-            const int b64 = (by >> 2) * b64_w + (bx >> 2), bi = 5 + (((by >> 1) & 1) * 2 + ((bx >> 1) & 1)) * 4 + (by & 1) * 2 + (bx & 1);
-            const svtme_tpl_block &b = blocks[(size_t)b64 * SVTME_TPL_BLOCKS + bi];
+    std::vector<std::pair<int, uint32_t>> found; // (level, position)
+    for (int sb = 0; sb < n_b64; ++sb) {
+        const int  sx = (sb % b64_w) * 4, sy = (sb / b64_w) * 4;
+        const bool big = pic->dispenser_search_level == 1 && sx * 16 + 64 <= (int)pic->width && sy * 16 + 64 <= (int)pic->height;
+        for (int k = 0; k < (big ? 4 : 16); ++k) {
+            const int S = big ? 2 : 1; // cells per side
+            const int bx = big ? sx + (k & 1) * 2 : sx + ((k >> 2) & 1) * 2 + (k & 1), by = big ? sy + (k >> 1) * 2 : sy + (k >> 3) * 2 + ((k >> 1) & 1);
+            if (bx * 16 + S * 8 > (int)pic->width || by * 16 + S * 8 > (int)pic->height) continue;
+            const int bi = big ? 1 + k : 5 + k;
+            const svtme_tpl_block &b = blocks[(size_t)sb * SVTME_TPL_BLOCKS + bi];
             if (!b.valid || b.best_is_inter) continue;
-            auto at = [&](int x, int y) { return x >= 0 && y >= 0 && x < bw16 ? level[(size_t)y * bw16 + x] : -1; };
-            const int l = 1 + std::max(std::max(at(bx - 1, by), at(bx, by - 1)), std::max(at(bx - 1, by - 1), bx == 0 ? at(1, by - 1) : -1));
-            level[(size_t)by * bw16 + bx] = l;
+            auto at = [&](int x, int y) { return x >= 0 && y >= 0 && x < bw16 && y < bh16 ? level[(size_t)y * bw16 + x] : -1; };
+            int  l  = -1;
+            for (int i = -1; i < (bx == 0 ? 2 * S : S); ++i) l = std::max(l, at(bx + i, by - 1)); // the row above (and above-right on the first column)
+            for (int i = 0; i < S; ++i) l = std::max(l, at(bx - 1, by + i)); // the column to the left
+            ++l;
+            for (int j = 0; j < S; ++j)
+                for (int i = 0; i < S; ++i)
+                    if (bx + i < bw16 && by + j < bh16) level[(size_t)(by + j) * bw16 + bx + i] = l;
             if ((int)level_count.size() <= l) level_count.resize(l + 1, 0);
             ++level_count[l];
+            found.emplace_back(l, (uint32_t)bx | ((uint32_t)by << 16));
         }
-    std::vector<uint32_t> order;
+    }
+    std::vector<uint32_t> order(found.size());
     {
         std::vector<int> next(level_count.size() + 1, 0);
         for (size_t l = 0; l < level_count.size(); ++l) next[l + 1] = next[l] + level_count[l];
-        order.resize(next.back());
-        for (int by = 0; by < bh16; ++by)
-            for (int bx = 0; bx < bw16; ++bx)
-                if (level[(size_t)by * bw16 + bx] >= 0) order[next[level[(size_t)by * bw16 + bx]]++] = (uint32_t)bx | ((uint32_t)by << 16);
+        for (const auto &f : found) order[next[f.first]++] = f.second;
     }
     const size_t rec_stride = ((size_t)pic->width + 63) / 64 * 64, list_off = par_off + (sizeof(TplParams) + 63) / 64 * 64;
     const size_t rec_off = (list_off + (size_t)bw16 * bh16 * 4 + 63) / 64 * 64, total = rec_off + rec_stride * pic->height;
@@ -1836,6 +1849,7 @@ extern "C" int svtme_tpl_recon(svtme_engine *e, const svtme_tpl_picture *pic, co
     p.height = (int)pic->height;
     p.b64_w  = b64_w;
     p.n_b64  = n_b64;
+    p.level  = pic->dispenser_search_level;
     p.disable_intra_pred = pic->disable_intra_pred;
     p.pf_shape     = all_modes ? 0 : pic->pf_shape; // DEFAULT_SHAPE without tpl_opt_flag (:1131-1133)
     p.rate         = all_modes; // rate_estimator, else 0 (:1141)

@@ -762,50 +762,114 @@ __device__ __forceinline__ void idct_n(const int32_t (&x)[16], int32_t (&X)[16],
     }
 }
 
+// svt_av1_idct32_new (:356-706): the odd half takes inputs 1, 17, 9, 25, 5, 21, 13, 29, 3, 19, 11, 27, 7, 23, 15, 31 as nodes
+// 16 .. 31 (the arrays below are indexed node - 16)
+__device__ __forceinline__ void idct_n(const int32_t (&x)[32], int32_t (&X)[32], CosTable c) {
+    constexpr int in_of[16] = {1, 17, 9, 25, 5, 21, 13, 29, 3, 19, 11, 27, 7, 23, 15, 31};
+    constexpr int k2[8]     = {62, 30, 46, 14, 54, 22, 38, 6}; // stage 2: node 16 + i with node 31 - i
+    int32_t       ev[16], E[16], o[16], b[16], d[16], e[16], f[16], g[16], h[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) ev[i] = x[2 * i], o[i] = x[in_of[i]];
+    idct_n(ev, E, c);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        b[i]      = rot<12>(o[i], TPL_C(k2[i]), o[15 - i], -TPL_C(64 - k2[i]));
+        b[15 - i] = rot<12>(o[i], TPL_C(64 - k2[i]), o[15 - i], TPL_C(k2[i]));
+    }
+#pragma unroll
+    for (int i = 0; i < 16; i += 4) { // stage 3
+        d[i] = clamp16(b[i] + b[i + 1]), d[i + 1] = clamp16(b[i] - b[i + 1]);
+        d[i + 2] = clamp16(-b[i + 2] + b[i + 3]), d[i + 3] = clamp16(b[i + 2] + b[i + 3]);
+    }
+    // stage 4
+    b[0] = d[0], b[3] = d[3], b[4] = d[4], b[7] = d[7], b[8] = d[8], b[11] = d[11], b[12] = d[12], b[15] = d[15];
+    b[1] = rot<12>(d[1], -TPL_C(8), d[14], TPL_C(56)), b[14] = rot<12>(d[1], TPL_C(56), d[14], TPL_C(8));
+    b[2] = rot<12>(d[2], -TPL_C(56), d[13], -TPL_C(8)), b[13] = rot<12>(d[2], -TPL_C(8), d[13], TPL_C(56));
+    b[5] = rot<12>(d[5], -TPL_C(40), d[10], TPL_C(24)), b[10] = rot<12>(d[5], TPL_C(24), d[10], TPL_C(40));
+    b[6] = rot<12>(d[6], -TPL_C(24), d[9], -TPL_C(40)), b[9] = rot<12>(d[6], -TPL_C(40), d[9], TPL_C(24));
+    // stage 5
+    e[0] = clamp16(b[0] + b[3]), e[1] = clamp16(b[1] + b[2]), e[2] = clamp16(b[1] - b[2]), e[3] = clamp16(b[0] - b[3]);
+    e[4] = clamp16(-b[4] + b[7]), e[5] = clamp16(-b[5] + b[6]), e[6] = clamp16(b[5] + b[6]), e[7] = clamp16(b[4] + b[7]);
+    e[8] = clamp16(b[8] + b[11]), e[9] = clamp16(b[9] + b[10]), e[10] = clamp16(b[9] - b[10]), e[11] = clamp16(b[8] - b[11]);
+    e[12] = clamp16(-b[12] + b[15]), e[13] = clamp16(-b[13] + b[14]), e[14] = clamp16(b[13] + b[14]), e[15] = clamp16(b[12] + b[15]);
+    // stage 6
+    f[0] = e[0], f[1] = e[1], f[6] = e[6], f[7] = e[7], f[8] = e[8], f[9] = e[9], f[14] = e[14], f[15] = e[15];
+    f[2] = rot<12>(e[2], -TPL_C(16), e[13], TPL_C(48)), f[13] = rot<12>(e[2], TPL_C(48), e[13], TPL_C(16));
+    f[3] = rot<12>(e[3], -TPL_C(16), e[12], TPL_C(48)), f[12] = rot<12>(e[3], TPL_C(48), e[12], TPL_C(16));
+    f[4] = rot<12>(e[4], -TPL_C(48), e[11], -TPL_C(16)), f[11] = rot<12>(e[4], -TPL_C(16), e[11], TPL_C(48));
+    f[5] = rot<12>(e[5], -TPL_C(48), e[10], -TPL_C(16)), f[10] = rot<12>(e[5], -TPL_C(16), e[10], TPL_C(48));
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { // stage 7
+        g[i]      = clamp16(f[i] + f[7 - i]);
+        g[7 - i]  = clamp16(f[i] - f[7 - i]);
+        g[8 + i]  = clamp16(-f[8 + i] + f[15 - i]);
+        g[15 - i] = clamp16(f[8 + i] + f[15 - i]);
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) h[i] = g[i], h[12 + i] = g[12 + i]; // stage 8
+#pragma unroll
+    for (int i = 4; i < 8; ++i) {
+        h[i]      = rot<12>(g[i], -TPL_C(32), g[15 - i], TPL_C(32));
+        h[15 - i] = rot<12>(g[i], TPL_C(32), g[15 - i], TPL_C(32));
+    }
+#pragma unroll
+    for (int i = 0; i < 16; ++i) { // stage 9
+        X[i]      = clamp16(E[i] + h[15 - i]);
+        X[31 - i] = clamp16(E[i] - h[15 - i]);
+    }
+}
 #undef TPL_C
 
-// The transforms of a 16x16 block whose lanes hold its source and predicted pixels (lane = row lane / 4, columns 4 (lane % 4)
-// ..): the 16 x H forward DCT of every (16 / H)-th row's residual and its quantisation as in tpl_transform; then, when
-// `inverse` and a level is left, the inverse DCT of the dequantised coefficients added to the prediction of those rows, the
-// rows between taking the row above them (:1145-1176). Returns the lane's four reconstructed pixels; recon_error and rate in
-// every lane.
-template <int H>
-__device__ __forceinline__ uint32_t tpl_recon_transform(ConstTplParams &p, uint32_t src, uint32_t prd, int32_t *lds, bool inverse, bool want_rate,
-                                                        long long &recon_error, long long &rate) {
-    constexpr int PITCH = 17, STEP = 16 / H, SHIFT1 = H == 4 ? 1 : 2, BIT_ROW = H == 16 ? 12 : 13, SHIFT_INV = H == 16 ? 2 : 1;
-    const int     lane = threadIdx.x & 63, r = lane >> 2, d = lane & 3;
+// The transforms of a block of side W whose lanes hold its source and predicted pixels (dword lane + 64 k of the block's rows,
+// N = W W / 256 dwords per lane): the W x H forward DCT of every (W / H)-th row's residual and its quantisation as in
+// tpl_transform; then, when `inverse` and a level is left, the inverse DCT of the dequantised coefficients added to the
+// prediction of those rows, the rows between taking the row above them (:1145-1176). (W, H) = (16, 16), (16, 8), (16, 4),
+// (32, 8). Leaves the lane's reconstructed pixels in out[]; recon_error and rate in every lane.
+template <int W, int H, int N>
+__device__ __forceinline__ void tpl_recon_transform(ConstTplParams &p, const uint32_t (&src)[N], const uint32_t (&prd)[N], uint32_t (&out)[N],
+                                                    int32_t *lds, bool inverse, bool want_rate, long long &recon_error, long long &rate) {
+    constexpr int  PITCH = W + 1, DW = W / 4, STEP = W / H, SHIFT1 = (W == 16 && H == 4) ? 1 : 2;
+    constexpr int  BIT_ROW = ((W == 16 && H == 16) || W == 32) ? 12 : 13, SHIFT_INV = (W == 16 && H < 16) ? 1 : 2;
+    constexpr bool RECT = W == 2 * H, RATE = W == 16 && H == 16;
+    static_assert(H * PITCH <= 16 * 17, "the coefficients fit the buffer");
+    const int lane = threadIdx.x & 63;
     wave_sync();
-    if (r % STEP == 0) {
 #pragma unroll
-        for (int j = 0; j < 4; ++j) lds[(r / STEP) * PITCH + 4 * d + j] = (int32_t)((src >> (8 * j)) & 0xff) - (int32_t)((prd >> (8 * j)) & 0xff);
+    for (int k = 0; k < N; ++k) {
+        const int idx = lane + 64 * k, r = idx / DW, d = idx % DW;
+        if (r % STEP == 0) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                lds[(r / STEP) * PITCH + 4 * d + j] = (int32_t)((src[k] >> (8 * j)) & 0xff) - (int32_t)((prd[k] >> (8 * j)) & 0xff);
+        }
     }
     wave_sync();
     {
-        int32_t in[H], out[H];
-        if (lane < 16) {
+        int32_t in[H], o[H];
+        if (lane < W) {
 #pragma unroll
             for (int i = 0; i < H; ++i) in[i] = lds[i * PITCH + lane] * 4;
-            fdct_n<13>(in, out, p.cos13);
+            fdct_n<13>(in, o, p.cos13);
         }
         wave_sync();
-        if (lane < 16) {
+        if (lane < W) {
 #pragma unroll
-            for (int i = 0; i < H; ++i) lds[i * PITCH + lane] = (out[i] + (1 << (SHIFT1 - 1))) >> SHIFT1;
+            for (int i = 0; i < H; ++i) lds[i * PITCH + lane] = (o[i] + (1 << (SHIFT1 - 1))) >> SHIFT1;
         }
     }
     wave_sync();
     long long e_sum = 0;
     int       eob = 0, logs = 0, any = 0;
-    const int kw = 16 >> p.pf_shape, kh = H >> p.pf_shape;
+    const int kw = W >> p.pf_shape, kh = H >> p.pf_shape;
     if (lane < H) {
-        int32_t in[16], out[16];
+        int32_t in[W], o[W];
 #pragma unroll
-        for (int i = 0; i < 16; ++i) in[i] = lds[lane * PITCH + i];
-        if (lane < kh) fdct_n<BIT_ROW>(in, out, BIT_ROW == 12 ? p.cos12 : p.cos13);
+        for (int i = 0; i < W; ++i) in[i] = lds[lane * PITCH + i];
+        if (lane < kh) fdct_n<BIT_ROW>(in, o, BIT_ROW == 12 ? p.cos12 : p.cos13);
 #pragma unroll
-        for (int i = 0; i < 16; ++i) {
-            int32_t v = (lane < kh && i < kw) ? out[i] : 0;
-            if (H == 8) v = (int32_t)(((long long)v * 5793 + 2048) >> 12); // NewSqrt2, 12 fractional bits
+        for (int i = 0; i < W; ++i) {
+            int32_t v = (lane < kh && i < kw) ? o[i] : 0;
+            if (RECT) v = (int32_t)(((long long)v * 5793 + 2048) >> 12); // NewSqrt2, 12 fractional bits
             const int32_t a  = v < 0 ? -v : v;
             const int     ac = (lane | i) != 0;
             int32_t       dq = 0;
@@ -815,7 +879,7 @@ __device__ __forceinline__ uint32_t tpl_recon_transform(ConstTplParams &p, uint3
                 dq                  = level * p.dequant[ac];
                 if (level) {
                     any = 1;
-                    if (H == 16 && want_rate) {
+                    if (RATE && want_rate) {
                         eob = max(eob, tpl_scan_pos16(lane, i) + 1);
                         logs += 31 - __clz(level + 1);
                     }
@@ -835,96 +899,125 @@ __device__ __forceinline__ uint32_t tpl_recon_transform(ConstTplParams &p, uint3
     }
     e_sum >>= 2;
     recon_error = e_sum < 1 ? 1 : e_sum;
-    rate        = want_rate ? (long long)(eob + 1 + logs) << 9 : 0;
-    if (!inverse || !any) return prd;
+    rate        = RATE && want_rate ? (long long)(eob + 1 + logs) << 9 : 0;
+#pragma unroll
+    for (int k = 0; k < N; ++k) out[k] = prd[k];
+    if (!inverse || !any) return;
     wave_sync();
     {
-        int32_t in[16], out[16];
+        int32_t in[W], o[W];
         if (lane < H) {
 #pragma unroll
-            for (int i = 0; i < 16; ++i) {
+            for (int i = 0; i < W; ++i) {
                 int32_t v = lds[lane * PITCH + i];
-                if (H == 8) v = (int32_t)(((long long)v * 2896 + 2048) >> 12); // new_inv_sqrt2, 12 fractional bits
+                if (RECT) v = (int32_t)(((long long)v * 2896 + 2048) >> 12); // new_inv_sqrt2, 12 fractional bits
                 in[i] = clamp16(v);
             }
-            idct_n(in, out, p.cos12);
+            idct_n(in, o, p.cos12);
 #pragma unroll
-            for (int i = 0; i < 16; ++i) lds[lane * PITCH + i] = (out[i] + (1 << (SHIFT_INV - 1))) >> SHIFT_INV;
+            for (int i = 0; i < W; ++i) lds[lane * PITCH + i] = (o[i] + (1 << (SHIFT_INV - 1))) >> SHIFT_INV;
         }
     }
     wave_sync();
     {
-        int32_t in[H], out[H];
-        if (lane < 16) {
+        int32_t in[H], o[H];
+        if (lane < W) {
 #pragma unroll
             for (int i = 0; i < H; ++i) in[i] = clamp16(lds[i * PITCH + lane]);
-            idct_n(in, out, p.cos12);
+            idct_n(in, o, p.cos12);
         }
         wave_sync();
-        if (lane < 16) {
+        if (lane < W) {
 #pragma unroll
-            for (int i = 0; i < H; ++i) lds[i * PITCH + lane] = (out[i] + 8) >> 4;
+            for (int i = 0; i < H; ++i) lds[i * PITCH + lane] = (o[i] + 8) >> 4;
         }
     }
     wave_sync();
-    // the transformed row of this lane's row: itself, or the one above it that was
-    const int      rt = r - r % STEP;
-    const uint32_t pt = (uint32_t)__shfl((int)prd, rt * 4 + d);
-    uint32_t       o  = 0;
+    // a pixel's transformed row: its own, or the one above it that was transformed - whose dword the same k of another lane holds
+    // (64 / DW rows per k, a multiple of STEP)
+    static_assert((64 / DW) % STEP == 0, "a row and its transformed row share k");
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        const int v = (int)((pt >> (8 * j)) & 0xff) + lds[(rt / STEP) * PITCH + 4 * d + j];
-        o |= (uint32_t)min(max(v, 0), 255) << (8 * j);
+    for (int k = 0; k < N; ++k) {
+        const int      idx = lane + 64 * k, r = idx / DW, d = idx % DW, rt = r - r % STEP;
+        const uint32_t pt  = (uint32_t)__shfl((int)prd[k], (rt * DW + d) & 63);
+        uint32_t       o   = 0;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int v = (int)((pt >> (8 * j)) & 0xff) + lds[(rt / STEP) * PITCH + 4 * d + j];
+            o |= (uint32_t)min(max(v, 0), 255) << (8 * j);
+        }
+        out[k] = o;
     }
-    return o;
 }
 
-// One block of the reconstruction path, whole wave; `b` is the search's record of the block.
+// One block of side S of the reconstruction path, whole wave; `b` is the search's record of the block.
+template <int S>
 __device__ __forceinline__ void tpl_recon_block(ConstTplParams &p, int b64, int bi, int x, int y, const svtme_tpl_block &b, int32_t *lds, uint8_t *edges) {
-    const int      lane = threadIdx.x & 63, r = lane >> 2, d = lane & 3;
+    constexpr int  DW = S / 4, N = S * S / 256;
+    const int      lane = threadIdx.x & 63;
     const DevPlane cur = load_plane(p.cur);
     DevPlane       rec = cur; // the reconstructed picture: the picture's size, no border
     rec.pix            = p.recon;
     rec.stride         = p.recon_stride;
-    const uint32_t src = *reinterpret_cast<const uint32_t *>(cur.pix + (ptrdiff_t)(y + r) * cur.stride + x + 4 * d);
-    uint32_t       prd;
+    uint32_t src[N], prd[N], out[N];
+#pragma unroll
+    for (int k = 0; k < N; ++k) {
+        const int idx = lane + 64 * k, r = idx / DW, d = idx % DW;
+        src[k]        = *reinterpret_cast<const uint32_t *>(cur.pix + (ptrdiff_t)(y + r) * cur.stride + x + 4 * d);
+    }
     if (b.best_is_inter) { // :1005-1030
-        const DevPlane rp = load_plane(p.ref[b.best_rf_idx >> 2][b.best_rf_idx & 3]);
-        __builtin_memcpy(&prd, rp.pix + (ptrdiff_t)(y + (b.mv_y >> 3) + r) * rp.stride + x + (b.mv_x >> 3) + 4 * d, 4);
-    } else if (p.dc_path || b.best_intra_mode == 0) { // :1044-1078; DC_PRED of :1080-1119 sees the same neighbours
+        const DevPlane rp  = load_plane(p.ref[b.best_rf_idx >> 2][b.best_rf_idx & 3]);
+        const uint8_t *org = rp.pix + (ptrdiff_t)(y + (b.mv_y >> 3)) * rp.stride + x + (b.mv_x >> 3);
+#pragma unroll
+        for (int k = 0; k < N; ++k) {
+            const int idx = lane + 64 * k, r = idx / DW, d = idx % DW;
+            __builtin_memcpy(&prd[k], org + (ptrdiff_t)r * rp.stride + 4 * d, 4);
+        }
+    } else if (S == 32 || p.dc_path || b.best_intra_mode == 0) { // :1044-1078; DC_PRED of :1080-1119 sees the same neighbours
         uint32_t sum = 0;
-        if (lane < 16) {
+        if (lane < S) {
             if (y > 0) sum += x + lane < p.width ? rec.pix[(ptrdiff_t)(y - 1) * rec.stride + x + lane] : 127u;
             if (x > 0) sum += y + lane < p.height ? rec.pix[(ptrdiff_t)(y + lane) * rec.stride + x - 1] : 129u;
         }
         sum              = wave_sum(sum);
-        const uint32_t n = (y > 0 ? 16 : 0) + (x > 0 ? 16 : 0);
-        prd              = (n ? (sum + (n >> 1)) / n : 128u) * 0x01010101u;
+        const uint32_t n = (y > 0 ? S : 0) + (x > 0 ? S : 0);
+        const uint32_t v = (n ? (sum + (n >> 1)) / n : 128u) * 0x01010101u;
+#pragma unroll
+        for (int k = 0; k < N; ++k) prd[k] = v;
     } else { // :1080-1119
-        uint8_t  *a0 = edges, *l0 = edges + kEdge, *a1 = edges + 2 * kEdge, *l1 = edges + 3 * kEdge;
-        const int mode = b.best_intra_mode;
-        wave_sync();
-        tpl_collect_edges(p, rec, x, y, a0, l0);
-        wave_sync();
-        if (mode >= 3 && mode <= 8) {
-            const int angle = mode == 3 ? 45 : (mode == 4 ? 135 : (mode == 5 ? 113 : (mode == 6 ? 157 : (mode == 7 ? 203 : 67))));
-            tpl_filter_edges(angle, x, y, a0, l0, a1, l1);
+        if constexpr (S == 16) {
+            uint8_t  *a0 = edges, *l0 = edges + kEdge, *a1 = edges + 2 * kEdge, *l1 = edges + 3 * kEdge;
+            const int mode = b.best_intra_mode;
             wave_sync();
-            prd = tpl_intra_dword(mode, a1 + 4, l1 + 4);
-        } else
-            prd = tpl_intra_dword(mode, a0 + 4, l0 + 4);
+            tpl_collect_edges(p, rec, x, y, a0, l0);
+            wave_sync();
+            if (mode >= 3 && mode <= 8) {
+                const int angle = mode == 3 ? 45 : (mode == 4 ? 135 : (mode == 5 ? 113 : (mode == 6 ? 157 : (mode == 7 ? 203 : 67))));
+                tpl_filter_edges(angle, x, y, a0, l0, a1, l1);
+                wave_sync();
+                prd[0] = tpl_intra_dword(mode, a1 + 4, l1 + 4);
+            } else
+                prd[0] = tpl_intra_dword(mode, a0 + 4, l0 + 4);
+        }
     }
-    long long      recon_error, rate;
-    const bool     inverse = !p.disable_intra_pred, want_rate = p.rate != 0;
-    uint32_t       out;
-    if (p.subsample_tx == 0) out = tpl_recon_transform<16>(p, src, prd, lds, inverse, want_rate, recon_error, rate);
-    else if (p.subsample_tx == 1) out = tpl_recon_transform<8>(p, src, prd, lds, inverse, false, recon_error, rate);
-    else out = tpl_recon_transform<4>(p, src, prd, lds, inverse, false, recon_error, rate);
-    if (y + r < p.height) {
-        uint8_t *dst = p.recon + (ptrdiff_t)(y + r) * p.recon_stride + x + 4 * d;
-        if (x + 4 * d + 4 <= p.width) *reinterpret_cast<uint32_t *>(dst) = out;
-        else
-            for (int j = 0; j < 4 && x + 4 * d + j < p.width; ++j) dst[j] = (uint8_t)(out >> (8 * j));
+    long long  recon_error, rate;
+    const bool inverse = !p.disable_intra_pred, want_rate = p.rate != 0;
+    if constexpr (S == 16) {
+        if (p.subsample_tx == 0) tpl_recon_transform<16, 16, N>(p, src, prd, out, lds, inverse, want_rate, recon_error, rate);
+        else if (p.subsample_tx == 1) tpl_recon_transform<16, 8, N>(p, src, prd, out, lds, inverse, false, recon_error, rate);
+        else tpl_recon_transform<16, 4, N>(p, src, prd, out, lds, inverse, false, recon_error, rate);
+    } else {
+        tpl_recon_transform<32, 8, N>(p, src, prd, out, lds, inverse, false, recon_error, rate);
+    }
+#pragma unroll
+    for (int k = 0; k < N; ++k) {
+        const int idx = lane + 64 * k, r = idx / DW, d = idx % DW;
+        if (y + r < p.height) {
+            uint8_t *dst = p.recon + (ptrdiff_t)(y + r) * p.recon_stride + x + 4 * d;
+            if (x + 4 * d + 4 <= p.width) *reinterpret_cast<uint32_t *>(dst) = out[k];
+            else
+                for (int j = 0; j < 4 && x + 4 * d + j < p.width; ++j) dst[j] = (uint8_t)(out[k] >> (8 * j));
+        }
     }
     if (lane == 0) { // :1179-1197, result_model_store :214-222
         const int       sub = p.subsample_tx;
@@ -940,41 +1033,53 @@ __device__ __forceinline__ void tpl_recon_block(ConstTplParams &p, int b64, int 
         }
         o.recrf_dist = max(o.recrf_dist, o.srcrf_dist);
         o.recrf_rate = max(o.recrf_rate, o.srcrf_rate);
-        o.srcrf_dist = max(o.srcrf_dist / 16, 1ll);
-        o.recrf_dist = max(o.recrf_dist / 16, 1ll);
-        o.srcrf_rate = max(o.srcrf_rate / 16, 1ll);
-        o.recrf_rate = max(o.recrf_rate / 16, 1ll);
+        o.srcrf_dist = max(o.srcrf_dist / S, 1ll);
+        o.recrf_dist = max(o.recrf_dist / S, 1ll);
+        o.srcrf_rate = max(o.srcrf_rate / S, 1ll);
+        o.recrf_rate = max(o.recrf_rate / S, 1ll);
         p.stats[(size_t)b64 * SVTME_TPL_BLOCKS + bi] = o;
     }
 }
 
-// INTRA false: grid (16, n_b64) as the search, the blocks predicted from reference pictures, which depend on nothing.
+// INTRA false: grid (16, n_b64) as the search (slot s of a 64x64 block: its s-th 16x16 block, or at level 1 its s-th 32x32
+// block, s < 4), the blocks predicted from reference pictures, which depend on nothing.
 // INTRA true: blocks predicted from their reconstructed neighbours - the blocks left of, above and above-left of them, and
 // for the picture's first column the block above-right (update_neighbor_samples_array_open_loop_mb_recon replaces the
 // upper-right and lower-left extensions by repeats everywhere else). The host has sorted them into levels, a block's level
-// one more than the highest of its intra neighbours'; a launch runs one level: blocks list[first + blockIdx.x] (bx | by << 16).
+// one more than the highest of its intra neighbours'; a launch runs one level: blocks list[first + blockIdx.x] (position in
+// 16-pixel units, x | y << 16).
 template <bool INTRA>
 __global__ void __launch_bounds__(64) tpl_recon_kernel(const TplParams *pp, const uint32_t *list, int first) {
     __shared__ int32_t lds[16 * 17];
     __shared__ __align__(4) uint8_t edges[4 * kEdge];
     ConstTplParams    &p = *(ConstTplParams *)pp;
-    int bx, by;
+    int bx, by; // in 16-pixel units
     if (INTRA) {
         const uint32_t at = list[first + (int)blockIdx.x];
         bx = (int)(at & 0xFFFFu);
         by = (int)(at >> 16);
     } else {
-        const int b64 = blockIdx.y, slot = blockIdx.x, q = slot >> 2, s = slot & 3;
-        bx = (b64 % p.b64_w) * 4 + (q & 1) * 2 + (s & 1);
-        by = (b64 / p.b64_w) * 4 + (q >> 1) * 2 + (s >> 1);
+        const int b64 = blockIdx.y, slot = blockIdx.x, sx = (b64 % p.b64_w) * 4, sy = (b64 / p.b64_w) * 4;
+        if (p.level == 1 && sx * 16 + 64 <= p.width && sy * 16 + 64 <= p.height) {
+            if (slot >= 4) return;
+            bx = sx + (slot & 1) * 2;
+            by = sy + (slot >> 1) * 2;
+        } else {
+            const int q = slot >> 2, s = slot & 3;
+            bx = sx + (q & 1) * 2 + (s & 1);
+            by = sy + (q >> 1) * 2 + (s >> 1);
+        }
     }
-    const int x = bx * 16, y = by * 16;
-    if (bx < 0 || x + 8 > p.width || y + 8 > p.height) return; // at least half of the block inside (:604-607)
-    const int b64 = (by >> 2) * p.b64_w + (bx >> 2);
-    const int bi  = 5 + (((by >> 1) & 1) * 2 + ((bx >> 1) & 1)) * 4 + (by & 1) * 2 + (bx & 1); // z-order inside the 64x64 block
+    const int  x = bx * 16, y = by * 16, b64 = (by >> 2) * p.b64_w + (bx >> 2);
+    const bool big = p.level == 1 && (bx & ~3) * 16 + 64 <= p.width && (by & ~3) * 16 + 64 <= p.height; // a 32x32 block of a complete 64x64 block
+    const int  S = big ? 32 : 16;
+    if (x + (S >> 1) > p.width || y + (S >> 1) > p.height) return; // at least half of the block inside (:604-607)
+    const int bi = big ? 1 + ((by >> 1) & 1) * 2 + ((bx >> 1) & 1)
+                       : 5 + (((by >> 1) & 1) * 2 + ((bx >> 1) & 1)) * 4 + (by & 1) * 2 + (bx & 1); // z-order inside the 64x64 block
     const svtme_tpl_block b = p.out[(size_t)b64 * SVTME_TPL_BLOCKS + bi];
     if (!b.valid || (b.best_is_inter != 0) == INTRA) return;
-    tpl_recon_block(p, b64, bi, x, y, b, lds, edges);
+    if (big) tpl_recon_block<32>(p, b64, bi, x, y, b, lds, edges);
+    else tpl_recon_block<16>(p, b64, bi, x, y, b, lds, edges);
 }
 
 } // namespace

@@ -49,10 +49,11 @@ def test_engine_reproduces_reference_tpl_search(name):
 STAT_FIELDS = ("srcrf_dist", "recrf_dist", "srcrf_rate", "recrf_rate")
 
 
-@pytest.mark.parametrize("name", sorted(n for n in tpl_cases.CASES if not n.startswith("tpl7")))
+@pytest.mark.parametrize("name", sorted(tpl_cases.CASES))
 def test_engine_reproduces_reference_tpl_reconstruction(name):
     """svtme_tpl_recon on the engine's own search results: the reconstructed picture's hash and every block's statistics as
-    the real reference's dispenser left them (16x16 blocks: 16x16 and 16x8 transforms, DC and all thirteen intra modes)."""
+    the real reference's dispenser left them (16x16 blocks: 16x16 and 16x8 transforms, DC and all thirteen intra modes; 32x32
+    blocks with the 32x8 transform and 16x4 in incomplete 64x64 blocks)."""
     frames, pics, per = load_case(name, tpl_cases.CASES[name])
     g = np.load(os.path.join(GOLDEN, name + ".npz"))
     eng = _engine(frames)
@@ -91,6 +92,8 @@ def test_random_reconstructions_match_the_restatement(seed):
                 subsample_tx=0, pf_shape=int(rng.integers(0, 3)))
     if not all_modes and ctrl["use_pred_sad_in_intra_search"] and ctrl["use_pred_sad_in_inter_search"]:
         ctrl["subsample_tx"] = int(rng.integers(0, 3))
+        if seed % 4 == 1:  # 32x32 blocks (32x8), 16x16 blocks with 16x4 in the 64x64 blocks the picture cuts
+            ctrl.update(dispenser_search_level=1, subsample_tx=2)
     dq = [int(rng.integers(4, 1400)), int(rng.integers(4, 1900))]
     quant = ([int(rng.integers(0, 1 + d)) for d in dq], [min(32767, int(rng.integers(1, 3)) * 32768 // d) for d in dq], dq)
     import svtme
@@ -121,8 +124,9 @@ def test_reconstruction_refuses_what_it_does_not_do():
         ctrl, me, tb, quant = per[1]
         p, keep, refs = picture_of(frames, pics[1], ctrl, me, quant=quant)
         blocks = eng.tpl_search(p)
-        for change in (dict(dispenser_search_level=1), dict(dispenser_search_level=2), dict(pf_shape=3), dict(subsample_tx=3),
-                       dict(tpl_opt_flag=0, subsample_tx=1)):
+        for change in (dict(dispenser_search_level=1, subsample_tx=0), dict(dispenser_search_level=1, subsample_tx=1),
+                       dict(dispenser_search_level=1, subsample_tx=2, tpl_opt_flag=0), dict(dispenser_search_level=2), dict(pf_shape=3),
+                       dict(subsample_tx=3), dict(tpl_opt_flag=0, subsample_tx=1)):
             q, keep2, _ = picture_of(frames, pics[1], dict(ctrl, **change), me, quant=quant)
             with pytest.raises(svtme.SvtmeError) as ei:
                 eng.tpl_recon(q, blocks)
