@@ -39,8 +39,18 @@ def digest(recs):
     return h.hexdigest()
 
 
+def stats_digest(recs):
+    """sha256 over the statistics the dispenser's reconstruction path left for the valid blocks of every picture."""
+    h = hashlib.sha256()
+    for pd, bd, tp, tb in recs:
+        v = tb["valid"] == 1
+        for f in tpl_cases.STAT_FIELDS:
+            h.update(np.ascontiguousarray(np.where(v, tb[f], 0)).tobytes())
+    return h.hexdigest()
+
+
 def main():
-    for name, c in {**tpl_cases.CASES, **tpl_cases.UNSUPPORTED_CASES}.items():
+    for name, c in ({} if "--digests-only" in sys.argv else {**tpl_cases.CASES, **tpl_cases.UNSUPPORTED_CASES}).items():
         frames, pics, recs = run(c)
         out = {"n_pics": np.int32(len(recs))}
         for i, (pd, bd, tp, tb) in enumerate(recs):
@@ -60,7 +70,7 @@ def main():
     for name, c in tpl_cases.DIGEST_CASES.items():
         frames, pics, recs = run(c)
         pd0 = recs[0][0]
-        dig[name] = dict(sha256=digest(recs), controls=[tplio.controls_of(r[2]) for r in recs],
+        dig[name] = dict(sha256=digest(recs), stats_sha256=stats_digest(recs), recon_hash=[int(r[2]["recon_hash"]) for r in recs], controls=[tplio.controls_of(r[2]) for r in recs],
                          quant=[list(q) for q in tplio.quant_of(recs[0][2])],
                          me_shape={k: int(pd0[k]) for k in ("enable_me_8x8", "enable_me_16x16", "max_cand", "max_refs", "max_l0",
                                                             "input_resolution")})

@@ -46,7 +46,7 @@ def test_engine_reproduces_reference_tpl_search(name):
         eng.close()
 
 
-STAT_FIELDS = ("srcrf_dist", "recrf_dist", "srcrf_rate", "recrf_rate")
+STAT_FIELDS = tpl_cases.STAT_FIELDS
 
 
 @pytest.mark.parametrize("name", sorted(tpl_cases.CASES))
@@ -252,7 +252,9 @@ def test_unsupported_controls_and_bad_arguments():
 
 def test_1080p_search_on_the_engines_own_me_results_equals_the_reference_digest():
     """The whole chain on the device at the benchmark's size: open-loop ME with the device tail, whose candidate and vector
-    arrays (bit-exact with the reference's, test_gpu_parity) feed the TPL search; the digest is the real reference's."""
+    arrays (bit-exact with the reference's, test_gpu_parity) feed the TPL search, whose block records feed the reconstruction
+    path; the digests of the search results and of the statistics and the reconstructed pictures' hashes are the real
+    reference's."""
     import svtme
     name, c = next(iter(tpl_cases.DIGEST_CASES.items()))
     want = json.load(open(os.path.join(GOLDEN, "tpl_digests.json")))[name]
@@ -267,7 +269,7 @@ def test_1080p_search_on_the_engines_own_me_results_equals_the_reference_digest(
         for i in range(n):
             eng.store_put(i + 1, i, frames[i])
         ctrl_me = svtme.derive_controls(c["enc_mode"], w, h, 0, 30 << 16)
-        hsh = hashlib.sha256()
+        hsh, stats_hsh, recon_hashes = hashlib.sha256(), hashlib.sha256(), []
         for pic, ctrl in zip(pics, want["controls"]):
             desc = eng.make_picture(w, h, pic.poc, pic.temporal_layer, pic.is_ref, pic.refs, ctrl_me, tail=tail, key_of=lambda poc: poc + 1)
             out = eng.run_picture(desc)
@@ -279,7 +281,13 @@ def test_1080p_search_on_the_engines_own_me_results_equals_the_reference_digest(
             got = eng.tpl_search(p)
             for f in tpl_cases.SEARCH_FIELDS:
                 hsh.update(np.ascontiguousarray(got[f]).tobytes())
+            stats, recon = eng.tpl_recon(p, got)
+            for f in tpl_cases.STAT_FIELDS:
+                stats_hsh.update(np.ascontiguousarray(stats[f]).tobytes())
+            recon_hashes.append(tplio.recon_hash(recon))
         assert hsh.hexdigest() == want["sha256"]
+        assert stats_hsh.hexdigest() == want["stats_sha256"]
+        assert recon_hashes == want["recon_hash"]
     finally:
         eng.close()
 

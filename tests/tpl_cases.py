@@ -36,5 +36,8 @@ SEARCH_FIELDS = ("valid", "best_intra_cost", "best_inter_cost", "mv_x", "mv_y", 
                  "src_recon_error", "src_rate")
 
 
+STAT_FIELDS = ("srcrf_dist", "recrf_dist", "srcrf_rate", "recrf_rate")
+
+
 def job_args(c):
     return {k: c[k] for k in ("width", "height", "n_frames", "enc_mode", "seed", "structure", "kind", "motion") if k in c}

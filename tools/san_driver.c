@@ -463,7 +463,42 @@ static uint64_t run_extras(uint32_t w, uint32_t h, uint32_t seed, uint64_t hsh) 
                     if (blk[i].valid && (blk[i].src_recon_error > 0) != (blk[i].best_is_inter != 0)) EXPECT(-123, SVTME_OK);
                 hsh = fnv(hsh, blk, sizeof(*blk) * (size_t)n_b64 * SVTME_TPL_BLOCKS);
             }
+        /* the reconstruction path on those answers: every transform the tpl levels use, with and without the picture coming
+           back; the reconstructed picture put back into the store as a reference of the next call */
+        {
+            svtme_tpl_stats *st  = (svtme_tpl_stats *)calloc((size_t)n_b64 * SVTME_TPL_BLOCKS, sizeof(*st));
+            uint8_t         *rec = (uint8_t *)malloc((size_t)w * h);
+            tp.pf_shape = 1;
+            tp.use_pred_sad_in_intra_search = tp.use_pred_sad_in_inter_search = 1;
+            for (int form = 0; form < 4; ++form) { /* 16x16, 16x8, 16x4 on 16x16 blocks; 32x8 on 32x32 blocks */
+                tp.dispenser_search_level = form == 3;
+                tp.subsample_tx           = (uint8_t)(form == 3 ? 2 : form);
+                CHECK(svtme_tpl_search(eng, &tp, blk));
+                CHECK(svtme_tpl_recon(eng, &tp, blk, st, form & 1 ? rec : NULL, w));
+                for (uint32_t i = 0; i < n_b64 * SVTME_TPL_BLOCKS; ++i)
+                    if ((st[i].recrf_dist > 0) != (blk[i].valid != 0) || st[i].recrf_dist < st[i].srcrf_dist) EXPECT(-126, SVTME_OK);
+                hsh = fnv(hsh, st, sizeof(*st) * (size_t)n_b64 * SVTME_TPL_BLOCKS);
+                if (form & 1) hsh = fnv(hsh, rec, (size_t)w * h);
+            }
+            CHECK(svtme_store_put(eng, 150, 7, rec, w, w, h));
+            tp.ref_key[0][0] = 150;
+            CHECK(svtme_tpl_recon(eng, &tp, blk, st, NULL, 0));
+            hsh = fnv(hsh, st, sizeof(*st) * (size_t)n_b64 * SVTME_TPL_BLOCKS);
+            tp.ref_key[0][0] = 100;
+            CHECK(svtme_store_release(eng, 150));
+            EXPECT(svtme_tpl_recon(eng, &tp, blk, NULL, NULL, 0), SVTME_ERR_BAD_ARG);
+            EXPECT(svtme_tpl_recon(eng, &tp, blk, st, rec, w - 8), SVTME_ERR_BAD_ARG);
+            tp.subsample_tx = 1; /* 32x32 blocks come with the 32x8 transform only */
+            EXPECT(svtme_tpl_recon(eng, &tp, blk, st, NULL, 0), SVTME_ERR_UNSUPPORTED);
+            tp.dispenser_search_level = 0;
+            tp.subsample_tx = 0;
+            tp.pf_shape     = 0;
+            blk[5].valid = 1, blk[5].best_is_inter = 1, blk[5].best_rf_idx = 6; /* a reference the picture does not have */
+            EXPECT(svtme_tpl_recon(eng, &tp, blk, st, NULL, 0), SVTME_ERR_BAD_ARG);
+            free(st); free(rec);
+        }
         tp.dispenser_search_level = 1; /* 32x32 blocks have no 16x16 transform */
+        tp.use_pred_sad_in_intra_search = tp.use_pred_sad_in_inter_search = 0;
         EXPECT(svtme_tpl_search(eng, &tp, blk), SVTME_ERR_UNSUPPORTED);
         tp.tpl_opt_flag = 0; /* every intra mode: 16x16 blocks only */
         tp.intra_mode_end = 12;
