@@ -641,6 +641,15 @@ typedef struct svtme_tpl_stats {
 } svtme_tpl_stats;
 int svtme_tpl_recon(svtme_engine *e, const svtme_tpl_picture *pic, const svtme_tpl_block *blocks /* [n_b64][SVTME_TPL_BLOCKS] */,
                     svtme_tpl_stats *stats /* [n_b64][SVTME_TPL_BLOCKS] */, uint8_t *recon, uint32_t recon_stride);
+/*
+ * Keeps the picture the engine's last successful svtme_tpl_recon reconstructed as a picture of the store under `key`, device
+ * to device: what the dispenser's caller does with encode_context_ptr->mc_flow_rec_picture_buffer[frame_idx] for the later
+ * pictures of the TPL group that reference it (tpl_mc_flow_dispenser pads it with generate_padding,
+ * EbSourceBasedOperationsProcess.c:1408-1414; references inside the group are read from there, :1011-1017). The store builds
+ * its padded planes from the reconstruction as svtme_store_put builds them from a source picture - no copy to the host and
+ * back. SVTME_ERR_NOT_FOUND without a reconstructed picture; otherwise svtme_store_put's codes. Release the key like any other.
+ */
+int svtme_tpl_recon_keep(svtme_engine *e, uint64_t key, uint64_t picture_number);
 
 const char *svtme_version(void);
 

@@ -141,6 +141,12 @@ struct GmState {
     // svtme_tpl_recon: block records, statistics, the picture's record and the reconstructed picture (first call allocates)
     uint8_t *d_rec = nullptr, *h_rec = nullptr;
     size_t   rec_bytes = 0;
+    // the picture the last svtme_tpl_recon left in d_rec (svtme_tpl_recon_keep builds store planes from it): where, and the
+    // events "reconstructed" (on the calls' stream) and "read by the store kernels" (on a store stream)
+    size_t     rec_pic_off = 0, rec_pic_stride = 0;
+    uint32_t   rec_w = 0, rec_h = 0;
+    hipEvent_t rec_done = nullptr, rec_read = nullptr;
+    bool       rec_read_pending = false;
 };
 constexpr size_t kGmCornerInts = 2 + 2 * (size_t)SVTME_GM_MAX_CORNERS, kGmMatchInts = 5 * (size_t)SVTME_GM_MAX_CORNERS;
 
@@ -396,6 +402,8 @@ extern "C" void svtme_destroy(svtme_engine *e) {
         if (g.h_buf) (void)hipHostFree(g.h_buf);
         if (g.h_tpl) (void)hipHostFree(g.h_tpl);
         if (g.h_rec) (void)hipHostFree(g.h_rec);
+        if (g.rec_done) (void)hipEventDestroy(g.rec_done);
+        if (g.rec_read) (void)hipEventDestroy(g.rec_read);
     }
     for (auto sm : e->s_me)
         if (sm) (void)hipStreamDestroy(sm);
@@ -409,13 +417,17 @@ extern "C" void svtme_destroy(svtme_engine *e) {
 // (height - 1) * stride + width bytes), the store kernels pick the pixels out of the strided copy; the caller keeps the
 // buffer unchanged until the planes are built. Otherwise the rows are packed into the slot's pinned staging buffer first
 // and the caller's buffer is free on return.
+// dev_src: the picture lies in device memory already (rows `stride` apart, complete once `after` has happened): no staging,
+// no upload; `done` (optional) is recorded behind the store kernels that read it.
 static int store_put_impl(svtme_engine *e, uint64_t key, uint64_t picture_number, const uint8_t *luma, uint32_t stride,
-                          uint32_t width, uint32_t height, bool pinned) {
+                          uint32_t width, uint32_t height, bool pinned, const uint8_t *dev_src = nullptr, hipEvent_t after = nullptr,
+                          hipEvent_t done = nullptr) {
+    if (dev_src) luma = dev_src, pinned = true; // (neither is read as host memory below)
     if (!e || !luma || width < 64 || height < 64 || width % 8 || height % 8 || width > e->cfg.max_width ||
         height > e->cfg.max_height || stride < width)
         return SVTME_ERR_BAD_ARG;
     // a strided copy needs dword-aligned rows and has to fit the upload buffer; anything else takes the packing path
-    if (pinned && (stride % 4 || stride - width > kMaxExtraStride)) pinned = false;
+    if (pinned && !dev_src && (stride % 4 || stride - width > kMaxExtraStride)) pinned = false;
     DEVICE_OR_FAIL(e->cfg.device);
     int      si;
     bool     fresh, wait_upload;
@@ -486,10 +498,19 @@ static int store_put_impl(svtme_engine *e, uint64_t key, uint64_t picture_number
     s.gen = ++e->put_gen;
     size_t plane_bytes;
     layout_planes(s.mem, width, height, &s.pic, &plane_bytes);
-    if (err == hipSuccess) err = hipMemcpyAsync(e->d_upload[ring], src, bytes, hipMemcpyHostToDevice, ss);
-    if (err == hipSuccess) {
-        launch_store_build(e->d_upload[ring], (int)src_stride, s.pic, 1, ss);
-        err = hipGetLastError();
+    if (dev_src) {
+        if (err == hipSuccess && after) err = hipStreamWaitEvent(ss, after, 0);
+        if (err == hipSuccess) {
+            launch_store_build(dev_src, (int)stride, s.pic, 1, ss);
+            err = hipGetLastError();
+        }
+        if (err == hipSuccess && done) err = hipEventRecord(done, ss);
+    } else {
+        if (err == hipSuccess) err = hipMemcpyAsync(e->d_upload[ring], src, bytes, hipMemcpyHostToDevice, ss);
+        if (err == hipSuccess) {
+            launch_store_build(e->d_upload[ring], (int)src_stride, s.pic, 1, ss);
+            err = hipGetLastError();
+        }
     }
     if (err == hipSuccess) err = hipEventRecord(s.ready, ss);
     s.putting = false;
@@ -1816,6 +1837,14 @@ extern "C" int svtme_tpl_recon(svtme_engine *e, const svtme_tpl_picture *pic, co
     }
     const size_t rec_stride = ((size_t)pic->width + 63) / 64 * 64, list_off = par_off + (sizeof(TplParams) + 63) / 64 * 64;
     const size_t rec_off = (list_off + (size_t)bw16 * bh16 * 4 + 63) / 64 * 64, total = rec_off + rec_stride * pic->height;
+    if (!g.rec_done && (hipEventCreateWithFlags(&g.rec_done, hipEventDisableTiming) != hipSuccess ||
+                        hipEventCreateWithFlags(&g.rec_read, hipEventDisableTiming) != hipSuccess))
+        return SVTME_ERR_NO_RESOURCES;
+    g.rec_w = g.rec_h = 0; // nothing to keep until this call has succeeded
+    if (g.rec_read_pending) { // store kernels of svtme_tpl_recon_keep may still read the last picture
+        if (hipEventSynchronize(g.rec_read) != hipSuccess) return SVTME_ERR_DEVICE;
+        g.rec_read_pending = false;
+    }
     if (g.rec_bytes < total) {
         if (g.d_rec) (void)hipFree(g.d_rec);
         if (g.h_rec) (void)hipHostFree(g.h_rec);
@@ -1881,11 +1910,28 @@ extern "C" int svtme_tpl_recon(svtme_engine *e, const svtme_tpl_picture *pic, co
     GM_TRY(hipGetLastError());
     GM_TRY(hipMemcpyAsync(g.h_rec + stat_off, g.d_rec + stat_off, stat_bytes, hipMemcpyDeviceToHost, st));
     if (recon) GM_TRY(hipMemcpyAsync(g.h_rec + rec_off, g.d_rec + rec_off, rec_stride * pic->height, hipMemcpyDeviceToHost, st));
+    GM_TRY(hipEventRecord(g.rec_done, st));
     GM_TRY(hipStreamSynchronize(st));
+    g.rec_pic_off    = rec_off;
+    g.rec_pic_stride = rec_stride;
+    g.rec_w          = pic->width;
+    g.rec_h          = pic->height;
     memcpy(stats, g.h_rec + stat_off, stat_bytes);
     if (recon)
         for (uint32_t y = 0; y < pic->height; ++y) memcpy(recon + (size_t)y * recon_stride, g.h_rec + rec_off + (size_t)y * rec_stride, pic->width);
     return SVTME_OK;
+}
+
+extern "C" int svtme_tpl_recon_keep(svtme_engine *e, uint64_t key, uint64_t picture_number) {
+    if (!e) return SVTME_ERR_BAD_ARG;
+    DEVICE_OR_FAIL(e->cfg.device);
+    std::lock_guard<std::mutex> gm_lock(e->gm.mu);
+    GmState &g = e->gm;
+    if (!g.rec_w) return SVTME_ERR_NOT_FOUND; // no reconstructed picture: no call yet, or the last one failed
+    const int rc = store_put_impl(e, key, picture_number, nullptr, (uint32_t)g.rec_pic_stride, g.rec_w, g.rec_h, true, g.d_rec + g.rec_pic_off,
+                                  g.rec_done, g.rec_read);
+    if (rc == SVTME_OK) g.rec_read_pending = true;
+    return rc;
 }
 
 // Diagnostic, not part of the public header: resident workgroups per CU of {hme_l0, hme_l12, me_search}.

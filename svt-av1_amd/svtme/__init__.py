@@ -122,7 +122,7 @@ EXPORTS = ("svtme_version", "svtme_derive_controls", "svtme_derive_tf_controls",
            "svtme_group_engine_for", "svtme_group_gm_set_tables",
            "svtme_gm_set_tables", "svtme_gm_corners", "svtme_gm_correspondences", "svtme_gm_warp_error", "svtme_gm_frame_error",
            "svtme_gm_refine",
-           "svtme_tpl_search", "svtme_tpl_recon", "svtme_set_tile_rects", "svtme_group_set_tile_rects",
+           "svtme_tpl_search", "svtme_tpl_recon", "svtme_tpl_recon_keep", "svtme_set_tile_rects", "svtme_group_set_tile_rects",
            "svtme_store_put_many", "svtme_store_copy_peer", "svtme_group_pictures_submit", "svtme_group_ticket_engine",
            "svtme_group_set_peer_copies", "svtme_group_peer_stats")
 MAX_BATCH = 32
@@ -236,6 +236,7 @@ def load_library():
                                     C.POINTER(C.c_uint32)]
     lib.svtme_tpl_search.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
     lib.svtme_tpl_recon.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32]
+    lib.svtme_tpl_recon_keep.argtypes = [C.c_void_p, C.c_uint64, C.c_uint64]
     lib.svtme_set_tile_rects.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p, C.c_uint32]
     lib.svtme_group_set_tile_rects.argtypes = lib.svtme_set_tile_rects.argtypes
     _lib = lib
@@ -708,6 +709,12 @@ class Engine:
         if rc:
             raise SvtmeError(rc, "svtme_tpl_recon")
         return stats, recon
+
+    def tpl_recon_keep(self, key, picture_number=0):
+        """svtme_tpl_recon_keep: the last reconstructed picture becomes a picture of the store under `key`, device to device."""
+        rc = self.lib.svtme_tpl_recon_keep(self.h, key, picture_number)
+        if rc:
+            raise SvtmeError(rc, "svtme_tpl_recon_keep")
 
     def timing(self, ticket):
         ms = (C.c_float * 8)()

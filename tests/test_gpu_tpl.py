@@ -116,6 +116,55 @@ def test_random_reconstructions_match_the_restatement(seed):
         eng.close()
 
 
+@pytest.mark.parametrize("seed", range(4))
+def test_kept_reconstruction_serves_as_reference_of_the_next_picture(seed):
+    """svtme_tpl_recon_keep: the reconstructed picture becomes a store picture device to device; a second picture that names it
+    as its reference gives, in search and reconstruction, what the restatement gives with the first one's reconstruction as
+    reference picture - and what the engine gives when that reconstruction is put from the host."""
+    import svtme
+    rng = np.random.default_rng(9000 + seed)
+    w, h = int(rng.integers(8, 40)) * 8, int(rng.integers(8, 30)) * 8
+    frames = support.make_job(w, h, 3, 8, seed=seed + 31, kind=["synth", "noise"][seed & 1])[0]
+    n_b64 = ((w + 63) // 64) * ((h + 63) // 64)
+    ctrl = dict(dispenser_search_level=0, disable_intra_pred=0, tpl_opt_flag=1, use_pred_sad_in_intra_search=1,
+                use_pred_sad_in_inter_search=1, subsample_tx=int(seed % 3), pf_shape=1)
+    quant = ([20, 24], [1638, 1365], [40, 48])
+    eng = svtme.Engine(w, h, store_slots=6, max_in_flight=2)
+    try:
+        with pytest.raises(svtme.SvtmeError) as ei:
+            eng.tpl_recon_keep(50)
+        assert ei.value.code == svtme.ERR_NOT_FOUND
+        for i in range(3):
+            eng.store_put(i + 1, i, frames[i])
+        me = _random_me(rng, n_b64, 85, (1, 0), 64)
+        # the first picture: frame 1 predicted from frame 0
+        p1, keep1 = tplio.make_picture(w, h, ctrl, me, cur_key=2, ref_keys=([1], []), quant=quant)
+        b1 = eng.tpl_search(p1)
+        stats1, recon1 = eng.tpl_recon(p1, b1)
+        want_recon1, want_stats1 = tplio.oracle_recon(frames[1], {(0, 0): frames[0]}, p1, b1)
+        assert np.array_equal(recon1, want_recon1)
+        eng.tpl_recon_keep(50, 1)
+        eng.store_put(51, 1, recon1)  # the same picture by way of the host
+        # the second picture: frame 2 predicted from the first one's reconstruction
+        outs = []
+        for key in (50, 51):
+            p2, keep2 = tplio.make_picture(w, h, ctrl, me, cur_key=3, ref_keys=([key], []), quant=quant)
+            b2 = eng.tpl_search(p2)
+            outs.append((b2,) + eng.tpl_recon(p2, b2))
+        want_b2 = tplio.oracle_search(frames[2], {(0, 0): want_recon1}, p2)
+        want_recon2, want_stats2 = tplio.oracle_recon(frames[2], {(0, 0): want_recon1}, p2, want_b2)
+        for b2, stats2, recon2 in outs:
+            assert_blocks_equal(b2, want_b2, "second picture")
+            for f in STAT_FIELDS:
+                assert np.array_equal(stats2[f], want_stats2[f]), f
+            assert np.array_equal(recon2, want_recon2)
+        eng.store_release(50)
+        eng.tpl_recon_keep(50, 2)  # the second picture's reconstruction under the released key
+        eng.store_release(50)
+    finally:
+        eng.close()
+
+
 def test_reconstruction_refuses_what_it_does_not_do():
     import svtme
     frames, pics, per = load_case("tpl4_m8_200x136", tpl_cases.CASES["tpl4_m8_200x136"])

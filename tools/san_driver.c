@@ -480,12 +480,13 @@ static uint64_t run_extras(uint32_t w, uint32_t h, uint32_t seed, uint64_t hsh) 
                 hsh = fnv(hsh, st, sizeof(*st) * (size_t)n_b64 * SVTME_TPL_BLOCKS);
                 if (form & 1) hsh = fnv(hsh, rec, (size_t)w * h);
             }
-            CHECK(svtme_store_put(eng, 150, 7, rec, w, w, h));
+            CHECK(svtme_tpl_recon_keep(eng, 150, 7)); /* device to device */
             tp.ref_key[0][0] = 150;
             CHECK(svtme_tpl_recon(eng, &tp, blk, st, NULL, 0));
             hsh = fnv(hsh, st, sizeof(*st) * (size_t)n_b64 * SVTME_TPL_BLOCKS);
             tp.ref_key[0][0] = 100;
             CHECK(svtme_store_release(eng, 150));
+            EXPECT(svtme_tpl_recon_keep(NULL, 150, 7), SVTME_ERR_BAD_ARG);
             EXPECT(svtme_tpl_recon(eng, &tp, blk, NULL, NULL, 0), SVTME_ERR_BAD_ARG);
             EXPECT(svtme_tpl_recon(eng, &tp, blk, st, rec, w - 8), SVTME_ERR_BAD_ARG);
             tp.subsample_tx = 1; /* 32x32 blocks come with the 32x8 transform only */
