@@ -1792,6 +1792,14 @@ extern "C" int svtme_tpl_recon(svtme_engine *e, const svtme_tpl_picture *pic, co
             continue;
         }
         if (b.best_rf_idx < 0 || b.best_rf_idx > 7 || (b.best_rf_idx & 3) >= pic->n_ref[b.best_rf_idx >> 2]) return SVTME_ERR_BAD_ARG;
+        // the vector keeps the predicted block within TPL_PADX / TPL_PADY pixels of the picture, as the search's clamp leaves it
+        // (:853-876): the planes' borders are what the kernels may read
+        const int bi = (int)(i % SVTME_TPL_BLOCKS), sb = (int)(i / SVTME_TPL_BLOCKS);
+        if (bi == 0) return SVTME_ERR_BAD_ARG; // (64x64 blocks: dispenser_search_level 2)
+        const int S = bi < 5 ? 32 : 16, q = bi < 5 ? bi - 1 : (bi - 5) >> 2, in_q = (bi - 5) & 3;
+        const int x = (sb % b64_w) * 64 + (q & 1) * 32 + (bi < 5 ? 0 : (in_q & 1) * 16), y = (sb / b64_w) * 64 + (q >> 1) * 32 + (bi < 5 ? 0 : (in_q >> 1) * 16);
+        const int px = x + (b.mv_x >> 3), py = y + (b.mv_y >> 3);
+        if (px < -32 || px + S > 32 + (int)pic->width - 1 || py < -32 || py + S > 32 + (int)pic->height - 1) return SVTME_ERR_BAD_ARG;
     }
     DEVICE_OR_FAIL(e->cfg.device);
     std::lock_guard<std::mutex> gm_lock(e->gm.mu);

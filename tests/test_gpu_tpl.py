@@ -186,6 +186,11 @@ def test_reconstruction_refuses_what_it_does_not_do():
         with pytest.raises(svtme.SvtmeError) as ei:
             eng.tpl_recon(p, bad)
         assert ei.value.code == svtme.ERR_BAD_ARG
+        bad = blocks.copy()
+        bad["mv_x"][tuple(inter)] = 8 * 4000  # a vector that leaves the reference picture's border
+        with pytest.raises(svtme.SvtmeError) as ei:
+            eng.tpl_recon(p, bad)
+        assert ei.value.code == svtme.ERR_BAD_ARG
     finally:
         eng.close()
 
