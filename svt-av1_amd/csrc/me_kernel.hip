@@ -902,7 +902,8 @@ __global__ void __launch_bounds__(256) params_write_kernel(const uint32_t *__res
 
 void launch_params_write(const PicParams *host, PicParams *dev, int n, hipStream_t s) {
     const int n_words = n * (int)(sizeof(PicParams) / 4);
-    hipLaunchKernelGGL(params_write_kernel, dim3((n_words + 1023) / 1024), dim3(256), 0, s, reinterpret_cast<const uint32_t *>(host),
+    // (a word per thread: every read crosses the host link, so they all go out at once - one round trip, not four)
+    hipLaunchKernelGGL(params_write_kernel, dim3((n_words + 255) / 256), dim3(256), 0, s, reinterpret_cast<const uint32_t *>(host),
                        reinterpret_cast<uint32_t *>(dev), n_words);
 }
 
