@@ -8,27 +8,46 @@ namespace svtme {
 
 // Zero-MV SAD of every (b64, reference) for the controls with me_early_exit_th (init_zz_sad :2318-2333, get_zz_sad
 // :1720-1742: the 64x64 block on every other row, x2), once instead of in each of the six level-0 / pre-HME items that
-// test it; also the per-reference header fields. One wave per (b64, reference).
+// test it; also the per-reference header fields. Four blocks per wave, 16 lanes each: a lane takes one dword column of the
+// block's 32 sampled rows, all 64 loads in flight together (the kernel is one memory round trip and a reduction: a quarter
+// of the waves for the same bytes).
 template <class PICS>
 __global__ void __launch_bounds__(HI_THREADS) hme_zz_kernel(PICS pp) {
-    const auto &p   = pp[blockIdx.z];
-    const int   b64 = blockIdx.x;
-    if (b64_left_out(p, b64)) return;
-    int b64x, b64y;
-    b64_origin(p, b64, b64x, b64y);
-    const int block_w = min(p.width - b64x, 64), block_h = min(p.height - b64y, 64);
-    int       l = 0, r = (int)blockIdx.y;
+    const auto &p    = pp[blockIdx.z];
+    const int   lane = threadIdx.x & 63, d = lane & 15;
+    const int   b64  = (int)blockIdx.x * 4 + (lane >> 4);
+    int         l = 0, r = (int)blockIdx.y;
     if (r >= p.n_ref[0] + (p.n_list == 2 ? p.n_ref[1] : 0)) return; // the grid covers the batch's longest reference list
     if (r >= p.n_ref[0]) {
         r -= p.n_ref[0];
         l = 1;
     }
+    const bool item = b64 < p.b64_w * p.b64_h && !b64_left_out(p, min(b64, p.b64_w * p.b64_h - 1));
+    int        b64x, b64y;
+    b64_origin(p, item ? b64 : 0, b64x, b64y);
+    const int  block_w = min(p.width - b64x, 64), block_h = min(p.height - b64y, 64), bwd = block_w >> 2, rows = block_h >> 1;
     const bool searched = ref_searched(p, l);
     uint32_t   zz = ~0u;
-    if (searched) zz = wave_block_sad_sub2(load_plane(p.cur.lvl[2]), load_plane(p.ref[l][r].lvl[2]), b64x, b64y, 0, 0, block_w, block_h >> 1) << 1;
-    if (threadIdx.x == 0) {
+    if (searched) {
+        const DevPlane cur = load_plane(p.cur.lvl[2]), ref = load_plane(p.ref[l][r].lvl[2]);
+        uint32_t       sv[32], fv[32];
+#pragma unroll
+        for (int k = 0; k < 32; ++k) {
+            const bool on = item && d < bwd && k < rows;
+            const int  rc = on ? k : 0, dc = on ? d : 0; // idle lanes repeat a valid address
+            sv[k] = *reinterpret_cast<const uint32_t *>(cur.pix + (ptrdiff_t)(b64y + 2 * rc) * cur.stride + b64x + 4 * dc);
+            fv[k] = *reinterpret_cast<const uint32_t *>(ref.pix + (ptrdiff_t)(b64y + 2 * rc) * ref.stride + b64x + 4 * dc);
+        }
+        uint32_t acc = 0;
+#pragma unroll
+        for (int k = 0; k < 32; ++k) acc = __builtin_amdgcn_sad_u8(sv[k], (item && d < bwd && k < rows) ? fv[k] : sv[k], acc);
+#pragma unroll
+        for (int m = 1; m < 16; m <<= 1) acc += __shfl_xor(acc, m); // the block's 16 lanes
+        zz = acc << 1;
+    }
+    if (item && d == 0) {
         HmeRefOut *out = &p.hme_out[(b64 * SVTME_MAX_LISTS + l) * SVTME_MAX_REFS + r];
-        if (searched) count_ops(p, 0, (unsigned long long)(block_h >> 1) * block_w);
+        if (searched) count_ops(p, 0, (unsigned long long)rows * block_w);
         out->zz_sad = zz;
         out->valid  = searched ? 1u : 0u;
     }
@@ -125,7 +144,7 @@ static void launch_hme_items_as(const Batch &b, PICS pics, hipStream_t s, hipEve
     bool       deps = false;
     for (int i = 0; i < b.n; ++i) deps = deps || b.host[i].dep_pre || b.host[i].dep_l0;
     const int n_phase = deps ? 2 : 1;
-    if (p0.ctrl.me_early_exit_th) hipLaunchKernelGGL(hme_zz_kernel<PICS>, dim3(n_b64, n_refs, b.n), dim3(HI_THREADS), 0, s, pics);
+    if (p0.ctrl.me_early_exit_th) hipLaunchKernelGGL(hme_zz_kernel<PICS>, dim3((n_b64 + 3) / 4, n_refs, b.n), dim3(HI_THREADS), 0, s, pics);
     for (int phase = 1; phase <= n_phase; ++phase) {
         const int hme_phase = n_phase == 1 ? 0 : phase;
         if (fs) hipLaunchKernelGGL((hme_l0_kernel<true, PICS>), g0, dim3(HI_THREADS), 0, s, pics, n_refs, refs_magic, hme_phase, 0);
