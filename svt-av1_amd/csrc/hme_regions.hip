@@ -10,7 +10,8 @@ namespace svtme {
 // set-up paid once instead of four times. A block or a window outside that shape (a picture's right / bottom edge) goes
 // through small_search region by region. (The first pass's 8 x 8 windows keep a work item per region: with two trips per
 // search the saving is smaller than what the larger item costs in resident waves.)
-template <class P>
+// L2 false: the controls have no level 2 (presets 7 and faster): that level's code, source block and windows are left out.
+template <bool L2, class P>
 __device__ __forceinline__ void l12_regions(const P &p, const uint32_t *src1, const uint32_t *src2, uint32_t *win, int b64x, int b64y,
                                             int block_w, int block_h, int l, int r, HmeRefOut *rec) {
     const auto &k    = p.ctrl;
@@ -48,7 +49,7 @@ __device__ __forceinline__ void l12_regions(const P &p, const uint32_t *src1, co
             }
         }
     }
-    for (int level = 1; level <= 2; ++level) {
+    for (int level = 1; level <= (L2 ? 2 : 1); ++level) {
         // a level that does not run, or level 1 on the early exit (:2032-2040; level 2 has none), leaves zeros
         if ((level == 1 ? !k.enable_hme_level1_flag : !k.enable_hme_level2_flag) || (level == 1 && early)) {
 #pragma unroll
@@ -92,7 +93,7 @@ __device__ __forceinline__ void l12_regions(const P &p, const uint32_t *src1, co
 #pragma unroll
             for (int q = 0; q < 4; ++q) key[q] = quick_scan<8, 3>(src, win + q * QuickGeo<8, 3>::WIN, rows, hh[q]);
             wave_sync();
-        } else if (quick) { // the 64-pixel block's windows: two at a time
+        } else if (quick && L2) { // the 64-pixel block's windows: two at a time
 #pragma unroll
             for (int half = 0; half < 2; ++half) {
                 const int wxp[2] = {wx[2 * half], wx[2 * half + 1]}, wyp[2] = {wy[2 * half], wy[2 * half + 1]};
@@ -124,12 +125,15 @@ __device__ __forceinline__ void l12_regions(const P &p, const uint32_t *src1, co
 
 constexpr int HI_WIN2_DWORDS_ALL = 2 * QuickGeo<16, 3>::WIN > 4 * QuickGeo<8, 3>::WIN ? 2 * QuickGeo<16, 3>::WIN : 4 * QuickGeo<8, 3>::WIN;
 static_assert(HI_WIN2_DWORDS_ALL * 4 >= HI_WIN2_BYTES, "small_search's window fits too");
+static_assert(HI_WIN2_BYTES / 4 >= 4 * QuickGeo<8, 3>::WIN, "and so do the four level-1 windows where small_search's sets the size");
 
-// One wave per (b64, reference): the 2 x 2 regions' levels 1 and 2 (sub-sampled searches only).
-template <class PICS>
+// One wave per (b64, reference): the 2 x 2 regions' levels 1 and 2 (sub-sampled searches only). Without level 2 the work item
+// needs 7.7 KB of LDS instead of 13.4 KB: four and more resident items per SIMD instead of 2.75.
+template <class PICS, bool L2>
 __global__ void __launch_bounds__(HI_THREADS) hme_l12_regions_kernel(PICS pp) {
-    __shared__ L12Shared<false>       S;
-    __shared__ __align__(16) uint32_t win[HI_WIN2_DWORDS_ALL + 64];
+    __shared__ __align__(16) uint32_t src1[16 * kSrcPitch<false>]; // sampled rows of the quarter-resolution 32x32 block
+    __shared__ __align__(16) uint32_t src2[L2 ? 32 * kSrcPitch<false> : 4]; // of the full-resolution 64x64 block
+    __shared__ __align__(16) uint32_t win[(L2 ? HI_WIN2_DWORDS_ALL : HI_WIN2_BYTES / 4) + 64];
     const auto &p = pp[blockIdx.y];
     const auto &k = p.ctrl;
     const int   n_refs = p.n_ref[0] + (p.n_list == 2 ? p.n_ref[1] : 0);
@@ -144,14 +148,22 @@ __global__ void __launch_bounds__(HI_THREADS) hme_l12_regions_kernel(PICS pp) {
         l = 1;
     }
     if (!ref_searched(p, l) || !k.enable_hme_flag) return;
-    stage_l12_blocks<false>(p, S, b64x, b64y, block_w, block_h);
+    if (k.enable_hme_level1_flag)
+        stage_block<8, 2, kSrcPitch<false>>(src1, load_plane(p.cur.lvl[1]), b64x >> 1, b64y >> 1, block_w >> 1, block_h >> 2);
+    if (L2 && k.enable_hme_level2_flag) stage_block<8, 2, kSrcPitch<false>>(src2, load_plane(p.cur.lvl[2]), b64x, b64y, block_w, block_h >> 1);
     wave_sync();
-    l12_regions(p, S.src1, S.src2, win, b64x, b64y, block_w, block_h, l, r, &p.hme_out[(b64 * SVTME_MAX_LISTS + l) * SVTME_MAX_REFS + r]);
+    l12_regions<L2>(p, src1, src2, win, b64x, b64y, block_w, block_h, l, r, &p.hme_out[(b64 * SVTME_MAX_LISTS + l) * SVTME_MAX_REFS + r]);
 }
 
 void launch_hme_l12_regions(const Batch &b, hipStream_t s) {
     const dim3 grid((b.n_b64() + 7) / 8 * 8 * b.max_refs(), b.n);
-    if (b.n == 1) hipLaunchKernelGGL((hme_l12_regions_kernel<OnePicture>), grid, dim3(HI_THREADS), 0, s, OnePicture{b.host[0]});
-    else hipLaunchKernelGGL((hme_l12_regions_kernel<ManyPictures>), grid, dim3(HI_THREADS), 0, s, ManyPictures{b.dev});
+    const bool l2 = b.host[0].ctrl.enable_hme_level2_flag != 0; // (the controls are the batch's)
+    if (b.n == 1) {
+        if (l2) hipLaunchKernelGGL((hme_l12_regions_kernel<OnePicture, true>), grid, dim3(HI_THREADS), 0, s, OnePicture{b.host[0]});
+        else hipLaunchKernelGGL((hme_l12_regions_kernel<OnePicture, false>), grid, dim3(HI_THREADS), 0, s, OnePicture{b.host[0]});
+    } else {
+        if (l2) hipLaunchKernelGGL((hme_l12_regions_kernel<ManyPictures, true>), grid, dim3(HI_THREADS), 0, s, ManyPictures{b.dev});
+        else hipLaunchKernelGGL((hme_l12_regions_kernel<ManyPictures, false>), grid, dim3(HI_THREADS), 0, s, ManyPictures{b.dev});
+    }
 }
 } // namespace svtme
