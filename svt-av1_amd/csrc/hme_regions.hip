@@ -93,7 +93,8 @@ __device__ __forceinline__ void l12_regions(const P &p, const uint32_t *src1, co
 #pragma unroll
             for (int q = 0; q < 4; ++q) key[q] = quick_scan<8, 3>(src, win + q * QuickGeo<8, 3>::WIN, rows, hh[q]);
             wave_sync();
-        } else if (quick && L2) { // the 64-pixel block's windows: two at a time
+        } else if (quick && L2) { // the 64-pixel block's windows
+#ifdef SVTME_L2_PAIRS // two at a time: half the round trips, 3.7 KB more LDS
 #pragma unroll
             for (int half = 0; half < 2; ++half) {
                 const int wxp[2] = {wx[2 * half], wx[2 * half + 1]}, wyp[2] = {wy[2 * half], wy[2 * half + 1]};
@@ -104,6 +105,16 @@ __device__ __forceinline__ void l12_regions(const P &p, const uint32_t *src1, co
                 key[2 * half]     = quick_scan<16, 3>(src, win, rows, hp[0]);
                 key[2 * half + 1] = quick_scan<16, 3>(src, win + QuickGeo<16, 3>::WIN, rows, hp[1]);
             }
+#else // one at a time: the work item fits a quarter more often
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int wxp[1] = {wx[q]}, wyp[1] = {wy[q]}, hp[1] = {hh[q]};
+                wave_sync();
+                quick_stage<16, 3, 1>(win, ref, rows, wxp, wyp, hp);
+                wave_sync();
+                key[q] = quick_scan<16, 3>(src, win, rows, hp[0]);
+            }
+#endif
             wave_sync();
         } else {
 #pragma unroll
@@ -123,7 +134,13 @@ __device__ __forceinline__ void l12_regions(const P &p, const uint32_t *src1, co
     }
 }
 
-constexpr int HI_WIN2_DWORDS_ALL = 2 * QuickGeo<16, 3>::WIN > 4 * QuickGeo<8, 3>::WIN ? 2 * QuickGeo<16, 3>::WIN : 4 * QuickGeo<8, 3>::WIN;
+#ifdef SVTME_L2_PAIRS
+constexpr int kL2AtOnce = 2;
+#else
+constexpr int kL2AtOnce = 1;
+#endif
+constexpr int HI_WIN2_DWORDS_QUICK = kL2AtOnce * QuickGeo<16, 3>::WIN > 4 * QuickGeo<8, 3>::WIN ? kL2AtOnce * QuickGeo<16, 3>::WIN : 4 * QuickGeo<8, 3>::WIN;
+constexpr int HI_WIN2_DWORDS_ALL = HI_WIN2_DWORDS_QUICK > HI_WIN2_BYTES / 4 ? HI_WIN2_DWORDS_QUICK : HI_WIN2_BYTES / 4;
 static_assert(HI_WIN2_DWORDS_ALL * 4 >= HI_WIN2_BYTES, "small_search's window fits too");
 static_assert(HI_WIN2_BYTES / 4 >= 4 * QuickGeo<8, 3>::WIN, "and so do the four level-1 windows where small_search's sets the size");
 
