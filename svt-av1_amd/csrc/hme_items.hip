@@ -104,9 +104,8 @@ __global__ void __launch_bounds__(HI_THREADS, 6) hme_l0_kernel(PICS pp, int grid
 }
 
 template <bool FS, class PICS>
-__global__ void __launch_bounds__(FS ? HI_THREADS_FS : HI_THREADS) hme_l12_kernel(PICS pp) {
-    __shared__ L12Shared<FS>          S;
-    __shared__ __align__(16) uint32_t win[(FS ? HI_WIN2_BYTES_FS : HI_WIN2_BYTES) / 4 + 64];
+__global__ void __launch_bounds__(FS ? HI_THREADS_FS : HI_THREADS, FS ? 4 : 5) hme_l12_kernel(PICS pp) {
+    __shared__ __align__(16) uint32_t lds[kL12Lds<FS>];
     const auto &p   = pp[blockIdx.y];
     const auto &k   = p.ctrl;
     const int             nw = k.num_hme_sa_w, nh = k.num_hme_sa_h;
@@ -124,9 +123,10 @@ __global__ void __launch_bounds__(FS ? HI_THREADS_FS : HI_THREADS) hme_l12_kerne
     }
     if (!ref_searched(p, l) || !k.enable_hme_flag || q >= nw * nh) return;
     // both levels' source blocks are fetched while the level-0 results arrive
-    stage_l12_blocks<FS>(p, S, b64x, b64y, block_w, block_h);
+    uint4 blk2[kL12Blk2<FS>];
+    fetch_l12_blocks<FS>(p, lds, blk2, b64x, b64y, block_w, block_h);
     wave_sync();
-    l12_region<FS>(p, S.src1, S.src2, win, b64x, b64y, block_w, block_h, l, r, q, &p.hme_out[(b64 * SVTME_MAX_LISTS + l) * SVTME_MAX_REFS + r]);
+    l12_region<FS>(p, lds, blk2, b64x, b64y, block_w, block_h, l, r, q, &p.hme_out[(b64 * SVTME_MAX_LISTS + l) * SVTME_MAX_REFS + r]);
 }
 
 template <class PICS>

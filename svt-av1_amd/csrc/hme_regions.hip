@@ -4,6 +4,23 @@
 
 namespace svtme {
 
+#ifdef SVTME_L2_PAIRS
+constexpr int kL2AtOnce = 2;
+#else
+constexpr int kL2AtOnce = 1;
+#endif
+// The work item's LDS in dwords: without level 2 the level-1 block and small_search's window; with it 8 KB (five items per
+// SIMD), of which level 1 takes its block and what is left as window, level 2 its larger block and the rest. 64 dwords of
+// slack after a window as everywhere (pieces staged and rows read past its end).
+template <bool L2>
+constexpr int kRegionsLds = L2 ? (kL2AtOnce == 1 ? 2048 : 32 * kSrcPitch<false> + 2 * QuickGeo<16, 3>::WIN + 64) : 16 * kSrcPitch<false> + HI_WIN2_BYTES / 4 + 64;
+template <bool L2>
+constexpr int kRegionsWinBytes = L2 ? (kRegionsLds<true> - 32 * kSrcPitch<false> - 64) * 4 : HI_WIN2_BYTES; // (level 2's is the smaller one)
+static_assert(kRegionsWinBytes<true> >= kL2AtOnce * QuickGeo<16, 3>::WIN * 4, "level 2's quick windows fit");
+static_assert(kRegionsLds<true> - 16 * kSrcPitch<false> - 64 >= 4 * QuickGeo<8, 3>::WIN, "level 1's four quick windows fit");
+static_assert(kRegionsWinBytes<false> >= 4 * QuickGeo<8, 3>::WIN * 4, "and without level 2");
+static_assert(kRegionsWinBytes<true> / 4 / 63 >= 16 + 4, "small_search: a 64-pixel block's 63 window rows for four positions fit");
+
 // Levels 1 and 2 of all four regions of reference (l, r) in one wave, for the shapes quick_search covers: what l12_region
 // does per region, for windows of 8 x (1..3) positions (the pre-analysis ME's), with the four level-1 windows fetched in one
 // memory round trip and the four level-2 windows in two, and the reference's record, the source blocks and the work item's
@@ -11,9 +28,12 @@ namespace svtme {
 // through small_search region by region. (The first pass's 8 x 8 windows keep a work item per region: with two trips per
 // search the saving is smaller than what the larger item costs in resident waves.)
 // L2 false: the controls have no level 2 (presets 7 and faster): that level's code, source block and windows are left out.
+// The two levels use `lds` one after the other: [level 1's source block][its windows], then [level 2's source block][its
+// window]; level 2's block was fetched with level 1's and waits in `blk2` (the launcher's work item holds as many bytes of
+// LDS as the larger level needs, not both levels').
 template <bool L2, class P>
-__device__ __forceinline__ void l12_regions(const P &p, const uint32_t *src1, const uint32_t *src2, uint32_t *win, int b64x, int b64y,
-                                            int block_w, int block_h, int l, int r, HmeRefOut *rec) {
+__device__ __forceinline__ void l12_regions(const P &p, uint32_t *lds, const uint4 (&blk2)[2], int b64x, int b64y, int block_w, int block_h,
+                                            int l, int r, HmeRefOut *rec) {
     const auto &k    = p.ctrl;
     const int   lane = threadIdx.x & 63;
     const bool  early = k.me_early_exit_th && rec->zz_sad < (k.me_early_exit_th >> 2);
@@ -84,8 +104,14 @@ __device__ __forceinline__ void l12_regions(const P &p, const uint32_t *src1, co
             quick = quick && w == 8 && h >= 1 && h <= 3;
         }
         if (lane == 0) count_ops(p, 2 + level, ops);
-        const uint32_t *src = level == 1 ? src1 : src2;
+        const uint32_t *src = lds;
+        uint32_t       *win = lds + (level == 1 ? 16 : 32) * kSrcPitch<false>;
         u64             key[4];
+        if (L2 && level == 2) {
+            wave_sync(); // level 1's reads of its block and windows are done
+            put_block<8, kSrcPitch<false>>(lds, blk2, block_w, block_h >> 1);
+            wave_sync();
+        }
         if (quick && level == 1) {
             wave_sync();
             quick_stage<8, 3, 4>(win, ref, rows, wx, wy, hh);
@@ -118,7 +144,7 @@ __device__ __forceinline__ void l12_regions(const P &p, const uint32_t *src1, co
             wave_sync();
         } else {
 #pragma unroll
-            for (int q = 0; q < 4; ++q) key[q] = small_search<false>(src, win, ref, bw, rows, wx[q], wy[q], ww[q], hh[q]);
+            for (int q = 0; q < 4; ++q) key[q] = small_search<false, kRegionsWinBytes<L2>>(src, win, ref, bw, rows, wx[q], wy[q], ww[q], hh[q]);
         }
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
@@ -134,23 +160,11 @@ __device__ __forceinline__ void l12_regions(const P &p, const uint32_t *src1, co
     }
 }
 
-#ifdef SVTME_L2_PAIRS
-constexpr int kL2AtOnce = 2;
-#else
-constexpr int kL2AtOnce = 1;
-#endif
-constexpr int HI_WIN2_DWORDS_QUICK = kL2AtOnce * QuickGeo<16, 3>::WIN > 4 * QuickGeo<8, 3>::WIN ? kL2AtOnce * QuickGeo<16, 3>::WIN : 4 * QuickGeo<8, 3>::WIN;
-constexpr int HI_WIN2_DWORDS_ALL = HI_WIN2_DWORDS_QUICK > HI_WIN2_BYTES / 4 ? HI_WIN2_DWORDS_QUICK : HI_WIN2_BYTES / 4;
-static_assert(HI_WIN2_DWORDS_ALL * 4 >= HI_WIN2_BYTES, "small_search's window fits too");
-static_assert(HI_WIN2_BYTES / 4 >= 4 * QuickGeo<8, 3>::WIN, "and so do the four level-1 windows where small_search's sets the size");
-
-// One wave per (b64, reference): the 2 x 2 regions' levels 1 and 2 (sub-sampled searches only). Without level 2 the work item
-// needs 7.7 KB of LDS instead of 13.4 KB: four and more resident items per SIMD instead of 2.75.
+// One wave per (b64, reference): the 2 x 2 regions' levels 1 and 2 (sub-sampled searches only). The kernel is a chain of
+// memory round trips: its rate is the number of work items a SIMD holds, which the LDS sets (7.7 KB without level 2, 8 KB with).
 template <class PICS, bool L2>
 __global__ void __launch_bounds__(HI_THREADS) hme_l12_regions_kernel(PICS pp) {
-    __shared__ __align__(16) uint32_t src1[16 * kSrcPitch<false>]; // sampled rows of the quarter-resolution 32x32 block
-    __shared__ __align__(16) uint32_t src2[L2 ? 32 * kSrcPitch<false> : 4]; // of the full-resolution 64x64 block
-    __shared__ __align__(16) uint32_t win[(L2 ? HI_WIN2_DWORDS_ALL : HI_WIN2_BYTES / 4) + 64];
+    __shared__ __align__(16) uint32_t lds[kRegionsLds<L2>];
     const auto &p = pp[blockIdx.y];
     const auto &k = p.ctrl;
     const int   n_refs = p.n_ref[0] + (p.n_list == 2 ? p.n_ref[1] : 0);
@@ -165,11 +179,12 @@ __global__ void __launch_bounds__(HI_THREADS) hme_l12_regions_kernel(PICS pp) {
         l = 1;
     }
     if (!ref_searched(p, l) || !k.enable_hme_flag) return;
-    if (k.enable_hme_level1_flag)
-        stage_block<8, 2, kSrcPitch<false>>(src1, load_plane(p.cur.lvl[1]), b64x >> 1, b64y >> 1, block_w >> 1, block_h >> 2);
-    if (L2 && k.enable_hme_level2_flag) stage_block<8, 2, kSrcPitch<false>>(src2, load_plane(p.cur.lvl[2]), b64x, b64y, block_w, block_h >> 1);
+    // sampled rows of the quarter-resolution 32x32 block and of the full-resolution 64x64 block
+    uint4 blk2[2] = {};
+    if (k.enable_hme_level1_flag) stage_block<8, 2, kSrcPitch<false>>(lds, load_plane(p.cur.lvl[1]), b64x >> 1, b64y >> 1, block_w >> 1, block_h >> 2);
+    if (L2 && k.enable_hme_level2_flag) fetch_block<8, 2>(blk2, load_plane(p.cur.lvl[2]), b64x, b64y, block_w, block_h >> 1);
     wave_sync();
-    l12_regions<L2>(p, src1, src2, win, b64x, b64y, block_w, block_h, l, r, &p.hme_out[(b64 * SVTME_MAX_LISTS + l) * SVTME_MAX_REFS + r]);
+    l12_regions<L2>(p, lds, blk2, b64x, b64y, block_w, block_h, l, r, &p.hme_out[(b64 * SVTME_MAX_LISTS + l) * SVTME_MAX_REFS + r]);
 }
 
 void launch_hme_l12_regions(const Batch &b, hipStream_t s) {

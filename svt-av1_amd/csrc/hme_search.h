@@ -469,37 +469,56 @@ __device__ __forceinline__ void l0_item(const P &p, uint32_t *win, int b64x, int
 // eight lanes fall into different banks (with 16 they all start in bank 0).
 template <bool FS>
 constexpr int kSrcPitch = FS ? 16 : 20;
+// The LDS of a level-1/2 work item (l12_region), in dwords. The levels use it one after the other: [the sampled rows of the
+// quarter-resolution 32x32 block][level 1's window], then [those of the full-resolution 64x64 block][level 2's window, of
+// kL12WinBytes], plus 64 dwords of slack after a window (pieces staged and rows read past its end). These kernels are chains
+// of memory round trips: their rate is the number of work items a SIMD holds, which this size sets.
 template <bool FS>
-struct L12Shared {
-    __align__(16) uint32_t src1[(FS ? 32 : 16) * kSrcPitch<FS>]; // sampled rows of the quarter-resolution 32x32 block
-    __align__(16) uint32_t src2[(FS ? 64 : 32) * kSrcPitch<FS>]; // sampled rows of the full-resolution 64x64 block
-};
+constexpr int kL12Src1 = (FS ? 32 : 16) * kSrcPitch<FS>;
+template <bool FS>
+constexpr int kL12Src2 = (FS ? 64 : 32) * kSrcPitch<FS>;
+template <bool FS>
+constexpr int kL12WinBytes = FS ? HI_WIN2_BYTES_FS : 5376; // (8 KB per work item without FULL_SAD_SEARCH: five per SIMD)
+template <bool FS>
+constexpr int kL12Lds = kL12Src2<FS> + kL12WinBytes<FS> / 4 + 64;
+template <bool FS>
+constexpr int kL12Blk2 = ((FS ? 64 : 32) + 15) / 16; // 16-byte pieces per lane of the 64x64 block's sampled rows
 
 // Exhaustive search of a small window with a large block whose sampled rows are staged at `src` (16 dwords per row):
 // position quads x block-row chunks over the lanes. bw: block width in pixels (multiple of 4 at these levels),
 // rows: sampled rows, 2 plane rows apart.
 // Sampled rows (STEP plane rows apart, at most 4 K of them) of the bw x rows block at (ox, oy) -> dst, PITCH dwords per
 // row. Issues its loads and stores without waiting: the caller's next barrier orders them.
+// (in two halves, for a caller that has the block's place in LDS only later: the pieces wait in registers)
+template <int K, int STEP>
+__device__ __forceinline__ void fetch_block(uint4 (&v)[(4 * K + 15) / 16], const DevPlane &cur, int ox, int oy, int bw, int rows) {
+    const int lane = threadIdx.x & 63, c = lane & 3, pr = (bw + 15) >> 4; // one wave fetches
+#pragma unroll
+    for (int k = 0; k < (4 * K + 15) / 16; ++k) {
+        const int r = (lane >> 2) + 16 * k;
+        v[k]        = make_uint4(0, 0, 0, 0);
+        if (c < pr && r < rows) __builtin_memcpy(&v[k], cur.pix + (ptrdiff_t)(oy + STEP * r) * cur.stride + ox + 16 * c, 16);
+    }
+}
+template <int K, int PITCH>
+__device__ __forceinline__ void put_block(uint32_t *dst, const uint4 (&v)[(4 * K + 15) / 16], int bw, int rows) {
+    static_assert(PITCH % 4 == 0, "rows start on 16-byte boundaries");
+    const int lane = threadIdx.x & 63, c = lane & 3, pr = (bw + 15) >> 4;
+#pragma unroll
+    for (int k = 0; k < (4 * K + 15) / 16; ++k) {
+        const int r = (lane >> 2) + 16 * k;
+        if (c < pr && r < rows) *reinterpret_cast<uint4 *>(dst + r * PITCH + 4 * c) = v[k];
+    }
+}
 template <int K = 8, int STEP = 2, int PITCH = 16>
 __device__ __forceinline__ void stage_block(uint32_t *dst, const DevPlane &cur, int ox, int oy, int bw, int rows) {
     // 16-byte pieces, a row's in neighbouring lanes: lane = (row of the trip: lane / 4, piece: lane % 4), 16 rows per trip
     // (PITCH is a multiple of 4 dwords and dst 16-byte aligned; a piece may reach past a narrower block's right edge,
     // into columns the searches do not read)
-    static_assert(PITCH % 4 == 0, "rows start on 16-byte boundaries");
-    const int lane = threadIdx.x & 63, c = lane & 3, pr = (bw + 15) >> 4; // one wave fetches
-    if (c >= pr) return;
     constexpr int KT = (4 * K + 15) / 16; // trips: up to 4 K rows, 16 per trip
     uint4         v[KT];
-#pragma unroll
-    for (int k = 0; k < KT; ++k) {
-        const int r = (lane >> 2) + 16 * k;
-        if (r < rows) __builtin_memcpy(&v[k], cur.pix + (ptrdiff_t)(oy + STEP * r) * cur.stride + ox + 16 * c, 16);
-    }
-#pragma unroll
-    for (int k = 0; k < KT; ++k) {
-        const int r = (lane >> 2) + 16 * k;
-        if (r < rows) *reinterpret_cast<uint4 *>(dst + r * PITCH + 4 * c) = v[k];
-    }
+    fetch_block<K, STEP>(v, cur, ox, oy, bw, rows);
+    put_block<K, PITCH>(dst, v, bw, rows);
 }
 
 // One sampled block row of BWD dwords against 4 adjacent positions of a staged window row.
@@ -515,11 +534,11 @@ __device__ __forceinline__ u64 row_qsad(const uint32_t *rr, const uint32_t *ss, 
     return a16;
 }
 
-template <bool FS>
+// WINB: the bytes at `win`.
+template <bool FS, int WINB = FS ? HI_WIN2_BYTES_FS : HI_WIN2_BYTES>
 __device__ u64 small_search(const uint32_t *src, uint32_t *win, const DevPlane &ref, int bw, int rows, int wx, int wy, int sa_w, int sa_h) {
     constexpr int STEP = FS ? 1 : 2; // plane rows between sampled block rows
     constexpr int NT   = 64;
-    constexpr int WINB = FS ? HI_WIN2_BYTES_FS : HI_WIN2_BYTES;
     const int lane = threadIdx.x & 63;
     u64       best = ~0ull;
     if (sa_w <= 0 || sa_h <= 0 || rows <= 0) return best;
@@ -527,7 +546,8 @@ __device__ u64 small_search(const uint32_t *src, uint32_t *win, const DevPlane &
     const int span       = (rows - 1) * STEP + 1;
     const int chunk_log2 = rows >= 16 ? 3 : (rows >= 4 ? 2 : 0), chunks = 1 << chunk_log2;
     const int rpc        = (rows + chunks - 1) >> chunk_log2; // sampled block rows per lane
-    const int xc         = 64; // positions per staged column chunk
+    // positions per staged column chunk: at most 64, and no more than leave room for one search row's `span` window rows
+    const int xc = 4 * max(min(16, ((WINB / 4 / span) & ~3) - bwd), 1);
     for (int x0 = 0; x0 < sa_w; x0 += xc) {
         const int n_xg = (min(xc, sa_w - x0) + 3) >> 2, pd = (n_xg + bwd + 3) & ~3;
         const int band = max(WINB / (4 * pd) - (span - 1), 1);
@@ -863,10 +883,11 @@ __device__ u64 quick_search(const uint32_t *src, uint32_t *win, const DevPlane &
 // Levels 1 and 2 of region q of reference (l, r), whole wave: first the level-0 result of the region, which gives way
 // to the better pre-HME result when it is the worst region (:1967-1999), then level 1 around the level-0 vector and
 // level 2 around the level-1 vector. `rec`: the reference's record with zz_sad, pre_* and raw_* complete (global or LDS);
-// src1 / src2: the sampled rows of the block at quarter / full resolution, staged by the caller.
+// lds: kL12Lds dwords with the quarter-resolution block's sampled rows staged at its start; blk2: the full-resolution
+// block's, fetched by the caller (fetch_l12_blocks), which move into `lds` when level 1 is done with it.
 template <bool FS, class P>
-__device__ __forceinline__ void l12_region(const P &p, const uint32_t *src1, const uint32_t *src2, uint32_t *win, int b64x, int b64y,
-                                           int block_w, int block_h, int l, int r, int q, HmeRefOut *rec) {
+__device__ __forceinline__ void l12_region(const P &p, uint32_t *lds, const uint4 (&blk2)[kL12Blk2<FS>], int b64x, int b64y, int block_w,
+                                           int block_h, int l, int r, int q, HmeRefOut *rec) {
     const auto &k    = p.ctrl;
     const int   lane = threadIdx.x & 63;
     const int   nw = k.num_hme_sa_w, nh = k.num_hme_sa_h;
@@ -926,8 +947,14 @@ __device__ __forceinline__ void l12_region(const P &p, const uint32_t *src1, con
         w = (int16_t)(w < 8 ? w : (w & ~0x07));
         clip_axis(oy, org_y, h, -pad, ref.height);
         if (lane == 0) count_ops(p, 2 + level, (unsigned long long)max((int)h, 0) * max((int)w, 0) * rows * bw);
-        const uint32_t *src = level == 1 ? src1 : src2;
+        const uint32_t *src = lds;
+        uint32_t       *win = lds + (level == 1 ? kL12Src1<FS> : kL12Src2<FS>);
         u64             key;
+        if (level == 2) {
+            wave_sync(); // level 1's reads of its block and window are done
+            put_block<FS ? 16 : 8, kSrcPitch<FS>>(lds, blk2, block_w, FS ? block_h : block_h >> 1);
+            wave_sync();
+        }
         if constexpr (!FS) {
             if (block_w == 64 && w == 8 && h >= 1 && h <= 3)
                 key = level == 1 ? quick_search<8, 3>(src, win, ref, rows, ox + org_x, oy + org_y, h)
@@ -936,13 +963,13 @@ __device__ __forceinline__ void l12_region(const P &p, const uint32_t *src1, con
                 key = level == 1 ? quick_search<8, 8>(src, win, ref, rows, ox + org_x, oy + org_y, h)
                                  : quick_search<16, 8>(src, win, ref, rows, ox + org_x, oy + org_y, h);
             else
-                key = small_search<FS>(src, win, ref, bw, rows, ox + org_x, oy + org_y, w, h);
+                key = small_search<FS, kL12WinBytes<FS>>(src, win, ref, bw, rows, ox + org_x, oy + org_y, w, h);
         } else {
             if (block_w == 64 && w >= 1 && w <= 16 && h >= 1 && h <= 16)
                 key = level == 1 ? strip_search_fs<2, 32, 2>(src, win, p.zero, ref, rows, ox + org_x, oy + org_y, w, h)
                                  : strip_search_fs<4, 64, 4>(src, win, p.zero, ref, rows, ox + org_x, oy + org_y, w, h);
             else
-                key = small_search<FS>(src, win, ref, bw, rows, ox + org_x, oy + org_y, w, h);
+                key = small_search<FS, kL12WinBytes<FS>>(src, win, ref, bw, rows, ox + org_x, oy + org_y, w, h);
         }
         uint32_t  sad;
         decode_key(key, org_x, org_y, level == 1 ? 2 : 1, cx, cy, sad, !FS);
@@ -954,17 +981,26 @@ __device__ __forceinline__ void l12_region(const P &p, const uint32_t *src1, con
     }
 }
 
-// Both levels' source blocks of a 64x64 block: sampled rows of the quarter- and the full-resolution block, one wave.
+static_assert(QuickGeo<16, 8>::WIN * 4 <= kL12WinBytes<false> && QuickGeo<8, 8>::WIN <= kL12Lds<false> - kL12Src1<false> - 64,
+              "the first pass's 8 x 8 windows fit");
+static_assert((16 + 63) * (4 + 4 * 4) * 4 <= kL12WinBytes<true> && (16 + 31) * (4 + 4 * 2) <= kL12Lds<true> - kL12Src1<true> - 64,
+              "the temporal filter's 16 x 16 windows fit");
+static_assert(kL12WinBytes<false> / 4 / 63 >= 16 + 4 && kL12WinBytes<true> / 4 / 64 >= 16 + 4, "small_search: four positions of a 64-pixel block fit");
+
+// Both levels' source blocks of a 64x64 block, one wave: the sampled rows of the quarter-resolution block to `lds`, those of
+// the full-resolution block into registers.
 template <bool FS, class P>
-__device__ __forceinline__ void stage_l12_blocks(const P &p, L12Shared<FS> &S, int b64x, int b64y, int block_w, int block_h) {
+__device__ __forceinline__ void fetch_l12_blocks(const P &p, uint32_t *lds, uint4 (&blk2)[kL12Blk2<FS>], int b64x, int b64y, int block_w, int block_h) {
     const auto &k = p.ctrl;
+#pragma unroll
+    for (int i = 0; i < kL12Blk2<FS>; ++i) blk2[i] = make_uint4(0, 0, 0, 0);
     if constexpr (FS) {
-        if (k.enable_hme_level1_flag) stage_block<8, 1>(S.src1, load_plane(p.cur.lvl[1]), b64x >> 1, b64y >> 1, block_w >> 1, block_h >> 1);
-        if (k.enable_hme_level2_flag) stage_block<16, 1>(S.src2, load_plane(p.cur.lvl[2]), b64x, b64y, block_w, block_h);
+        if (k.enable_hme_level1_flag) stage_block<8, 1>(lds, load_plane(p.cur.lvl[1]), b64x >> 1, b64y >> 1, block_w >> 1, block_h >> 1);
+        if (k.enable_hme_level2_flag) fetch_block<16, 1>(blk2, load_plane(p.cur.lvl[2]), b64x, b64y, block_w, block_h);
     } else {
         if (k.enable_hme_level1_flag)
-            stage_block<8, 2, kSrcPitch<false>>(S.src1, load_plane(p.cur.lvl[1]), b64x >> 1, b64y >> 1, block_w >> 1, block_h >> 2);
-        if (k.enable_hme_level2_flag) stage_block<8, 2, kSrcPitch<false>>(S.src2, load_plane(p.cur.lvl[2]), b64x, b64y, block_w, block_h >> 1);
+            stage_block<8, 2, kSrcPitch<false>>(lds, load_plane(p.cur.lvl[1]), b64x >> 1, b64y >> 1, block_w >> 1, block_h >> 2);
+        if (k.enable_hme_level2_flag) fetch_block<8, 2>(blk2, load_plane(p.cur.lvl[2]), b64x, b64y, block_w, block_h >> 1);
     }
 }
 
