@@ -99,10 +99,11 @@ def compare_picture(out, bd, pic, where=""):
 
 
 def run_engine_job(frames, pics, enc_mode, sc_class1=0, frame_rate=30 << 16, engine=None, tail=None, serial_hme=0,
-                   restricted=0, number_scale=1, tiles=None, batch=1):
+                   restricted=0, number_scale=1, tiles=None, batch=1, edit_controls=None):
     """Runs every picture of the job through the engine's C ABI; returns the list of output dicts. tail: an
     svtme.Tail to run the host tail on the device as well. batch > 1: the pictures go through svtme_pictures_submit,
-    `batch` at a time (one set of launches for all of them, one search stream), as the benchmark submits them."""
+    `batch` at a time (one set of launches for all of them, one search stream), as the benchmark submits them.
+    edit_controls: called with the derived controls before the pictures are described."""
     import svtme
     n, h, w = frames.shape
     own = engine is None
@@ -112,6 +113,8 @@ def run_engine_job(frames, pics, enc_mode, sc_class1=0, frame_rate=30 << 16, eng
             eng.store_put(i, i, frames[i])
         set_uniform_tiles(eng, w, h, tiles)
         ctrl = svtme.derive_controls(enc_mode, w, h, sc_class1, frame_rate)
+        if edit_controls:
+            edit_controls(ctrl)  # settings no preset has
         outs = []
         descs = [eng.make_picture(w, h, p.poc, p.temporal_layer, p.is_ref, p.refs, ctrl, tail=tail,
                                   restricted_motion_vector=restricted, number_of=lambda poc: poc * number_scale) for p in pics]

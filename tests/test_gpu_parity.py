@@ -177,6 +177,28 @@ def test_serial_hme_kernel_matches_reference_temporal_filter_golden():
             assert np.array_equal(v, want[f]), (i, f)
 
 
+@pytest.mark.parametrize("l1,l2,mode", [((40, 5), (64, 9), 3), ((24, 2), (16, 3), 8), ((8, 16), (72, 4), 3), ((64, 3), (40, 3), 6),
+                                        ((16, 1), (48, 12), 1)])
+def test_level_1_and_2_windows_no_preset_has(l1, l2, mode):
+    """Level-1 / level-2 search areas wider and taller than any preset's (theirs are 8 x 3, 8 x 8 and 16 x 16): the work-item
+    kernels and the serial kernel, two implementations with different window staging, must agree on every output. (No
+    reference run covers these: the reference derives its controls itself.)"""
+    frames, pics, _ = support.make_job(328, 200, 9, mode, seed=31 + l1[0])
+
+    def edit(c):
+        c.hme_l1_sa.width, c.hme_l1_sa.height = l1
+        c.hme_l2_sa.width, c.hme_l2_sa.height = l2
+        c.enable_hme_level1_flag = c.enable_hme_level2_flag = 1
+
+    a = support.run_engine_job(frames, pics, mode, edit_controls=edit)
+    b = support.run_engine_job(frames, pics, mode, edit_controls=edit, serial_hme=1)
+    for p, x, y in zip(pics, a, b):
+        for f in ("zz_sad", "sr_divisor", "best_sad", "best_mv"):
+            assert np.array_equal(x[f], y[f]), (p.poc, f)
+        for f in ("hme_sc_x", "hme_sc_y", "hme_sad", "do_ref"):
+            assert np.array_equal(x["search_results"][f], y["search_results"][f]), (p.poc, f)
+
+
 def test_engine_rejects_what_it_does_not_implement():
     frames, pics, _ = support.make_job(128, 128, 3, 8, seed=1)
     eng = svtme.Engine(128, 128, store_slots=4, max_in_flight=1)
