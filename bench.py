@@ -43,16 +43,19 @@ WORKLOADS = {
     "1080p_ra_m3": dict(width=1920, height=1080, enc_mode=3, structure="ra", n_frames=17, bit_depth=8, batch=16),
     # "batch": pictures per svtme_pictures_submit call (the pictures of a mini-GOP are posted back to back,
     # EbPictureDecisionProcess.c:6842-6874). The fast presets are bound by per-launch costs, which a mini-GOP submitted at
-    # once pays once; the slow ones gain the shorter kernel tails (measured: profiles/r02_batch_sweep.txt)
-    "1080p_ra_m8": dict(width=1920, height=1080, enc_mode=8, structure="ra", n_frames=17, bit_depth=8, batch=16),
-    "720p_ld_m12": dict(width=1280, height=720, enc_mode=12, structure="ldp", n_frames=17, bit_depth=8, batch=16),
+    # once pays once; the slow ones gain the shorter kernel tails (measured: profiles/r02_batch_sweep.txt). 1080p preset 8
+    # and 720p preset 12 hand over two mini-GOPs per call (a look-ahead of 32 pictures): 7 us of kernels per 720p picture are
+    # still short against what a set of launches costs (profiles/r03_batch_sweep.txt).
+    "1080p_ra_m8": dict(width=1920, height=1080, enc_mode=8, structure="ra", n_frames=17, bit_depth=8, batch=32),
+    "720p_ld_m12": dict(width=1280, height=720, enc_mode=12, structure="ldp", n_frames=17, bit_depth=8, batch=32),
     "4k_ra_m8": dict(width=3840, height=2160, enc_mode=8, structure="ra", n_frames=17, bit_depth=10, batch=16),
     "8k_ra_m2": dict(width=7680, height=4320, enc_mode=2, structure="ra", n_frames=17, bit_depth=8, batch=2),
     # temporal-filter searches (ME_MCTF): a 7-frame window, the centre frame searched in each of its 6 neighbours; one
     # "picture" = one (centre, neighbour) pair. tf = (tf_ctrls.hme_me_level, tf_ctrls.me_exit_th): level 0 is what presets
-    # up to M5 use, level 2 with the 16x16 exit threshold what the fast presets use (EbEncHandle.c:2556-2876).
+    # up to M5 use, level 2 with the 16x16 exit threshold what the fast presets use (EbEncHandle.c:2556-2876). A submission
+    # is the six pairs of one filtered picture, at level 2 those of two filtered pictures.
     "1080p_tf_l0": dict(width=1920, height=1080, enc_mode=0, structure="tf", n_frames=7, bit_depth=8, tf=(0, 0), batch=6),
-    "1080p_tf_l2": dict(width=1920, height=1080, enc_mode=8, structure="tf", n_frames=7, bit_depth=8, tf=(2, 256), batch=6),
+    "1080p_tf_l2": dict(width=1920, height=1080, enc_mode=8, structure="tf", n_frames=7, bit_depth=8, tf=(2, 256), batch=12),
     # first-pass ME of a two-pass encode (ME_FIRST_PASS): every frame searches the previous and the first frame;
     # fp = (ipp_pass_ctrls.bypass_zz_check, ipp_pass_ctrls.reduce_me_search)
     "1080p_first_pass": dict(width=1920, height=1080, enc_mode=8, structure="fp", n_frames=17, bit_depth=8, fp=(0, 0), batch=16),

@@ -99,11 +99,12 @@ def compare_picture(out, bd, pic, where=""):
 
 
 def run_engine_job(frames, pics, enc_mode, sc_class1=0, frame_rate=30 << 16, engine=None, tail=None, serial_hme=0,
-                   restricted=0, number_scale=1, tiles=None, batch=1, edit_controls=None):
+                   restricted=0, number_scale=1, tiles=None, batch=1, edit_controls=None, repeat=1):
     """Runs every picture of the job through the engine's C ABI; returns the list of output dicts. tail: an
     svtme.Tail to run the host tail on the device as well. batch > 1: the pictures go through svtme_pictures_submit,
     `batch` at a time (one set of launches for all of them, one search stream), as the benchmark submits them.
-    edit_controls: called with the derived controls before the pictures are described."""
+    edit_controls: called with the derived controls before the pictures are described. repeat: the job's pictures are
+    submitted this many times over, one copy after the other (batches larger than the job); the outputs come in that order."""
     import svtme
     n, h, w = frames.shape
     own = engine is None
@@ -118,6 +119,7 @@ def run_engine_job(frames, pics, enc_mode, sc_class1=0, frame_rate=30 << 16, eng
         outs = []
         descs = [eng.make_picture(w, h, p.poc, p.temporal_layer, p.is_ref, p.refs, ctrl, tail=tail,
                                   restricted_motion_vector=restricted, number_of=lambda poc: poc * number_scale) for p in pics]
+        descs = descs * repeat
         if batch > 1:
             for i in range(0, len(descs), batch):
                 tickets = eng.submit_batch(descs[i:i + batch]) if len(descs[i:i + batch]) > 1 else [eng.submit(descs[i])]
