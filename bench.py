@@ -47,7 +47,10 @@ WORKLOADS = {
     # and 720p preset 12 hand over two mini-GOPs per call (a look-ahead of 32 pictures): 7 us of kernels per 720p picture are
     # still short against what a set of launches costs (profiles/r03_batch_sweep.txt).
     "1080p_ra_m8": dict(width=1920, height=1080, enc_mode=8, structure="ra", n_frames=17, bit_depth=8, batch=32),
-    "720p_ld_m12": dict(width=1280, height=720, enc_mode=12, structure="ldp", n_frames=17, bit_depth=8, batch=32),
+    # "streams": the batches alternate over two search streams, so that the kernels of one fill the tails of the other's -
+    # every workload gains 5-25 % that way (profiles/r03_bench_*_two_streams.json), but kernels that share the GPU cannot be
+    # timed one by one inside the timed region, so only this launch-bound workload (0.06 of the roof) does it by default
+    "720p_ld_m12": dict(width=1280, height=720, enc_mode=12, structure="ldp", n_frames=17, bit_depth=8, batch=32, streams=2),
     "4k_ra_m8": dict(width=3840, height=2160, enc_mode=8, structure="ra", n_frames=17, bit_depth=10, batch=16),
     "8k_ra_m2": dict(width=7680, height=4320, enc_mode=2, structure="ra", n_frames=17, bit_depth=8, batch=2),
     # temporal-filter searches (ME_MCTF): a 7-frame window, the centre frame searched in each of its 6 neighbours; one
@@ -142,7 +145,7 @@ def main():
                     help="pictures per svtme_pictures_submit call (they share their kernel launches); 0 = the workload's default")
     ap.add_argument("--search-streams", type=int, default=0, choices=[0, 1, 2, 3],
                     help="0 = the engine's default: one stream for batches, three for pictures submitted singly")
-    ap.add_argument("--kernel-steps", type=int, default=8, help="steps of the one-stream pass that times the kernels")
+    ap.add_argument("--kernel-steps", type=int, default=24, help="steps of the one-stream pass that times the kernels")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-verify", action="store_true",
                     help="skip the check (outside the timed region) of one more step's results against the reference's digest")
@@ -243,6 +246,8 @@ def main():
                                   first_pass_bypass_zz=fp[0] if fp else None, b64_step=wl.get("b64_step", 0)) for p in pics]
 
     # per-kernel events only where they are needed: with one search stream they are the roofline timings
+    if not args.search_streams and args.batch > 1 and not args.with_upload and not args.group:
+        args.search_streams = wl.get("streams", 0)
     streams = args.search_streams or (1 if args.batch > 1 else 3)  # what the engine makes of 0
     eng, descs = make_engine(args.search_streams, 1 if streams == 1 else 0)
     new_stats = lambda: {"ms": np.zeros(8, np.float64), "launches": 0, "ops": np.zeros(6, np.float64)}  # noqa: E731
@@ -485,7 +490,7 @@ def main():
         eng.close()
         eng, descs = make_engine(1, 1)
         solo = new_stats()
-        run_steps(1, None)
+        run_steps(max(1, args.kernel_steps // 3), None)  # (the new engine's buffers took long enough for the clocks to drop)
         run_steps(args.kernel_steps, solo)
         torch.cuda.synchronize()
     if rank == 0:

@@ -29,6 +29,14 @@ run 1080p_ra_m3_with_upload --with-upload --no-cpu-baseline
 run 1080p_ra_m8_with_upload --workload 1080p_ra_m8 --with-upload --no-cpu-baseline
 run 4k_ra_m8_with_upload --workload 4k_ra_m8 --with-upload --no-cpu-baseline
 run 720p_ld_m12_with_upload --workload 720p_ld_m12 --with-upload --no-cpu-baseline
+# batches alternating over two search streams: the kernels of one batch fill the tails of the other's (higher rates; the
+# kernels' own durations then come from a one-stream pass after the timed region)
+run 1080p_ra_m3_two_streams --search-streams 2 --no-cpu-baseline
+run 4k_ra_m8_two_streams --workload 4k_ra_m8 --search-streams 2 --no-cpu-baseline
+run 1080p_ra_m8_two_streams --workload 1080p_ra_m8 --search-streams 2 --no-cpu-baseline
+run 720p_ld_m12_one_stream --workload 720p_ld_m12 --search-streams 1 --no-cpu-baseline # (its default is two)
+run 1080p_tf_l0_two_streams --workload 1080p_tf_l0 --search-streams 2 --no-cpu-baseline
+run 1080p_first_pass_two_streams --workload 1080p_first_pass --search-streams 2 --no-cpu-baseline
 # one process, two engines on this GPU behind svtme_group (a rehearsal of the N-GPU group mode: batched submits, uploads
 # and peer copies inside the timed region)
 SVTME_BENCH_REHEARSAL=1 run 1080p_ra_m8_group2_one_gpu --workload 1080p_ra_m8 --group --gpus 2 --no-cpu-baseline
