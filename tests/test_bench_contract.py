@@ -38,8 +38,10 @@ def check_line(d, expect_cpu_baseline):
 
 @pytest.mark.parametrize("path", sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]_bench_*.json"))))
 def test_committed_bench_lines_keep_the_contract(path):
-    with open(path) as f:  # (the upload-inclusive and group lines are a second view of a workload and carry no CPU baseline)
-        check_line(json.loads(f.read().strip().splitlines()[-1]), expect_cpu_baseline="with_upload" not in path and "_group" not in path)
+    # (the upload-inclusive, group and other-stream-count lines are a second view of a workload and carry no CPU baseline)
+    second_view = any(t in path for t in ("with_upload", "_group", "_two_streams", "_one_stream"))
+    with open(path) as f:
+        check_line(json.loads(f.read().strip().splitlines()[-1]), expect_cpu_baseline=not second_view)
 
 
 def test_bench_help_needs_no_gpu():
