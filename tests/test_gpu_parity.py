@@ -199,6 +199,40 @@ def test_level_1_and_2_windows_no_preset_has(l1, l2, mode):
             assert np.array_equal(x["search_results"][f], y["search_results"][f]), (p.poc, f)
 
 
+@pytest.mark.parametrize("case", [
+    dict(l0=((40, 12), (200, 100)), regions=(2, 2), mode=3),
+    dict(l0=((16, 16), (16, 16)), regions=(1, 1), mode=8),
+    dict(l0=((300, 8), (600, 40)), regions=(2, 1), mode=3),
+    dict(l0=((24, 6), (48, 10)), regions=(1, 2), mode=6, pre=(((24, 50), (24, 200)), ((50, 5), (200, 5)))),
+    dict(l0=((100, 2), (100, 2)), regions=(2, 2), mode=10, pre=(((8, 30), (8, 30)), ((30, 1), (30, 1))), skip_line=1),
+])
+def test_level_0_and_pre_hme_areas_no_preset_has(case):
+    """Level-0 and pre-HME search areas and region counts outside the presets' (theirs: 2 x 2 regions, widths that are
+    multiples of 16 after the region split, pre-HME 8 x 100..400 and 96..384 x 3): the work-item kernels against the serial
+    kernel, as in the test above."""
+    mode = case["mode"]
+    frames, pics, _ = support.make_job(328, 200, 9, mode, seed=77)
+
+    def edit(c):
+        (c.hme_l0_sa.sa_min.width, c.hme_l0_sa.sa_min.height), (c.hme_l0_sa.sa_max.width, c.hme_l0_sa.sa_max.height) = case["l0"]
+        c.num_hme_sa_w, c.num_hme_sa_h = case["regions"]
+        c.enable_hme_flag = c.enable_hme_level0_flag = 1
+        if "pre" in case:
+            c.prehme_enable = 1
+            c.prehme_skip_search_line = case.get("skip_line", 0)
+            for i, (lo, hi) in enumerate(case["pre"]):
+                c.prehme_sa_cfg[i].sa_min.width, c.prehme_sa_cfg[i].sa_min.height = lo
+                c.prehme_sa_cfg[i].sa_max.width, c.prehme_sa_cfg[i].sa_max.height = hi
+
+    a = support.run_engine_job(frames, pics, mode, edit_controls=edit)
+    b = support.run_engine_job(frames, pics, mode, edit_controls=edit, serial_hme=1)
+    for p, x, y in zip(pics, a, b):
+        for f in ("zz_sad", "sr_divisor", "best_sad", "best_mv"):
+            assert np.array_equal(x[f], y[f]), (p.poc, f)
+        for f in ("hme_sc_x", "hme_sc_y", "hme_sad", "do_ref"):
+            assert np.array_equal(x["search_results"][f], y["search_results"][f]), (p.poc, f)
+
+
 def test_engine_rejects_what_it_does_not_implement():
     frames, pics, _ = support.make_job(128, 128, 3, 8, seed=1)
     eng = svtme.Engine(128, 128, store_slots=4, max_in_flight=1)
