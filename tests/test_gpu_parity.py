@@ -233,6 +233,48 @@ def test_level_0_and_pre_hme_areas_no_preset_has(case):
             assert np.array_equal(x["search_results"][f], y["search_results"][f]), (p.poc, f)
 
 
+ME_AREAS = [((8, 3), (8, 3)), ((24, 5), (40, 7)), ((64, 8), (64, 8)), ((16, 32), (16, 32)), ((32, 16), (32, 16)), ((12, 9), (20, 11)),
+            ((8, 1), (8, 1)), ((48, 10), (48, 10)), ((16, 2), (56, 9))]
+
+
+def _run_me_areas(path=None):
+    """The ME_AREAS jobs through the engine; path: where to save the outputs (the child process of the test below)."""
+    out = {}
+    for i, (lo, hi) in enumerate(ME_AREAS):
+        mode = (8, 10, 12)[i % 3]
+        frames, pics, _ = support.make_job(328, 200, 9, mode, seed=90 + i, structure=("ra", "ldb")[i % 2])
+
+        def edit(c):
+            c.me_sa.sa_min.width, c.me_sa.sa_min.height = lo
+            c.me_sa.sa_max.width, c.me_sa.sa_max.height = hi
+
+        for j, o in enumerate(support.run_engine_job(frames, pics, mode, edit_controls=edit)):
+            for f in ("zz_sad", "sr_divisor", "best_sad", "best_mv"):
+                out["%d_%d_%s" % (i, j, f)] = o[f]
+            out["%d_%d_sr" % (i, j)] = np.frombuffer(o["search_results"].tobytes(), np.uint8)
+    if path:
+        np.savez(path, **out)
+    return out
+
+
+def test_integer_search_areas_no_preset_has(tmp_path):
+    """Integer search areas of at most one work item per window that no preset has (theirs: 8 x 3, 8 x 6, 16 x 9 ...), where
+    the work item plans, searches and finishes its window and walks small windows with all lanes: every output must equal
+    what the three general kernels give (a child process with SVTME_ME_UNFUSED=1: the switch is read once per process)."""
+    import subprocess
+    import sys
+    here = _run_me_areas()
+    path = str(tmp_path / "unfused.npz")
+    env = dict(os.environ, SVTME_ME_UNFUSED="1")
+    code = "import sys; sys.path[:0] = %r; import test_gpu_parity as t; t._run_me_areas(%r)" % ([p for p in sys.path if p], path)
+    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=280)
+    assert r.returncode == 0, r.stderr[-2000:]
+    there = np.load(path)
+    assert sorted(there.files) == sorted(here)
+    for k in here:
+        assert np.array_equal(here[k], there[k]), k
+
+
 def test_engine_rejects_what_it_does_not_implement():
     frames, pics, _ = support.make_job(128, 128, 3, 8, seed=1)
     eng = svtme.Engine(128, 128, store_slots=4, max_in_flight=1)
