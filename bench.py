@@ -250,6 +250,7 @@ def main():
         args.search_streams = wl.get("streams", 0)
     streams = args.search_streams or (1 if args.batch > 1 else 3)  # what the engine makes of 0
     eng, descs = make_engine(args.search_streams, 1 if streams == 1 else 0)
+    engine_times_kernels, timing_state = [streams == 1], [True]  # (the engine starts with the events on)
     new_stats = lambda: {"ms": np.zeros(8, np.float64), "launches": 0, "ops": np.zeros(6, np.float64)}  # noqa: E731
     stats = new_stats()
 
@@ -284,6 +285,7 @@ def main():
         counts the durations are set against are averages over whole steps; one svtme_picture_timing call for a
         submission: its pictures share their launches and report equal shares). keep: a list that receives every picture's results."""
         e, ds = e or eng, ds or descs
+        timing_switch = e is eng and engine_times_kernels[0]
         tickets, group, new_sources = [], [], []
         sampled, cur_step = set(), [0]
 
@@ -308,6 +310,11 @@ def main():
             if new_sources:
                 put_sources(e, new_sources, flush.ks)
                 new_sources.clear()
+            if timing_switch:  # per-kernel events only on the submissions whose durations will be read
+                want = collect is not None or (sample is not None and cur_step[0] % sample[1] == 0)
+                if want != timing_state[0]:
+                    e.kernel_timing(want)
+                    timing_state[0] = want
             new = e.submit_batch(group) if len(group) > 1 else [e.submit(group[0])]
             if sample is not None and cur_step[0] % sample[1] == 0:
                 sampled.add(new[0])
@@ -411,14 +418,14 @@ def main():
     g0 = grp.stats() if grp is not None else None
     t0 = time.perf_counter()
     # nothing but (put,) submit / wait / done per picture inside the timed region - and, with one search stream, one
-    # svtme_picture_timing call per submission of every few steps (~64 calls over the region): the kernels' HIP events
+    # svtme_picture_timing call per submission of every few steps (16-odd steps over the region; the engine records the
+    # per-kernel events for those submissions only, because they cost device time: svtme_kernel_timing): the kernels' HIP events
     timed = new_stats()
-    submits_per_step = max(1, (per_rank[rank] // args.steps + args.batch - 1) // args.batch)
     if grp is not None:
         run_group_steps(args.steps, count=True)
     elif not args.group:
         run_steps(args.steps, None, upload=args.with_upload, owners=owners_timed,
-                  sample=(timed, max(1, args.steps * submits_per_step // 64)) if streams == 1 else None)
+                  sample=(timed, max(1, args.steps // 16)) if streams == 1 else None)
     if grp is not None and not rehearsal:
         for d in range(args.gpus):
             torch.cuda.synchronize(d)
@@ -489,6 +496,7 @@ def main():
     if rank == 0 and streams != 1 and args.kernel_steps > 0:
         eng.close()
         eng, descs = make_engine(1, 1)
+        engine_times_kernels[0], timing_state[0] = True, True
         solo = new_stats()
         run_steps(max(1, args.kernel_steps // 3), None)  # (the new engine's buffers took long enough for the clocks to drop)
         run_steps(args.kernel_steps, solo)

@@ -405,6 +405,12 @@ int svtme_picture_search_static(svtme_engine *e, const svtme_picture *pic, void 
  * share (1 / [7]) of the batch's durations. Diagnostic only. */
 int svtme_picture_timing(svtme_engine *e, svtme_ticket ticket, float ms[8]);
 
+/* Switches the per-kernel events of the submissions that follow on (1) or off (0); svtme_config.kernel_timing is the
+ * state an engine starts in. The events cost a few microseconds of device time per submission, which a launch-bound
+ * workload notices (a tenth of the rate at 720p preset 12): a caller that samples kernel durations switches them on for
+ * the submissions it will ask svtme_picture_timing about. No counterpart in the reference: a measurement aid. */
+int svtme_kernel_timing(svtme_engine *e, int on);
+
 /* Number of abs-diff-accumulate operations the waited picture's searches performed (after clipping, early exits
  * and pruning): [0] zero-MV / search-centre SADs, [1] pre-HME, [2] HME L0, [3] L1, [4] L2, [5] integer search.
  * Diagnostic: the numerator of the roofline figures. */

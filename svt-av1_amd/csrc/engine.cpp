@@ -192,6 +192,7 @@ struct svtme_engine {
     std::condition_variable cv_sync_readers; // a slot's last global-motion / TPL reader has left, or a put has been enqueued (with mu)
     hipStream_t         s_store[2] = {nullptr, nullptr}, s_me[4] = {nullptr, nullptr, nullptr, nullptr}, s_copy = nullptr;
     unsigned            next_me = 0, next_upload = 0, n_upload = 1;
+    bool                timing_on = false; // per-kernel events on the submissions that follow (svtme_kernel_timing)
     int                 copy_on_search_stream = -1; // -1: with three search streams only; 0 / 1: diagnostic override
     std::vector<Slot>   slots;
     std::vector<Flight> flights;
@@ -293,6 +294,7 @@ extern "C" int svtme_create(const svtme_config *cfg, svtme_engine **out) {
     svtme_engine *e = new (std::nothrow) svtme_engine();
     if (!e) return SVTME_ERR_NO_RESOURCES;
     e->cfg = *cfg;
+    e->timing_on = cfg->kernel_timing != 0;
     auto fail = [&](int code) {
         svtme_destroy(e);
         return code;
@@ -1079,7 +1081,7 @@ extern "C" int svtme_pictures_submit(svtme_engine *e, const svtme_picture *pics,
     // (with three search streams the copy stays on the picture's own stream: the other two keep the GPU busy, and
     // the process stays within four hardware queues)
     const hipStream_t sc = (e->copy_on_search_stream < 0 ? n_sm >= 3 : e->copy_on_search_stream != 0) ? sm : e->s_copy;
-    const bool  kt = e->cfg.kernel_timing != 0;
+    const bool  kt = e->timing_on;
     // ---- everything the batch puts on its streams. (The HME records and the counters are zero on entry: allocated so,
     // and every picture's last search kernel clears them again.)
     auto enqueue = [&]() -> hipError_t {
@@ -1354,6 +1356,13 @@ extern "C" int svtme_picture_timing(svtme_engine *e, svtme_ticket ticket, float 
     HIP_TRY(hipEventElapsedTime(&ms[6], B.ev[0], B.ev[6]));
     for (int i = 0; i < 7; ++i) ms[i] /= (float)B.n;
     ms[7] = (float)B.n;
+    return SVTME_OK;
+}
+
+extern "C" int svtme_kernel_timing(svtme_engine *e, int on) {
+    if (!e || on < 0 || on > 1) return SVTME_ERR_BAD_ARG;
+    std::lock_guard<std::mutex> lock(e->mu);
+    e->timing_on = on != 0;
     return SVTME_OK;
 }
 

@@ -114,7 +114,7 @@ class Results(C.Structure):
 EXPORTS = ("svtme_version", "svtme_derive_controls", "svtme_derive_tf_controls", "svtme_derive_first_pass_controls",
            "svtme_input_resolution", "svtme_create", "svtme_destroy",
            "svtme_store_put", "svtme_store_release", "svtme_store_read", "svtme_picture_submit", "svtme_picture_wait",
-           "svtme_picture_done", "svtme_picture_timing", "svtme_picture_ops", "svtme_unpack_b64",
+           "svtme_picture_done", "svtme_picture_timing", "svtme_kernel_timing", "svtme_picture_ops", "svtme_unpack_b64",
            "svtme_picture_search_static", "svtme_store_put_pinned", "svtme_store_wait", "svtme_host_register",
            "svtme_host_unregister", "svtme_host_alloc", "svtme_host_free", "svtme_pictures_submit",
            "svtme_group_create", "svtme_group_destroy", "svtme_group_size", "svtme_group_store_put", "svtme_group_store_release",
@@ -211,6 +211,7 @@ def load_library():
     lib.svtme_picture_wait.argtypes = [C.c_void_p, C.c_uint64, C.POINTER(Results)]
     lib.svtme_picture_done.argtypes = [C.c_void_p, C.c_uint64]
     lib.svtme_picture_timing.argtypes = [C.c_void_p, C.c_uint64, C.POINTER(C.c_float * 8)]
+    lib.svtme_kernel_timing.argtypes = [C.c_void_p, C.c_int]
     lib.svtme_picture_ops.argtypes = [C.c_void_p, C.c_uint64, C.POINTER(C.c_uint64 * 6)]
     lib.svtme_unpack_b64.argtypes = [C.POINTER(Results), C.c_uint32] + [C.c_void_p] * 5
     lib.svtme_picture_search_static.argtypes = [C.c_void_p, C.POINTER(Picture), C.c_void_p, C.c_size_t, C.POINTER(Results)]
@@ -715,6 +716,12 @@ class Engine:
         rc = self.lib.svtme_tpl_recon_keep(self.h, key, picture_number)
         if rc:
             raise SvtmeError(rc, "svtme_tpl_recon_keep")
+
+    def kernel_timing(self, on):
+        """Per-kernel events on the submissions that follow: on / off (svtme_kernel_timing)."""
+        rc = self.lib.svtme_kernel_timing(self.h, 1 if on else 0)
+        if rc:
+            raise SvtmeError(rc, "svtme_kernel_timing")
 
     def timing(self, ticket):
         ms = (C.c_float * 8)()

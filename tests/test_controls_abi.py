@@ -50,6 +50,7 @@ def test_bad_arguments_are_rejected_without_touching_a_device():
     assert lib.svtme_tpl_search(None, None, None) == svtme.ERR_BAD_ARG
     assert lib.svtme_tpl_recon(None, None, None, None, None, 0) == svtme.ERR_BAD_ARG
     assert lib.svtme_tpl_recon_keep(None, 0, 0) == svtme.ERR_BAD_ARG
+    assert lib.svtme_kernel_timing(None, 1) == svtme.ERR_BAD_ARG
 
 
 def test_engine_creation_fails_loudly_without_a_gpu():

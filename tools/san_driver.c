@@ -334,6 +334,19 @@ static uint64_t run_extras(uint32_t w, uint32_t h, uint32_t seed, uint64_t hsh) 
         svtme_picture five[5] = {pic[0], pic[1], pic[2], pic[0], pic[1]}; /* more than the engine keeps in flight */
         EXPECT(svtme_pictures_submit(eng, five, 5, t), SVTME_ERR_NO_RESOURCES);
     }
+    /* the per-kernel events switched on for a submission (this engine starts without them) and off again */
+    for (int on = 1; on >= 0; --on) {
+        float ms[8];
+        EXPECT(svtme_kernel_timing(eng, 2), SVTME_ERR_BAD_ARG);
+        CHECK(svtme_kernel_timing(eng, on));
+        CHECK(svtme_pictures_submit(eng, pic, 3, t));
+        for (int i = 0; i < 3; ++i) {
+            CHECK(svtme_picture_wait(eng, t[i], &res));
+            CHECK(svtme_picture_timing(eng, t[i], ms));
+            if ((on ? ms[0] <= 0.f || ms[3] <= 0.f : ms[0] != 0.f || ms[3] != 0.f) || ms[5] <= 0.f) EXPECT(-102 - on, SVTME_OK);
+            CHECK(svtme_picture_done(eng, t[i]));
+        }
+    }
     /* the same picture through the entry point that allocates nothing, results in page-locked memory of ours */
     {
         const size_t n_b64 = (size_t)((w + 63) / 64) * ((h + 63) / 64), bytes = SVTME_STATIC_RESULT_BYTES(n_b64, 3);
