@@ -712,6 +712,16 @@ struct QuickGeo {
     static constexpr int NB  = ((MAXH + 2 * (8 * RPC - 1)) * PR + 63) / 64; // pieces per lane
     static constexpr int WIN = ((MAXH + 2 * (8 * RPC - 1)) * PD + 3) & ~3; // dwords of a staged window (16-byte multiple)
     static_assert(PD - 4 * (PR - 1) == 2, "the last piece of a row is half a piece");
+    // piece index -> row: i / PR as a 24-bit multiplication and a shift, exact for every piece index of a window
+    static constexpr uint32_t ROW_MAGIC = (2048 + PR - 1) / PR;
+    static_assert((uint32_t)(64 * NB) * (ROW_MAGIC * PR - 2048) < 2048, "i * ROW_MAGIC >> 11 == i / PR for i < 64 NB");
+    // (the pieces' addresses as 32-bit offsets from the window's first byte through 24-bit multiplications: full-rate
+    // instructions where a division by a constant, a 64-bit multiply-add and a 32-bit multiplication run at a quarter)
+    static __device__ __forceinline__ void piece(int i, int stride, uint32_t &from, int &at) {
+        const uint32_t r = __umul24((uint32_t)i, ROW_MAGIC) >> 11, c = (uint32_t)i - __umul24(r, (uint32_t)PR);
+        from = __umul24(r, (uint32_t)stride) + 16u * c;
+        at   = (int)(__umul24(r, (uint32_t)PD) + 4u * c) | (c == PR - 1 ? (int)0x80000000 : 0);
+    }
 };
 
 // The window of NQ searches at once: all loads of all windows are issued before the first store, so the NQ windows cost
@@ -732,9 +742,10 @@ __device__ __forceinline__ void quick_stage(uint32_t *win, const DevPlane &ref, 
         const uint8_t *g = ref.pix + (ptrdiff_t)wy[q] * ref.stride + wx[q];
 #pragma unroll
         for (int k = 0; k < G::NB; ++k) {
-            const int i = min(lane + 64 * k, n - 1), r = i / G::PR, c = i - r * G::PR;
-            __builtin_memcpy(&v[q][k], g + (ptrdiff_t)r * ref.stride + 16 * c, 16);
-            at[q][k] = (q * G::WIN + r * G::PD + 4 * c) | (c == G::PR - 1 ? (int)0x80000000 : 0);
+            uint32_t from;
+            G::piece(min(lane + 64 * k, n - 1), ref.stride, from, at[q][k]);
+            __builtin_memcpy(&v[q][k], g + from, 16);
+            at[q][k] += q * G::WIN; // (the flag bit stays: the sum of the low bits is below 2^31)
         }
     }
 #pragma unroll
@@ -759,7 +770,8 @@ __device__ __forceinline__ u64 quick_scan(const uint32_t *src, const uint32_t *w
     constexpr int PD = G::PD, RPC = G::RPC;
     const int     lane = threadIdx.x & 63;
     const int     chunk = lane & 7, q = lane >> 3, xg = q & 1;
-    u64           best = ~0ull;
+    uint32_t      best = ~0u;
+    static_assert(MAXH <= 8 && BWD <= 16, "the 32-bit keys below");
 #pragma unroll
     for (int y0 = 0; y0 < MAXH; y0 += 4) {
         if (y0 >= sa_h) break; // wave-uniform
@@ -783,101 +795,38 @@ __device__ __forceinline__ u64 quick_scan(const uint32_t *src, const uint32_t *w
                 }
             }
         }
+        // the eight chunks' sums meet in every lane of the position quad (the last step through row_half_mirror: lane i
+        // of a half row and lane 7 - i lie in different quads of lanes, which both hold their quad's sum by then)
         uint32_t a32[4];
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             a32[i] = (uint32_t)(a16 >> (16 * i)) & 0xFFFFu;
             a32[i] += quad_xor1(a32[i]);
             a32[i] += quad_xor2(a32[i]);
-            a32[i] += __shfl_xor(a32[i], 4);
+            a32[i] += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)a32[i], 0x141, 0xF, 0xF, false);
         }
+        // 32-bit keys SAD << 6 | y << 3 | x (SAD <= 32 rows x 64 pixels x 255 < 2^20, y and x < 8): they order like the 64-bit ones
         if (active && chunk == 0) {
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const u64 kk = ((u64)a32[i] << 32) | ((uint32_t)yl << 16) | (uint32_t)(xg * 4 + i);
-                best         = kk < best ? kk : best;
-            }
+            for (int i = 0; i < 4; ++i) best = min(best, (a32[i] << 6) | ((uint32_t)yl << 3) | (uint32_t)(xg * 4 + i));
         }
     }
-    return wave_min_u64(best);
+    best = wave_min_u32(best);
+    if (best == ~0u) return ~0ull;
+    return ((u64)(best >> 6) << 32) | (((best >> 3) & 7u) << 16) | (best & 7u);
 }
 
 
 // One such search by itself (a work item per region): the same staging and scan in one piece.
 template <int BWD, int MAXH>
 __device__ u64 quick_search(const uint32_t *src, uint32_t *win, const DevPlane &ref, int rows, int wx, int wy, int sa_h) {
-    constexpr int PD  = BWD + 2; // dwords per staged row: 8 positions + the block width - 1 more pixels, rounded up
-    constexpr int RPC = BWD / 4; // sampled block rows per lane (rows <= 8 RPC); RPC x 4 BWD x 255 fits the 16-bit sums
-    constexpr int PR  = (PD + 3) / 4; // 16-byte pieces per staged row; the last one carries PD - 4 (PR - 1) = 2 dwords
-    constexpr int NB  = ((MAXH + 2 * (8 * RPC - 1)) * PR + 63) / 64;
-    static_assert(PD - 4 * (PR - 1) == 2, "the last piece of a row is half a piece");
-    const int     lane = threadIdx.x & 63;
-    const int     n = (sa_h + 2 * (rows - 1)) * PR;
+    const int wxs[1] = {wx}, wys[1] = {wy}, hs[1] = {sa_h};
     wave_sync();
-    {
-        // piece i = lane + 64 k of the window, 16 bytes in one load (a third of the load instructions of dword loads,
-        // which is what this kernel waits for); indices past the end repeat the last piece (same value, same slot). The
-        // LDS rows stay PD dwords apart (the walk's bank pattern), so a row's last piece stores its first 8 bytes only.
-        const uint8_t *g = ref.pix + (ptrdiff_t)wy * ref.stride + wx;
-        uint4          v[NB];
-        int            at[NB];
-#pragma unroll
-        for (int k = 0; k < NB; ++k) {
-            const int i = min(lane + 64 * k, n - 1), r = i / PR, c = i - r * PR;
-            __builtin_memcpy(&v[k], g + (ptrdiff_t)r * ref.stride + 16 * c, 16);
-            at[k] = (r * PD + 4 * c) | (c == PR - 1 ? (int)0x80000000 : 0);
-        }
-#pragma unroll
-        for (int k = 0; k < NB; ++k) {
-            uint2 *dst = reinterpret_cast<uint2 *>(win + (at[k] & 0x7FFFFFFF)); // (PD is even: 8-byte aligned)
-            dst[0]     = make_uint2(v[k].x, v[k].y);
-            if (at[k] >= 0) dst[1] = make_uint2(v[k].z, v[k].w);
-        }
-    }
+    quick_stage<BWD, MAXH, 1>(win, ref, rows, wxs, wys, hs);
     wave_sync();
-    const int chunk = lane & 7, q = lane >> 3, xg = q & 1;
-    u64       best = ~0ull;
-#pragma unroll
-    for (int y0 = 0; y0 < MAXH; y0 += 4) {
-        if (y0 >= sa_h) break; // wave-uniform
-        const int  yl     = y0 + (q >> 1);
-        const bool active = yl < sa_h;
-        u64        a16 = 0;
-        if (active) {
-#pragma unroll
-            for (int jj = 0; jj < RPC; ++jj) {
-                const int j = jj * 8 + chunk;
-                if (j < rows) {
-                    const uint32_t *rr = win + (yl + 2 * j) * PD + xg;
-                    const uint32_t *ss = src + j * kSrcPitch<false>;
-                    uint32_t        rv[BWD + 1], sv[BWD];
-#pragma unroll
-                    for (int d = 0; d <= BWD; ++d) rv[d] = rr[d];
-#pragma unroll
-                    for (int d = 0; d < BWD; ++d) sv[d] = ss[d];
-#pragma unroll
-                    for (int d = 0; d < BWD; ++d) a16 = __builtin_amdgcn_qsad_pk_u16_u8(((u64)rv[d + 1] << 32) | rv[d], sv[d], a16);
-                }
-            }
-        }
-        uint32_t a32[4];
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            a32[i] = (uint32_t)(a16 >> (16 * i)) & 0xFFFFu;
-            a32[i] += quad_xor1(a32[i]);
-            a32[i] += quad_xor2(a32[i]);
-            a32[i] += __shfl_xor(a32[i], 4);
-        }
-        if (active && chunk == 0) {
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const u64 kk = ((u64)a32[i] << 32) | ((uint32_t)yl << 16) | (uint32_t)(xg * 4 + i);
-                best         = kk < best ? kk : best;
-            }
-        }
-    }
+    const u64 key = quick_scan<BWD, MAXH>(src, win, rows, sa_h);
     wave_sync();
-    return wave_min_u64(best);
+    return key;
 }
 
 // Levels 1 and 2 of region q of reference (l, r), whole wave: first the level-0 result of the region, which gives way

@@ -188,6 +188,19 @@ __device__ __forceinline__ u64 wave_min_u64(u64 v) {
     return ((u64)hi << 32) | lo;
 }
 
+// The same for a 32-bit key: a v_min_u32 with a DPP operand per step.
+__device__ __forceinline__ uint32_t wave_min_u32(uint32_t v) {
+#define SVTME_MIN_STEP(CTRL, ROWS) v = min(v, (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, CTRL, ROWS, 0xF, false));
+    SVTME_MIN_STEP(0xB1, 0xF) // quad_perm [1, 0, 3, 2]
+    SVTME_MIN_STEP(0x4E, 0xF) // quad_perm [2, 3, 0, 1]
+    SVTME_MIN_STEP(0x141, 0xF) // row_half_mirror
+    SVTME_MIN_STEP(0x140, 0xF) // row_mirror
+    SVTME_MIN_STEP(0x142, 0xA) // row_bcast:15 into rows 1 and 3
+    SVTME_MIN_STEP(0x143, 0xC) // row_bcast:31 into rows 2 and 3
+#undef SVTME_MIN_STEP
+    return (uint32_t)__builtin_amdgcn_readlane((int)v, 63);
+}
+
 // The same for a single wave and a block of at most 64 x 32 sampled rows, every other plane row (the zero-MV and
 // search-centre checks of a 64x64 block): lane = one dword column of 8 sampled rows, all loads in flight together, no
 // LDS. Returns the sum in every lane.
