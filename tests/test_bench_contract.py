@@ -44,6 +44,24 @@ def test_committed_bench_lines_keep_the_contract(path):
         check_line(json.loads(f.read().strip().splitlines()[-1]), expect_cpu_baseline=not second_view)
 
 
+def test_full_size_parity_test_submits_what_the_benchmark_submits():
+    """The batches of test_engine_matches_reference_digests_at_full_size are bench.py's (pictures per submit): the parity of
+    the timed configuration cannot drift from the configuration that is timed."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("bench_for_test", os.path.join(ROOT, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    import svtme
+    import test_gpu_parity as t
+    same = {"m3_ra_1920x1080": "1080p_ra_m3", "m8_ra_1920x1080": "1080p_ra_m8", "m12_ldp_1280x720": "720p_ld_m12",
+            "m8_ra_3840x2160": "4k_ra_m8", "m2_ra_7680x4320": "8k_ra_m2"}
+    for case, workload in same.items():
+        wl = bench.WORKLOADS[workload]
+        assert t.BENCH_BATCH[case] == wl["batch"] <= svtme.MAX_BATCH, (case, workload)
+        c = t.MOD.DIGEST_CASES.get(case) or t.MOD.BIG_DIGEST_CASES[case]
+        assert (c["width"], c["height"], c["enc_mode"]) == (wl["width"], wl["height"], wl["enc_mode"]), (case, workload)
+
+
 def test_bench_help_needs_no_gpu():
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--help"], capture_output=True, text=True, timeout=120)
     assert r.returncode == 0 and "--gpus" in r.stdout and "--steps" in r.stdout and "--warmup" in r.stdout
